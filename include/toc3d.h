@@ -1,0 +1,221 @@
+/*
+ * libtoc3d_gfx950 -- C ABI of the MI355X (gfx950) kernels for the ToC3D / EVA-02 ViT backbone hot path.
+ *
+ * The reference (DYZhang09/ToC3D) is 100 % Python on stock torch ops: it has no native operator
+ * interface for this path, so there is nothing like an existing FFI to bind.  Each entry point below
+ * therefore replaces a *reference Python function* (cited as file:line, paths relative to
+ * projects/mmdet3d_plugin/models/) and is what a maintainer would call from that function's body --
+ * see INTEGRATION.md for the ctypes stubs.
+ *
+ * Conventions (all functions):
+ *   - return TOC3D_OK (0) or a negative error code; never throw, never exit; text via toc3d_last_error().
+ *   - the caller owns every buffer (device pointers); no hidden allocation, no hidden synchronisation;
+ *     all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the legacy default stream).
+ *   - the library holds no mutable global state: packed weights and index maps are plain caller-owned
+ *     device buffers, so calls are re-entrant across host threads / streams and capturable in a hipGraph.
+ *   - `dtype` selects the arithmetic type of activations and packed weights: TOC3D_BF16 (bf16 operands on
+ *     v_mfma_f32_16x16x32_bf16, f32 accumulate) or TOC3D_F32 (exact f32 on v_mfma_f32_16x16x4_f32, the
+ *     strict-parity path).  The residual stream, LayerNorm statistics, softmax, scorer and merge weights
+ *     are always f32.
+ *   - "act" buffers are row-major [rows, ld] of `dtype`; K-like dims are padded to multiples of 64
+ *     elements with zeros (e.g. the SwiGLU hidden 2730 -> 2752).
+ *   - the dlopen() of this library creates no HIP context (safe before fork()).
+ */
+#ifndef TOC3D_H_
+#define TOC3D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOC3D_ABI_VERSION 1
+
+#define TOC3D_OK 0
+#define TOC3D_ERR_ARG (-1)
+#define TOC3D_ERR_UNSUPPORTED (-2)
+#define TOC3D_ERR_LAUNCH (-3)
+
+/* dtype */
+#define TOC3D_DTYPE_F32 0
+#define TOC3D_DTYPE_BF16 1
+
+/* toc3d_linear epilogues */
+#define TOC3D_EPI_BIAS 0      /* out(act)  = A.W^T + bias                                            */
+#define TOC3D_EPI_RESIDUAL 1  /* out(f32)  = residual + (A.W^T + bias)        (+ optional raw capture) */
+#define TOC3D_EPI_SWIGLU 2    /* out(act)  = silu(A.W1^T + b1) * (A.W2^T + b2), W packed interleaved   */
+#define TOC3D_EPI_GELU 3      /* out(act)  = gelu_erf(A.W^T + bias)                                    */
+
+typedef void* toc3d_stream_t;
+
+int toc3d_abi_version(void);
+const char* toc3d_last_error(void); /* thread-local, valid until the next failing call on this thread */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Linear layers (MFMA GEMM).  Replaces every F.linear / nn.Linear on the path:
+ *   backbones/eva_vit.py:45-49 (SwiGLU w1,w2,w3), :97-99,115 (q/k/v/proj), toc3d_eva_vit.py:495-497,514,
+ *   backbones/toc3d_utils.py:99-112 (scorer in_conv/out_conv), backbones/eva_utils.py:279-287 (patch conv
+ *   as im2col GEMM), necks/cp_fpn.py:114-135 (1x1 lateral conv).
+ * A [M, lda] act, W [ceil(N/128)*128, ldw] act (toc3d_pack_weight / toc3d_pack_swiglu), bias [N] f32 or NULL.
+ * K must be a multiple of 64 (pad at pack time).  Epilogue-specific arguments:
+ *   RESIDUAL: out f32 [M, ldo]; residual f32 [*, ldr] or NULL; residual row = residual_row_mod > 0 ?
+ *             m % residual_row_mod : m (patch-embed adds abs-pos[m % T]); if rep_period > 0 the rows with
+ *             m % rep_period == rep_period-1 (representative tokens, toc3d_eva_vit.py:452-453) also store
+ *             the raw branch output (A.W^T + bias) to rep_out[(m / rep_period), N] f32.
+ *   SWIGLU:   N = 2*Hp packed columns, out act [M, ldo >= Hp]; hidden units >= n_valid are written as 0.
+ */
+int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                 void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                 float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                 toc3d_stream_t stream);
+
+/* f32 [N, K] state-dict weight -> act [Np, Kp], zero padded (Np multiple of 128, Kp multiple of 64). */
+int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out, int64_t Np, int64_t Kp, toc3d_stream_t stream);
+/* mlp.w1 / mlp.w2 (eva_vit.py:35-36) -> interleaved [2*Hp, Kp] + bias [2*Hp]; packed row 32b+i = w1 row 16b+i,
+ * row 32b+16+i = w2 row 16b+i. */
+int toc3d_pack_swiglu(int dtype, const float* w1, const float* w2, const float* b1, const float* b2, int64_t Hd, int64_t K,
+                      void* out_w, float* out_b, int64_t Hp, int64_t Kp, toc3d_stream_t stream);
+
+/* PatchEmbed input side (backbones/eva_utils.py:283-287): img f32 NCHW [V, Cin, H, W] -> rows
+ * [V*(H/p)*(W/p), ldo] act with column order (ch, py, px) == flattened Conv2d weight. */
+int toc3d_im2col_patches(int dtype, const float* img, void* out, int64_t ldo, int64_t V, int64_t Cin, int64_t H, int64_t W,
+                         int64_t patch, toc3d_stream_t stream);
+
+/* get_abs_pos (backbones/eva_utils.py:229-258): pos f32 [S*S, C] (cls row already dropped) -> out f32 [h*w, C],
+ * bicubic, align_corners=False, A = -0.75 (torch F.interpolate semantics).  Copy if S == h == w. */
+int toc3d_abs_pos_bicubic(const float* pos, int64_t S, int64_t C, float* out, int64_t h, int64_t w, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * LayerNorm.
+ * toc3d_layernorm_rows: Block.norm1 / norm2 (backbones/eva_vit.py:249,263; toc3d_eva_vit.py:372,382) and the
+ *   scorer's in_conv LayerNorm (toc3d_utils.py:100,118-122).  x f32 [*, ldx]; row m reads x[row_index ?
+ *   row_index[m] : m] (index < 0 = all-zero row -> output beta); row_scale (nullable) multiplies the row
+ *   first (token mask, toc3d_utils.py:118).  out act [M, ldo].  One wavefront per row, two-pass variance.
+ * toc3d_layernorm_act: SwiGLU.ffn_ln over the hidden (eva_vit.py:39,48).  x act [M, ldx], n valid columns;
+ *   out act [M, ldo]; columns [n, ldo) are written as zeros (K padding for w3).
+ */
+int toc3d_layernorm_rows(int dtype, const float* x, int64_t ldx, const int32_t* row_index, const float* row_scale,
+                         const float* gamma, const float* beta, float eps, void* out, int64_t ldo, int64_t M, int64_t C,
+                         toc3d_stream_t stream);
+int toc3d_layernorm_act(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* out,
+                        int64_t ldo, int64_t M, int64_t n, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Window geometry for dense blocks: window_partition (backbones/eva_utils.py:89-110) as index maps, no copy.
+ * For V views of h x w tokens and window side L: nW = V*ceil(h/L)*ceil(w/L) windows of N = L*L slots.
+ *   rows  [nW, N] int32: global token row (v*h*w + r*w + c) of the j-th *real* token of the window (slot order)
+ *   slots [nW, N] int32: its slot id sr*L + sc (row of the RoPE table, eva_utils.py:364-371)
+ *   count [nW]: number of real tokens;  npad [nW]: N - count zero-padded slots (keys k=0, v=v_bias)
+ */
+int toc3d_window_map_dense(int64_t V, int64_t h, int64_t w, int64_t L, int32_t* rows, int32_t* slots, int32_t* count,
+                           int32_t* npad, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Windowed multi-head attention with RoPE-by-slot (backbones/eva_vit.py:101-113, toc3d_eva_vit.py:499-512,
+ * backbones/eva_utils.py:378-379,396-403).  head_dim must be 64.
+ * qkv act [*, ldqkv] = [q | k | v] per row (each C wide, head-major); for window i the participating rows are
+ * rows[i*stride + j], j < count[i], with RoPE table rows slots[i*stride + j]; q,k are rotated (pairs 2t,2t+1),
+ * q scaled by `scale` after RoPE, softmax over the window's keys plus npad[i] virtual keys with logit 0 and
+ * value v_bias (NULL npad = none).  out act [*, ldo]: out[row, head*64 + d].  Flash-style, keys streamed in
+ * tiles of 64 through LDS, online softmax in f32.  max_count = max_i count[i] (grid sizing only).
+ */
+int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
+                           const int32_t* slots, const int32_t* count, const int32_t* npad, int64_t stride, int64_t nwin,
+                           int64_t max_count, int64_t num_heads, const float* rope_cos, const float* rope_sin,
+                           const float* v_bias, float scale, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Token selection.
+ * toc3d_rank_desc: ScoreBasedTokenSelector.sample's sort (backbones/toc3d_utils.py:139) with the tie rule pinned
+ *   (descending, equal scores -> lower index first == torch.sort(stable=True)).  scores f32 [B, n] ->
+ *   order int64 [B, n] (order[b, rank] = index).  keep_idx = order[:, :k], drop_idx = order[:, k:].
+ * toc3d_window_topk: the per-window selection of an accelerated block (backbones/toc3d_eva_vit.py:412-438):
+ *   partitions the image-level scores f32 [V, h, w] into windows of side L (pad score -1e6, :415), ranks the
+ *   N = L*L slots of every window, keeps k = int(N*ratio) (computed by the caller) and emits
+ *     order  [nW, N] int32   slot ids, descending-stable; [:k] slow, [k:] fast
+ *     tok    [nW, N] int32   global token row of order[.,j], or -1 for a padded slot
+ *     wgt    [nW, N] f32     merge_tokens weight s_j / sum_{fast} s (toc3d_utils.py:68) for j >= k, 0 for j < k
+ *     arows  [nW, k+1] int32 compact row ids i*(k+1)+j            } attention descriptors of the slow set
+ *     aslots [nW, k+1] int32 RoPE slots: order[., :k] then slot k  } (representative token uses slot k, :434)
+ *     acount [nW] = k+1 (k when k == N)
+ */
+int toc3d_rank_desc(const float* scores, int64_t B, int64_t n, int64_t* order, toc3d_stream_t stream);
+int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int64_t L, int64_t k, int32_t* order,
+                      int32_t* tok, float* wgt, int32_t* arows, int32_t* aslots, int32_t* acount, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Accelerated block front / back end (backbones/toc3d_eva_vit.py:421-430 and :449-467).
+ * toc3d_gather_merge_ln: builds the compact slow set of every window from the residual stream x f32 [V*T, C]:
+ *   rows j < k: copy of token tok[i, j] (zeros for pads) -> shortcut f32 [nW*(k+1), C] and LN1 -> a_out act;
+ *   row  k   : representative token sum_{j>=k} wgt[i,j] * x[tok[i,j]] (batch_index_select + merge_tokens,
+ *              toc3d_utils.py:28-44,65-70), same two outputs.  One launch; merge reduced deterministically.
+ * toc3d_scatter_update: batch_index_fill + window_unpartition (toc3d_utils.py:47-62, eva_utils.py:113-133) done
+ *   in place on x: slow tokens <- slow_out rows; fast tokens += rep_raw1[i] + rep_raw2[i] (:452-456); padded
+ *   slots are dropped.
+ */
+int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, int64_t nW, int64_t N,
+                          int64_t k, const float* gamma, const float* beta, float eps, float* shortcut, void* a_out,
+                          int64_t lda, toc3d_stream_t stream);
+int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, int64_t nW, int64_t N, int64_t k, const float* slow_out,
+                         const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Motion-aware query-guided scorer (backbones/toc3d_utils.py:232-252, 334-360; utils/misc.py:154-200;
+ * utils/positional_encoding.py:14-81).
+ * toc3d_motion_queries: get_motion_aware_queries for B frames x Q queries (query dim 256):
+ *   queries f32 [B,Q,256], ref_points f32 [B,Q,3], vel f32 [B,Q,2], timestamp f64 [B,Q] (timestamp_is_f64=1) or
+ *   f32, ego_pose f32 [B,Q,4,4], ego_pose_inv f32 [B,4,4]; `w` = the scorer's parameters packed by
+ *   toc3d_motion_weights_floats()/toc3d_pack_motion_weights (transposed [in,out] for coalescing; dimt3 [128] and
+ *   dimt1 [256] are the f32 tables temperature ** (2*floor(i/2)/n) of positional_encoding.py:18,32, computed by
+ *   the host with the same torch expression because a 1-ulp change flips sin(2 pi t / dim_t) at epoch-scale t)
+ *   -> out f32 [B,Q,256].
+ *   sin/cos use the accurate range-reduced device functions (f64 for the time embedding), SURVEY quirk 14.
+ * toc3d_collapse_query_scorer: input_proj + einsum + aggregate collapse exactly to a [C,2] matrix per frame:
+ *   Wc = W_in^T (mq^T W_agg^T) * scale, bc = b_in (mq^T W_agg^T) * scale + b_agg.   wc f32 [B, C, 2], bc f32 [B, 2].
+ * toc3d_score_tokens: per token: logits = (x*mask) . Wc + bc; pred = log_softmax(logits); score = pred[0];
+ *   new soft mask = softmax(pred + gumbel)[0] (toc3d_utils.py:147, F.gumbel_softmax tau=1 with injected noise;
+ *   NULL gumbel = zeros).  x f32 [V*T, C]; mask f32 [V*T] or NULL (= ones); views_per_frame maps view -> frame.
+ *   Outputs pred f32 [V*T, 2], score f32 [V*T], mask_out f32 [V*T].
+ */
+int64_t toc3d_motion_weights_floats(void);
+int toc3d_pack_motion_weights(const float* qe0_w, const float* qe0_b, const float* qe2_w, const float* qe2_b,
+                              const float* pe_red_w, const float* pe_red_b, const float* pe_gam_w, const float* pe_gam_b,
+                              const float* pe_bet_w, const float* pe_bet_b, const float* q_red_w, const float* q_red_b,
+                              const float* q_gam_w, const float* q_gam_b, const float* q_bet_w, const float* q_bet_b,
+                              const float* te_w, const float* te_b, const float* te_ln_w, const float* te_ln_b,
+                              const float* pc_range, const float* dimt3, const float* dimt1, float* out,
+                              toc3d_stream_t stream);
+int toc3d_motion_queries(const float* w, const float* queries, const float* ref_points, const float* vel, const void* timestamp,
+                         int timestamp_is_f64, const float* ego_pose, const float* ego_pose_inv, int64_t B, int64_t Q,
+                         float* out, toc3d_stream_t stream);
+int toc3d_collapse_query_scorer(const float* mq, const float* w_in, const float* b_in, const float* w_agg, const float* b_agg,
+                                int64_t B, int64_t Q, int64_t C, float scale, float* wc, float* bc, toc3d_stream_t stream);
+int toc3d_score_tokens(const float* x, int64_t C, const float* mask, const float* wc, const float* bc, const float* gumbel,
+                       int64_t V, int64_t T, int64_t views_per_frame, float* pred, float* score, float* mask_out,
+                       toc3d_stream_t stream);
+
+/* First-frame scorer pieces (ScoreBasedTokenSelector.score, backbones/toc3d_utils.py:114-129): the two big
+ * Linear layers run through toc3d_linear (GELU epilogue); these cover the rest.
+ * toc3d_global_mean_half: t act [V*T, ld]: columns [C/2, C) of every row of a view are replaced by that view's
+ *   mean over tokens (:125-126).  toc3d_score_head: final Linear(256->2)+LogSoftmax (:110-111) fused with the
+ *   Gumbel soft mask; f act [V*T, ld] (K = kdim), w f32 [2, kdim], b f32 [2]; outputs as toc3d_score_tokens. */
+int toc3d_global_mean_half(int dtype, void* t, int64_t ld, int64_t V, int64_t T, int64_t C, toc3d_stream_t stream);
+int toc3d_score_head(int dtype, const void* f, int64_t ld, int64_t kdim, const float* w, const float* b, const float* gumbel,
+                     int64_t M, float* pred, float* score, float* mask_out, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Layout helpers at the module boundary.
+ * toc3d_nhwc_to_nchw: x f32 [V, T, C] -> out f32 [V, C, T] (materialises the reference's permute(0,3,1,2),
+ *   toc3d_eva_vit.py:294, for consumers that need contiguous NCHW).
+ * toc3d_im2col_3x3: CPFPN's 3x3 conv (necks/cp_fpn.py:124-133) as a GEMM: x f32 [V, h, w, C] (NHWC) ->
+ *   rows [V*h*w, 9*C] act with column order (ky, kx, c); the weight is packed to match by the host.
+ */
+int toc3d_nhwc_to_nchw(const float* x, float* out, int64_t V, int64_t T, int64_t C, toc3d_stream_t stream);
+int toc3d_im2col_3x3(int dtype, const float* x, void* out, int64_t ldo, int64_t V, int64_t h, int64_t w, int64_t C,
+                     toc3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOC3D_H_ */

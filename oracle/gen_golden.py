@@ -1,0 +1,240 @@
+"""TEST INFRASTRUCTURE -- generate golden vectors from the REAL reference (build container only).
+
+Usage (from the repo root, in the container that has /root/reference):
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz + *.json
+
+The fixtures are data only (inputs are regenerated from ``toc3d_amd.synth`` by name/seed, so only
+expected outputs are stored).  Each fixture records the synth seed and config name it was made with.
+The reference runs with the two harness patches documented in ``oracle/ref_harness.py`` (stable
+sort, injected Gumbel noise).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from oracle import ref_harness as RH
+from toc3d_amd import configs, synth
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def run_reference_toc3d(cfg, sd, inp, prev_exists, capture_blocks=()):
+    model = RH.build_reference_toc3d(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    caps = {}
+    hooks = []
+    for i in capture_blocks:
+        hooks.append(model.blocks[i].register_forward_hook(lambda m, a, o, i=i: caps.__setitem__(f"block{i}.out", o.detach().clone())))
+    with torch.no_grad(), RH.deterministic_reference(inp["gumbel"]) as calls:
+        out = model(inp["x"], temp_queries=inp["temp_queries"], prev_exists=prev_exists,
+                    temp_ref_points=inp["temp_ref_points"], temp_vel=inp["temp_vel"],
+                    temp_timestamp=inp["temp_timestamp"], temp_ego_pose=inp["temp_ego_pose"],
+                    ego_pose_inv=inp["ego_pose_inv"])
+    for h in hooks:
+        h.remove()
+    assert calls["n_img"] == len(cfg["pruning_loc"]), calls
+    return out, caps, model
+
+
+def gen_state_dict_spec():
+    """Pin ``synth.state_dict_spec`` (names + shapes) against the reference modules' own state_dict()."""
+    res = {}
+    for name in ("toc3d_tiny", "eva_tiny", "toc3d_faster", "eva_dense"):
+        cfg = configs.get(name)
+        model = RH.build_reference_toc3d(cfg) if synth.is_toc3d(cfg) else RH.build_reference_eva(cfg)
+        ref = {k: list(v.shape) for k, v in model.state_dict().items()}
+        mine = {k: list(v) for k, v in synth.state_dict_spec(cfg).items()}
+        assert ref == mine, (name, set(ref) ^ set(mine), [k for k in ref if k in mine and ref[k] != mine[k]])
+        # rope buffers: synth formula must be bit-identical to the reference buffers
+        sd = synth.make_state_dict(cfg) if "tiny" in name else None
+        if sd is not None:
+            for k, v in model.state_dict().items():
+                if "freqs_" in k:
+                    assert torch.equal(v, sd[k]), k
+        res[name] = ref
+        del model
+    with open(os.path.join(OUT, "state_dict_spec.json"), "w") as f:
+        json.dump(res, f, indent=0, sort_keys=True)
+    print("  wrote state_dict_spec.json")
+
+
+def gen_units():
+    """Small full-tensor fixtures for the helper functions on the path (SURVEY.md 8c 'F-unit'/'F-scorer')."""
+    ref = RH.load_reference()
+    U, EU, M, P = ref.toc3d_utils, ref.eva_utils, ref.misc, ref.posenc
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+    # window partition / unpartition incl. pad value -1e6 (eva_utils.py:89-133)
+    x = torch.randn(2, 20, 50, 8, generator=g)
+    for ws in (16, 20):
+        w, pad = EU.window_partition(x, ws)
+        out[f"wp{ws}.in"], out[f"wp{ws}.out"] = _np(x), _np(w)
+        s, _ = EU.window_partition(x[..., :1], ws, pad_value=-1e6)
+        out[f"wp{ws}.score"] = _np(s)
+        out[f"wp{ws}.unpart"] = _np(EU.window_unpartition(w, ws, pad, (20, 50)))
+    # abs pos (eva_utils.py:229-258)
+    pe = torch.randn(1, 197, 16, generator=g)
+    out["abs_pos.in"] = _np(pe)
+    for hw in ((20, 50), (40, 100), (50, 100)):
+        out[f"abs_pos.{hw[0]}x{hw[1]}"] = _np(EU.get_abs_pos(pe, True, hw))
+    # rope tables + application dense and index-selected (eva_utils.py:325-403)
+    import contextlib
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        r16 = EU.VisionRotaryEmbeddingFast(dim=32, pt_seq_len=16, ft_seq_len=16)
+        r20 = EU.VisionRotaryEmbeddingFastWithSelection(dim=32, pt_seq_len=16, ft_seq_len=20)
+    out["rope16.cos"], out["rope16.sin"] = _np(r16.freqs_cos), _np(r16.freqs_sin)
+    out["rope20.cos"], out["rope20.sin"] = _np(r20.freqs_cos), _np(r20.freqs_sin)
+    t = torch.randn(2, 2, 256, 64, generator=g)
+    out["rope16.t"], out["rope16.applied"] = _np(t), _np(r16(t))
+    t2 = torch.randn(2, 2, 37, 64, generator=g)
+    sel = torch.stack([torch.randperm(400, generator=g)[:37] for _ in range(2)])
+    out["rope20.t"], out["rope20.sel"], out["rope20.applied"] = _np(t2), _np(sel), _np(r20(t2, sel))
+    # gather / scatter / merge with -1e6 pads (toc3d_utils.py:28-70)
+    xs = torch.randn(3, 40, 8, generator=g)
+    sc = torch.randn(3, 40, generator=g) - 3.0
+    sc[:, 30:] = -1e6
+    xs[:, 30:] = 0
+    idx1 = torch.stack([torch.randperm(40, generator=g) for _ in range(3)])
+    out["sel.x"], out["sel.idx"] = _np(xs), _np(idx1)
+    out["sel.gather"] = _np(U.batch_index_select(xs, idx1[:, :12]))
+    out["merge.score"] = _np(sc)
+    out["merge.out"] = _np(U.merge_tokens(U.batch_index_select(xs, idx1[:, 12:]), U.batch_index_select(sc, idx1[:, 12:])))
+    out["fill.out"] = _np(U.batch_index_fill(torch.zeros_like(xs), U.batch_index_select(xs, idx1[:, :12]) + 1.0,
+                                             U.batch_index_select(xs, idx1[:, 12:]) - 1.0, idx1[:, :12], idx1[:, 12:]))
+    # positional encodings (positional_encoding.py:14-81), incl. f64 epoch-scale timestamps
+    p3 = torch.rand(2, 5, 3, generator=g)
+    out["pe3d.in"], out["pe3d.out"] = _np(p3), _np(P.pos2posemb3d(p3))
+    ts = torch.tensor([[[0.25], [-1.5e9 - 0.5], [-1.5e9 - 17.0]]], dtype=torch.float64)
+    out["pe1d.in"], out["pe1d.out"] = _np(ts), _np(P.pos2posemb1d(ts))
+    e = torch.cat([torch.randn(1, 3, 2, generator=g), ts.float(), torch.randn(1, 3, 12, generator=g)], -1)
+    out["nerf.in"], out["nerf.out"] = _np(e), _np(P.nerf_positional_encoding(e))
+    # transform_reference_points (misc.py:191-200)
+    inp = synth.make_inputs(configs.get("toc3d_tiny"), hw=(320, 800))
+    out["trp.out"] = _np(M.transform_reference_points(inp["temp_ref_points"], inp["ego_pose_inv"], reverse=False))
+    _save("units", **out)
+
+
+def gen_scorer(cfg_name="toc3d_tiny"):
+    """Scorer stage fixtures: motion-aware queries, both scorers' logits, sample() (toc3d_utils.py:114-158,232-252,334-360)."""
+    cfg = configs.get(cfg_name)
+    sd = synth.make_state_dict(cfg)
+    model = RH.build_reference_toc3d(cfg)
+    model.load_state_dict(sd, strict=True)
+    out = {}
+    for flavour, epoch in (("u01", False), ("epoch", True)):
+        inp = synth.make_inputs(cfg, views_per_frame=2, epoch_timestamps=epoch)
+        sp = model.score_predictor[1]
+        x = torch.from_numpy(synth._rng("scorer/x").standard_normal((2, 20, 50, cfg["embed_dim"]), dtype=np.float32))
+        m = torch.from_numpy(synth._rng("scorer/m").random((2, 20, 50, 1), dtype=np.float32))
+        with torch.no_grad(), RH.deterministic_reference([inp["gumbel"][1]]):
+            mq = sp.get_motion_aware_queries(inp["temp_queries"], inp["temp_ref_points"], inp["temp_vel"],
+                                             inp["temp_timestamp"], inp["temp_ego_pose"], inp["ego_pose_inv"])
+            pred_q = sp.query_based_score(x, m, mq)[0]
+            pred_s = sp.__class__.__mro__[2].score(sp, x, m)          # ScoreBasedTokenSelector.score
+            ks, ds, ki, di, nm = sp.sample(pred_q)
+        out[f"{flavour}.mq"] = _np(mq)
+        out[f"{flavour}.pred_query"] = _np(pred_q)
+        out[f"{flavour}.pred_score"] = _np(pred_s)
+        out[f"{flavour}.keep_idx"], out[f"{flavour}.drop_idx"], out[f"{flavour}.mask"] = _np(ki), _np(di), _np(nm)
+    _save(f"scorer_{cfg_name}", **out)
+
+
+def gen_tiny_e2e():
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    for tag, prev, epoch in (("prev", True, False), ("first", False, False), ("prev_epoch", True, True)):
+        inp = synth.make_inputs(cfg, views_per_frame=2, epoch_timestamps=epoch)
+        out, caps, _ = run_reference_toc3d(cfg, sd, inp, prev, capture_blocks=(2, 3, 8) if tag == "prev" else ())
+        arrs = {"last_feat": _np(out.img_feats["last_feat"])}
+        for s in range(3):
+            arrs[f"token_mask{s}"] = _np(out.token_masks[s])
+            arrs[f"keep_idx{s}"] = _np(out.keep_idx[s])
+            arrs[f"drop_idx{s}"] = _np(out.drop_idx[s])
+        for k, v in caps.items():
+            arrs[k] = _np(v)
+        _save(f"tiny_toc3d_{tag}", **arrs)
+    # dense baseline
+    ecfg = configs.get("eva_tiny")
+    esd = synth.make_state_dict(ecfg)
+    em = RH.build_reference_eva(ecfg)
+    em.load_state_dict(esd, strict=True)
+    inp = synth.make_inputs(ecfg, views_per_frame=2)
+    with torch.no_grad():
+        o = em(inp["x"])
+    _save("tiny_eva", last_feat=_np(o["last_feat"]))
+    # neck on the tiny feature map
+    ncfg = dict(configs.CPFPN_TINY)
+    nsd = synth.neck_state_dict(ncfg)
+    nm = RH.build_reference_cpfpn(ncfg)
+    nm.load_state_dict(nsd, strict=True)
+    with torch.no_grad():
+        n0, n1 = nm([o["last_feat"]])
+    _save("tiny_neck", level0=_np(n0), level1=_np(n1))
+
+
+def gen_vitl(names=("toc3d_faster", "toc3d_fast", "eva_dense"), hw=(320, 800)):
+    """Full-size ViT-L fixtures, stored as every-16th-channel slices + per-view norms (SURVEY.md 8c 'F-L-e2e')."""
+    for name in names:
+        cfg = configs.get(name)
+        t0 = time.time()
+        sd = synth.make_state_dict(cfg)
+        inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
+        if synth.is_toc3d(cfg):
+            out, caps, _ = run_reference_toc3d(cfg, sd, inp, True, capture_blocks=(5, 6, 11, 17))
+            feat = out.img_feats["last_feat"]
+            arrs = {}
+            for s in range(3):
+                arrs[f"keep_idx{s}"] = _np(out.keep_idx[s]).astype(np.int32)
+                arrs[f"token_mask{s}"] = _np(out.token_masks[s]).astype(np.float32)[..., 0]
+            for k, v in caps.items():
+                arrs[k + ".c16"] = _np(v[..., ::16])
+        else:
+            m = RH.build_reference_eva(cfg)
+            m.load_state_dict(sd, strict=True)
+            with torch.no_grad():
+                feat = m(inp["x"])["last_feat"]
+            arrs = {}
+        arrs["last_feat.c16"] = _np(feat[:, ::16])
+        arrs["last_feat.view_l2"] = _np(feat.flatten(1).double().norm(dim=1))
+        arrs["last_feat.token_l2"] = _np(feat.double().norm(dim=1))
+        suffix = "" if hw == (320, 800) else f"_{hw[1]}x{hw[0]}"
+        _save(f"vitl_{name}{suffix}", **arrs)
+        print(f"  {name}: reference forward + weights {time.time() - t0:.1f}s")
+
+
+def main(argv):
+    assert RH.reference_available(), "run in the build container"
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    what = set(argv) or {"spec", "units", "scorer", "tiny", "vitl"}
+    if "spec" in what:
+        gen_state_dict_spec()
+    if "units" in what:
+        gen_units()
+    if "scorer" in what:
+        gen_scorer()
+    if "tiny" in what:
+        gen_tiny_e2e()
+    if "vitl" in what:
+        gen_vitl()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

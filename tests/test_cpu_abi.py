@@ -1,0 +1,81 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/toc3d.h declares, the ctypes
+signatures agree with the header, and the host-side modules mirror the reference interface."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import toc3d_amd
+from toc3d_amd import configs, lib
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(lib.LIB_PATH), "build first: make -C toc3d_amd/csrc"
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    names = lib.header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(dll, n), f"{n} declared in include/toc3d.h but not exported"
+    l = lib.load()
+    assert l.toc3d_abi_version() == 1
+    assert l.toc3d_motion_weights_floats() > 500000
+
+
+def test_ctypes_signatures_match_header():
+    txt = re.sub(r"/\*.*?\*/", "", open(lib.HEADER_PATH).read(), flags=re.S)
+    seen = 0
+    for m in re.finditer(r"\bint\s+(toc3d_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+        name, args = m.group(1), m.group(2)
+        if name == "toc3d_abi_version":
+            continue
+        sig = ""
+        for a in (x.strip() for x in args.split(",")):
+            if "*" in a or "toc3d_stream_t" in a:
+                sig += "p"
+            elif a.startswith("int64_t"):
+                sig += "l"
+            elif a.startswith("int "):
+                sig += "i"
+            elif a.startswith("float "):
+                sig += "f"
+            else:
+                raise AssertionError(f"unparsed parameter {a!r} in {name}")
+        assert lib._SIGS[name] == sig, name
+        seen += 1
+    assert seen == len(lib._SIGS)
+
+
+def test_argument_validation_reports_errors_without_gpu():
+    l = lib.load()
+    rc = l.toc3d_linear(lib.BF16, 0, None, 0, None, 0, None, None, 0, None, 0, 0, None, 0, 4, 4, 64, 0, None)
+    assert rc == -1 and b"null buffer" in l.toc3d_last_error()
+    with pytest.raises(RuntimeError, match="toc3d_rank_desc failed"):
+        lib.call("toc3d_rank_desc", None, 1, 10, None, None)
+
+
+def test_module_surface_matches_reference(golden_dir):
+    spec = json.load(open(os.path.join(golden_dir, "state_dict_spec.json")))
+    for name in ("toc3d_tiny", "eva_tiny"):
+        m = toc3d_amd.build_backbone(configs.get(name))
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == spec[name]
+    m = toc3d_amd.build_backbone(configs.get("toc3d_tiny"))
+    assert m.pruning_loc == [3, 6, 9] and m.pruning_num_queries == 64          # read by Petr3D (petr3d.py:73-74,123)
+    assert set(toc3d_amd.BACKBONES.module_dict) >= {"ToC3DEVAViT", "EVA_ViT"} and "CPFPN" in toc3d_amd.NECKS.module_dict
+    with pytest.raises(AssertionError):                                            # toc3d_eva_vit.py:141-142
+        toc3d_amd.build_backbone(dict(configs.get("toc3d_tiny"), pruning_loc=[2, 6, 9]))
+    with pytest.raises(NotImplementedError):
+        toc3d_amd.build_backbone(dict(configs.get("toc3d_tiny"), use_rel_pos=True))
+    n = toc3d_amd.build_neck(configs.CPFPN_TINY)
+    assert list(n.state_dict()) == ["lateral_convs.0.conv.weight", "lateral_convs.0.conv.bias", "fpn_convs.0.conv.weight", "fpn_convs.0.conv.bias"]
+
+
+def test_no_cpu_fallback():
+    m = toc3d_amd.build_backbone(configs.get("eva_tiny"))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(2, 3, 320, 800))
+    n = toc3d_amd.build_neck(configs.CPFPN_TINY)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        n([torch.zeros(2, 128, 20, 50)])

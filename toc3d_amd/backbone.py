@@ -1,0 +1,642 @@
+"""Drop-in ``ToC3DEVAViT`` / ``EVA_ViT`` backbones whose forward runs on the gfx950 HIP kernels.
+
+Host-side mirror of the reference's backbone interface (same class names, constructor kwargs, forward
+signature, return type and state-dict names):
+
+* ``ToC3DEVAViT``  <- ``projects/mmdet3d_plugin/models/backbones/toc3d_eva_vit.py:25-326``
+* ``EVA_ViT``      <- ``projects/mmdet3d_plugin/models/backbones/eva_vit.py:270-428``
+* ``ToC3DViTReturnType`` <- ``.../backbones/toc3d_utils.py:10-25``
+
+The modules only *hold* parameters (so a reference ``.pth`` loads unchanged) and sequence calls into the
+C ABI (``include/toc3d.h``); no torch op touches activations on the hot path.  PyTorch is used for device
+memory, streams and parameter bookkeeping only.  There is no CPU fallback: a non-CUDA input raises.
+
+Extra (non-reference) constructor kwarg: ``precision`` = ``"bf16"`` (bf16 MFMA operands, f32 accumulate,
+f32 residual stream) or ``"fp32"`` (exact-f32 MFMA, the strict-parity path).
+Extra forward kwarg: ``gumbel_noise`` (list of 3 tensors (B*Nv, T, 2)) to make the stochastic soft mask
+(``toc3d_utils.py:147``) reproducible; when omitted the noise is drawn on the device like the reference does.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import lib
+from .synth import MOTION_DIM, QUERY_DIM, rope_tables
+
+
+class ToC3DViTReturnType:
+    """Same fields as the reference's return type (``toc3d_utils.py:10-25``)."""
+
+    def __init__(self, img_feats=None, token_masks=None, attn_scores=None, keep_idx=None, drop_idx=None,
+                 aux_outputs: list = None) -> None:
+        self.img_feats = img_feats
+        self.token_masks = token_masks
+        self.attn_scores = attn_scores
+        self.keep_idx = keep_idx
+        self.drop_idx = drop_idx
+        self.aux_outputs = aux_outputs
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (reference state-dict naming; forward is never called on them)
+# ------------------------------------------------------------------------------------------------
+class _Rope(nn.Module):
+    def __init__(self, side: int, half_head_dim: int, pt_seq_len: int):
+        super().__init__()
+        cos, sin = rope_tables(side, half_head_dim, pt_seq_len)
+        self.register_buffer("freqs_cos", cos)
+        self.register_buffer("freqs_sin", sin)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, in_chans, embed_dim, patch):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch, stride=patch)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, qkv_bias, rope):
+        super().__init__()
+        self.q_proj = nn.Linear(dim, dim, bias=False)
+        self.k_proj = nn.Linear(dim, dim, bias=False)
+        self.v_proj = nn.Linear(dim, dim, bias=False)
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(dim))
+            self.v_bias = nn.Parameter(torch.zeros(dim))
+        else:
+            self.q_bias = self.v_bias = None
+        self.rope = rope
+        self.proj = nn.Linear(dim, dim)
+
+
+class _SwiGLU(nn.Module):
+    def __init__(self, dim, hidden, norm_layer):
+        super().__init__()
+        self.w1 = nn.Linear(dim, hidden)
+        self.w2 = nn.Linear(dim, hidden)
+        self.ffn_ln = norm_layer(hidden)
+        self.w3 = nn.Linear(hidden, dim)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, mlp_ratio, qkv_bias, norm_layer, rope):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = _Attention(dim, qkv_bias, rope)
+        self.norm2 = norm_layer(dim)
+        self.mlp = _SwiGLU(dim, int(dim * mlp_ratio), norm_layer)
+
+
+class _MLN(nn.Module):
+    """utils/misc.py:154-188 (parameters + its reset_parameters init)."""
+
+    def __init__(self, c_dim, f_dim=QUERY_DIM):
+        super().__init__()
+        self.reduce = nn.Sequential(nn.Linear(c_dim, f_dim), nn.ReLU())
+        self.gamma = nn.Linear(f_dim, f_dim)
+        self.beta = nn.Linear(f_dim, f_dim)
+        nn.init.zeros_(self.gamma.weight)
+        nn.init.zeros_(self.beta.weight)
+        nn.init.ones_(self.gamma.bias)
+        nn.init.zeros_(self.beta.bias)
+
+
+class _Scorer(nn.Module):
+    """MotionAwareQueryGuidedTokenSelector parameters (toc3d_utils.py:99-112,216-224,321-332)."""
+
+    def __init__(self, embed_dim, num_queries, ratio, pc_range):
+        super().__init__()
+        self.ratio = ratio
+        q = QUERY_DIM
+        self.in_conv = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, embed_dim), nn.GELU())
+        self.out_conv = nn.Sequential(nn.Linear(embed_dim, embed_dim // 2), nn.GELU(),
+                                      nn.Linear(embed_dim // 2, embed_dim // 4), nn.GELU(),
+                                      nn.Linear(embed_dim // 4, 2), nn.LogSoftmax(dim=-1))
+        self.input_proj = nn.Sequential(nn.Linear(embed_dim, q))
+        self.aggregate = nn.Sequential(nn.Linear(num_queries, 2), nn.LogSoftmax(dim=-1))
+        self.pc_range = nn.Parameter(torch.tensor(pc_range, dtype=torch.float32), requires_grad=False)
+        self.query_embedding = nn.Sequential(nn.Linear(q * 3 // 2, q), nn.ReLU(), nn.Linear(q, q))
+        self.ego_pose_pe = _MLN(MOTION_DIM)
+        self.ego_pose_queries = _MLN(MOTION_DIM)
+        self.time_embedding = nn.Sequential(nn.Linear(q, q), nn.LayerNorm(q))
+
+
+def _init_weights(m):
+    """toc3d_eva_vit.py:219-228 / eva_vit.py:400-407."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# shared engine: weight packing + per-shape plan + the launch sequence
+# ------------------------------------------------------------------------------------------------
+class _BackboneBase(nn.Module):
+    LN_EPS = 1e-6            # norm_layer=partial(nn.LayerNorm, eps=1e-6), toc3d_eva_vit.py:38
+    SCORER_LN_EPS = 1e-5     # nn.LayerNorm default inside the scorers
+
+    def _setup_common(self, img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias,
+                      use_abs_pos, pt_hw_seq_len, window_size, global_window_size, global_attn_indexes,
+                      pretrain_img_size, pretrain_use_cls_token, out_feature, precision):
+        assert precision in ("bf16", "fp32"), precision
+        if embed_dim // num_heads != 64 or embed_dim % num_heads:
+            raise NotImplementedError("the HIP attention kernel is built for head_dim 64 (EVA-02 L/B/tiny test config)")
+        if embed_dim % 64 or embed_dim > 1024:
+            raise NotImplementedError("embed_dim must be a multiple of 64 and <= 1024")
+        self.precision = precision
+        self.embed_dim, self.depth, self.num_heads = embed_dim, depth, num_heads
+        self.patch_size, self.in_chans = patch_size, in_chans
+        self.window_size, self.global_window_size = window_size, global_window_size
+        self.global_attn_indexes = tuple(global_attn_indexes)
+        self.pretrain_use_cls_token = pretrain_use_cls_token
+        self.hidden_dim = int(embed_dim * mlp_ratio)
+        self.patch_embed = _PatchEmbed(in_chans, embed_dim, patch_size)
+        if use_abs_pos:
+            npatch = (pretrain_img_size // patch_size) ** 2
+            self.pos_embed = nn.Parameter(torch.zeros(1, npatch + (1 if pretrain_use_cls_token else 0), embed_dim))
+        else:
+            self.pos_embed = None
+        half = embed_dim // num_heads // 2
+        self.rope_win = _Rope(window_size, half, pt_hw_seq_len)
+        self.rope_glb = _Rope(img_size // patch_size, half, pt_hw_seq_len)
+        if img_size // patch_size != global_window_size:
+            raise NotImplementedError("global RoPE table side (img_size/patch) must equal global_window_size")
+        self._out_features = [out_feature]
+        self._out_feature_channels = {out_feature: embed_dim}
+        self._out_feature_strides = {out_feature: patch_size}
+        self._packed = None
+        self._plans: Dict[tuple, dict] = {}
+        self.alias_outputs = False      # True: returned tensors alias the reused workspace (benchmarks)
+
+    # -- state-dict hook: re-pack after new weights arrive ------------------------------------------
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    @property
+    def _dt(self):
+        return lib.BF16 if self.precision == "bf16" else lib.F32
+
+    @property
+    def _tdt(self):
+        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+
+    def _block_side(self, i):
+        return self.global_window_size if i in self.global_attn_indexes else self.window_size
+
+    def _pack_linear(self, w: torch.Tensor):
+        """f32 [N, K] -> act [ceil128(N), ceil64(K)] via the C ABI."""
+        w = w.detach().float().contiguous()
+        N, K = w.shape
+        Np, Kp = _round_up(N, 128), _round_up(K, 64)
+        out = torch.empty(Np, Kp, dtype=self._tdt, device=w.device)
+        lib.call("toc3d_pack_weight", self._dt, w, N, K, out, Np, Kp, lib.stream_ptr())
+        return out
+
+    @staticmethod
+    def _f32(t):
+        return t.detach().float().contiguous()
+
+    def _pack_blocks(self, dev):
+        C, Hd = self.embed_dim, self.hidden_dim
+        Hp = _round_up(Hd, 64)
+        blocks = []
+        for blk in self.blocks:
+            a, m = blk.attn, blk.mlp
+            p = {}
+            p["wqkv"] = self._pack_linear(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0))
+            zb = torch.zeros(C, device=dev)
+            qb = a.q_bias if a.q_bias is not None else zb
+            vb = a.v_bias if a.v_bias is not None else zb
+            p["bqkv"] = self._f32(torch.cat([qb, zb, vb]))
+            p["v_bias"] = self._f32(vb)
+            p["wproj"], p["bproj"] = self._pack_linear(a.proj.weight), self._f32(a.proj.bias)
+            w12 = torch.empty(2 * Hp, C, dtype=self._tdt, device=dev)
+            b12 = torch.empty(2 * Hp, dtype=torch.float32, device=dev)
+            lib.call("toc3d_pack_swiglu", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias),
+                     self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
+            p["w12"], p["b12"] = w12, b12
+            p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
+            for n, mod in (("ln1", blk.norm1), ("ln2", blk.norm2), ("lnf", m.ffn_ln)):
+                p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
+            p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
+            blocks.append(p)
+        torch.cuda.current_stream().synchronize()      # the f32 temporaries above must outlive the pack kernels
+        return blocks
+
+    def _pack_common(self):
+        dev = self.patch_embed.proj.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("toc3d_amd backbones run on an AMD GPU through libtoc3d_gfx950.so; there is no CPU path "
+                               "(move the module to cuda)")
+        lib.load()
+        P = {"dev": dev}
+        C = self.embed_dim
+        P["w_patch"] = self._pack_linear(self.patch_embed.proj.weight.reshape(C, -1))
+        P["b_patch"] = self._f32(self.patch_embed.proj.bias)
+        P["blocks"] = self._pack_blocks(dev)
+        return P
+
+    def _pos_for(self, h, w, dev):
+        C = self.embed_dim
+        if self.pos_embed is None:
+            return None
+        pe = self._f32(self.pos_embed[0, 1:] if self.pretrain_use_cls_token else self.pos_embed[0])
+        S = int(math.isqrt(pe.shape[0]))
+        assert S * S == pe.shape[0]
+        out = torch.empty(h * w, C, dtype=torch.float32, device=dev)
+        lib.call("toc3d_abs_pos_bicubic", pe, S, C, out, h, w, lib.stream_ptr())
+        torch.cuda.current_stream().synchronize()
+        return out
+
+    def _dense_map(self, V, h, w, L, dev):
+        nW = V * (-(-h // L)) * (-(-w // L))
+        N = L * L
+        d = {"rows": torch.empty(nW, N, dtype=torch.int32, device=dev), "slots": torch.empty(nW, N, dtype=torch.int32, device=dev),
+             "count": torch.empty(nW, dtype=torch.int32, device=dev), "npad": torch.empty(nW, dtype=torch.int32, device=dev),
+             "nW": nW, "N": N, "max_count": min(N, min(L, h) * min(L, w))}
+        lib.call("toc3d_window_map_dense", V, h, w, L, d["rows"], d["slots"], d["count"], d["npad"], lib.stream_ptr())
+        return d
+
+    def _base_plan(self, V, H, W, dev, max_rows):
+        C, Hp = self.embed_dim, _round_up(self.hidden_dim, 64)
+        p = self.patch_size
+        h, w = H // p, W // p
+        T, M = h * w, V * h * w
+        R = max(M, max_rows)
+        tdt = self._tdt
+        Kc = self.in_chans * p * p
+        plan = dict(V=V, h=h, w=w, T=T, M=M,
+                    x=torch.empty(M, C, dtype=torch.float32, device=dev),
+                    a=torch.empty(R, C, dtype=tdt, device=dev),
+                    qkv=torch.empty(R, 3 * C, dtype=tdt, device=dev),
+                    att=torch.empty(R, C, dtype=tdt, device=dev),
+                    hid=torch.zeros(R, Hp, dtype=tdt, device=dev),
+                    hln=torch.zeros(R, Hp, dtype=tdt, device=dev),
+                    col=torch.zeros(M, _round_up(Kc, 64), dtype=tdt, device=dev),
+                    pos=self._pos_for(h, w, dev), Kc=Kc)
+        plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
+        return plan
+
+    # -- launch sequences -----------------------------------------------------------------------------
+    def _stem(self, plan, img, P):
+        """PatchEmbed + abs-pos add (toc3d_eva_vit.py:243-247) -> residual stream x f32 [V*T, C]."""
+        s = lib.stream_ptr()
+        C, V = self.embed_dim, plan["V"]
+        H, W = img.shape[2], img.shape[3]
+        Kp = plan["col"].shape[1]
+        lib.call("toc3d_im2col_patches", self._dt, img, plan["col"], Kp, V, self.in_chans, H, W, self.patch_size, s)
+        lib.call("toc3d_linear", self._dt, lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
+                 plan["x"], C, plan["pos"], C, plan["T"] if plan["pos"] is not None else 0, None, 0, plan["M"], C, Kp, 0, s)
+
+    def _mlp(self, bp, plan, rows, res, rep_out, rep_period):
+        """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
+        s = lib.stream_ptr()
+        C, Hd = self.embed_dim, self.hidden_dim
+        Hp = plan["hid"].shape[1]
+        dt = self._dt
+        lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
+        lib.call("toc3d_linear", dt, lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, 0,
+                 rows, 2 * Hp, C, Hd, s)
+        lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
+        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,
+                 rep_out, rep_period, rows, C, Hp, 0, s)
+
+    def _dense_block(self, i, plan, P):
+        """Block.forward (eva_vit.py:247-268): LN -> window attention (pads folded analytically) -> +res; MLP -> +res."""
+        s = lib.stream_ptr()
+        bp = P["blocks"][i]
+        C, M, dt = self.embed_dim, plan["M"], self._dt
+        x = plan["x"]
+        dm = plan["dense"][self._block_side(i)]
+        lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
+        lib.call("toc3d_linear", dt, lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, 0,
+                 M, 3 * C, C, 0, s)
+        lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], dm["npad"],
+                 dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["v_bias"], 64 ** -0.5, s)
+        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, 0, M, C, C, 0, s)
+        self._mlp(bp, plan, M, x, None, 0)
+
+    def _check_input(self, x):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise RuntimeError("toc3d_amd: input must be a CUDA/HIP tensor -- the HIP extension is the only compute path "
+                               "(no CPU fallback)")
+        if x.dim() != 4 or x.shape[1] != self.in_chans or x.shape[2] % self.patch_size or x.shape[3] % self.patch_size:
+            raise ValueError(f"expected (B*Nv, {self.in_chans}, H, W) with H, W multiples of {self.patch_size}, got {tuple(x.shape)}")
+        return x.float().contiguous()
+
+    def _feature_view(self, plan):
+        x = plan["x"] if self.alias_outputs else plan["x"].clone()
+        return x.view(plan["V"], plan["h"], plan["w"], self.embed_dim).permute(0, 3, 1, 2)   # NCHW view of NHWC (:294)
+
+    def output_shape(self):
+        return {n: dict(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]) for n in self._out_features}
+
+
+class EVA_ViT(_BackboneBase):
+    """Dense EVA-02 ViT (StreamPETR baseline backbone), reference ``eva_vit.py:270-428``."""
+
+    def __init__(self, img_size=1024, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4 * 2 / 3,
+                 qkv_bias=True, drop_path_rate=0.0, norm_layer=partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU,
+                 use_abs_pos=True, use_rel_pos=False, rope=True, pt_hw_seq_len=16, intp_freq=True, window_size=0,
+                 global_window_size=20, use_checkpoint=True, global_attn_indexes=(), residual_block_indexes=(),
+                 use_act_checkpoint=False, pretrain_img_size=224, pretrain_use_cls_token=True, return_intermediate=False,
+                 out_feature="last_feat", xattn=True, precision="bf16", **unused):
+        super().__init__()
+        if use_rel_pos or len(residual_block_indexes) or return_intermediate or not rope or not intp_freq or window_size <= 0:
+            raise NotImplementedError("use_rel_pos / residual blocks / return_intermediate / rope=False / window_size=0 "
+                                      "are dead code for the shipped configs and not built")
+        self._setup_common(img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, use_abs_pos,
+                           pt_hw_seq_len, window_size, global_window_size, global_attn_indexes, pretrain_img_size,
+                           pretrain_use_cls_token, out_feature, precision)
+        self.blocks = nn.ModuleList([
+            _Block(embed_dim, mlp_ratio, qkv_bias, partial(nn.LayerNorm, eps=1e-6),
+                   self.rope_glb if i in self.global_attn_indexes else self.rope_win) for i in range(depth)])
+        if self.pos_embed is not None:
+            nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        self.apply(_init_weights)
+
+    @torch.no_grad()
+    def forward(self, x, *args, **kwargs):
+        x = self._check_input(x)
+        if self._packed is None:
+            self._packed = self._pack_common()
+        key = tuple(x.shape)
+        if key not in self._plans:
+            self._plans[key] = self._base_plan(x.shape[0], x.shape[2], x.shape[3], x.device, 0)
+        plan, P = self._plans[key], self._packed
+        self._stem(plan, x, P)
+        for i in range(self.depth):
+            self._dense_block(i, plan, P)
+        return {self._out_features[0]: self._feature_view(plan)}
+
+
+class ToC3DEVAViT(_BackboneBase):
+    """EVA-02 ViT with ToC3D motion-query-guided token compression, reference ``toc3d_eva_vit.py:25-326``."""
+
+    def __init__(self, img_size=1024, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4 * 2 / 3,
+                 qkv_bias=True, drop_path_rate=0.0, norm_layer=partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU,
+                 use_abs_pos=True, use_rel_pos=False, rope=True, rope_acc=False, pt_hw_seq_len=16, intp_freq=True,
+                 window_size=0, global_window_size=20, use_checkpoint=True, global_attn_indexes=(), residual_block_indexes=(),
+                 use_act_checkpoint=False, pretrain_img_size=224, pretrain_use_cls_token=True, out_feature="last_feat",
+                 return_intermediate=False, xattn=True, pruning_loc=None, pruning_score_type="attention", score_mask=True,
+                 pruning_attn_scale=True, pruning_num_queries=256, accelerate_global=True, token_ratio=None,
+                 use_represent_tokens=True, pc_range=None, token_selection_loss=None, precision="bf16", **unused):
+        super().__init__()
+        if (use_rel_pos or len(residual_block_indexes) or return_intermediate or not rope or not rope_acc or not intp_freq
+                or pruning_score_type != "attention" or not score_mask or not use_represent_tokens or window_size <= 0):
+            raise NotImplementedError("only the shipped ToC3D configuration family is built: rope + rope_acc, "
+                                      "pruning_score_type='attention', score_mask, use_represent_tokens")
+        pruning_loc = list(pruning_loc or [])
+        assert token_ratio is not None and len(token_ratio) == len(pruning_loc)
+        assert len(set(pruning_loc) & set(global_attn_indexes)) == 0, \
+            "The pruning score calculation layer cannot be the global attention layer"          # toc3d_eva_vit.py:141-142
+        assert pc_range is not None
+        if any(not (0.0 < r < 1.0) for r in token_ratio):
+            raise NotImplementedError("token_ratio must be in (0, 1): ratio 1.0 makes the reference return permuted tokens "
+                                      "(toc3d_eva_vit.py:463); use EVA_ViT for the dense baseline")
+        self._setup_common(img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, use_abs_pos,
+                           pt_hw_seq_len, window_size, global_window_size, global_attn_indexes, pretrain_img_size,
+                           pretrain_use_cls_token, out_feature, precision)
+        self.pruning_loc = pruning_loc
+        self.pruning_num_queries = pruning_num_queries
+        self.pruning_attn_scale = pruning_attn_scale
+        self.accelerate_global = accelerate_global
+        self.token_ratio = list(token_ratio)
+        self.use_represent_tokens = use_represent_tokens
+        self.token_selection_loss = None                 # training-only (TokenSelectionLoss); inference build
+        half = embed_dim // num_heads // 2
+        self.score_predictor = nn.ModuleList([_Scorer(embed_dim, pruning_num_queries, token_ratio[i], pc_range)
+                                              for i in range(len(pruning_loc))])
+        self.rope_win_acc = _Rope(window_size, half, pt_hw_seq_len)
+        self.rope_glb_acc = _Rope(img_size // patch_size, half, pt_hw_seq_len)
+        self.blocks = nn.ModuleList()
+        for i in range(depth):
+            glb = i in self.global_attn_indexes
+            if self._accelerated(i):
+                r = self.rope_glb_acc if glb else self.rope_win_acc
+            else:
+                r = self.rope_glb if glb else self.rope_win
+            self.blocks.append(_Block(embed_dim, mlp_ratio, qkv_bias, partial(nn.LayerNorm, eps=1e-6), r))
+        if self.pos_embed is not None:
+            nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        self.apply(_init_weights)                        # like the reference (:217) this also re-inits the MLN gamma/beta Linears
+
+    def _accelerated(self, i):                           # toc3d_eva_vit.py:178-180
+        return len(self.pruning_loc) > 0 and i >= self.pruning_loc[0] and (self.accelerate_global or i not in self.global_attn_indexes)
+
+    def loss(self, *a, **k):
+        raise NotImplementedError("training-only: TokenSelectionLoss is outside the inference hot path")
+
+    # -- packing -------------------------------------------------------------------------------------
+    def _pack(self):
+        P = self._pack_common()
+        dev = P["dev"]
+        s = lib.stream_ptr()
+        nfl = lib.load().toc3d_motion_weights_floats()
+        # positional_encoding.py:18,32 -- same torch expression as the reference, evaluated on the host
+        d3 = torch.arange(128, dtype=torch.float32)
+        d3 = (10000 ** (2 * torch.div(d3, 2, rounding_mode="floor") / 128)).to(dev)
+        d1 = torch.arange(256, dtype=torch.float32)
+        d1 = (10000 ** (2 * torch.div(d1, 2, rounding_mode="floor") / 256)).to(dev)
+        f = self._f32
+        P["scorers"] = []
+        keep = []
+        for sp in self.score_predictor:
+            q = {}
+            mw = torch.empty(nfl, dtype=torch.float32, device=dev)
+            srcs = [f(sp.query_embedding[0].weight), f(sp.query_embedding[0].bias), f(sp.query_embedding[2].weight), f(sp.query_embedding[2].bias)]
+            for mln in (sp.ego_pose_pe, sp.ego_pose_queries):
+                srcs += [f(mln.reduce[0].weight), f(mln.reduce[0].bias), f(mln.gamma.weight), f(mln.gamma.bias), f(mln.beta.weight), f(mln.beta.bias)]
+            srcs += [f(sp.time_embedding[0].weight), f(sp.time_embedding[0].bias), f(sp.time_embedding[1].weight), f(sp.time_embedding[1].bias),
+                     f(sp.pc_range), d3, d1]
+            keep.append(srcs)
+            lib.call("toc3d_pack_motion_weights", *srcs, mw, s)
+            q["motion"] = mw
+            q["w_in"], q["b_in"] = f(sp.input_proj[0].weight), f(sp.input_proj[0].bias)
+            q["w_agg"], q["b_agg"] = f(sp.aggregate[0].weight), f(sp.aggregate[0].bias)
+            q["scale"] = QUERY_DIM ** -0.5 if self.pruning_attn_scale else 1.0
+            # first-frame scorer (ScoreBasedTokenSelector.score)
+            q["ln_w"], q["ln_b"] = f(sp.in_conv[0].weight), f(sp.in_conv[0].bias)
+            q["w_ic"], q["b_ic"] = self._pack_linear(sp.in_conv[1].weight), f(sp.in_conv[1].bias)
+            q["w_o0"], q["b_o0"] = self._pack_linear(sp.out_conv[0].weight), f(sp.out_conv[0].bias)
+            q["w_o2"], q["b_o2"] = self._pack_linear(sp.out_conv[2].weight), f(sp.out_conv[2].bias)
+            q["w_o4"], q["b_o4"] = f(sp.out_conv[4].weight), f(sp.out_conv[4].bias)
+            P["scorers"].append(q)
+        torch.cuda.current_stream().synchronize()
+        return P
+
+    def _plan(self, V, H, W, B, dev):
+        C = self.embed_dim
+        p = self.patch_size
+        h, w = H // p, W // p
+        sel_geo = {}
+        max_rows, max_nw = 0, 0
+        for L in {self.window_size, self.global_window_size}:
+            nW = V * (-(-h // L)) * (-(-w // L))
+            max_nw = max(max_nw, nW)
+            for st, r in enumerate(self.token_ratio):
+                k = int(L * L * r)                        # toc3d_utils.py:138
+                sel_geo[(st, L)] = (nW, L * L, k)
+                max_rows = max(max_rows, nW * (k + 1))
+        plan = self._base_plan(V, H, W, dev, max_rows)
+        T, M = plan["T"], plan["M"]
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        plan["B"] = B
+        plan["slow"] = torch.empty(max_rows, C, **f32)
+        plan["rep1"] = torch.empty(max_nw, C, **f32)
+        plan["rep2"] = torch.empty(max_nw, C, **f32)
+        plan["sel"] = {}
+        for key, (nW, N, k) in sel_geo.items():
+            plan["sel"][key] = dict(nW=nW, N=N, k=k, order=torch.empty(nW, N, **i32), tok=torch.empty(nW, N, **i32),
+                                    wgt=torch.empty(nW, N, **f32), arows=torch.empty(nW, k + 1, **i32),
+                                    aslots=torch.empty(nW, k + 1, **i32), acount=torch.empty(nW, **i32))
+        Q = self.pruning_num_queries
+        plan["mq"] = torch.empty(B, Q, QUERY_DIM, **f32)
+        plan["wc"] = torch.empty(B, C, 2, **f32)
+        plan["bc"] = torch.empty(B, 2, **f32)
+        ns = len(self.pruning_loc)
+        plan["pred"] = [torch.empty(M, 2, **f32) for _ in range(ns)]
+        plan["score"] = [torch.empty(M, **f32) for _ in range(ns)]
+        plan["mask"] = [torch.empty(M, **f32) for _ in range(ns)]
+        plan["order"] = [torch.empty(V, T, dtype=torch.int64, device=dev) for _ in range(ns)]
+        plan["u1"] = plan["u2"] = None                    # first-frame scorer scratch, allocated on demand
+        return plan
+
+    # -- scorer stage (toc3d_eva_vit.py:264-285) -------------------------------------------------------
+    def _score_stage(self, st, plan, P, inputs, prev_exists, gumbel):
+        s = lib.stream_ptr()
+        q = P["scorers"][st]
+        C, dt = self.embed_dim, self._dt
+        V, T, M, B = plan["V"], plan["T"], plan["M"], plan["B"]
+        x = plan["x"]
+        mask_prev = plan["mask"][st - 1] if st > 0 else None        # masks start as ones (:251), replaced per stage (:266)
+        g = gumbel[st] if gumbel is not None else None
+        pred, score, mask = plan["pred"][st], plan["score"][st], plan["mask"][st]
+        if prev_exists:
+            tq, rp, vel, ts, pose, inv = inputs
+            Q = tq.shape[1]
+            lib.call("toc3d_motion_queries", q["motion"], tq, rp, vel, ts, 1 if ts.dtype == torch.float64 else 0, pose, inv, B, Q, plan["mq"], s)
+            lib.call("toc3d_collapse_query_scorer", plan["mq"], q["w_in"], q["b_in"], q["w_agg"], q["b_agg"], B, Q, C, float(q["scale"]),
+                     plan["wc"], plan["bc"], s)
+            lib.call("toc3d_score_tokens", x, C, mask_prev, plan["wc"], plan["bc"], g, V, T, V // B, pred, score, mask, s)
+        else:
+            # ScoreBasedTokenSelector.score (toc3d_utils.py:114-129); the reference also evaluates the motion-aware
+            # queries here and discards them (:376-385) -- skipped, no observable effect
+            if plan["u1"] is None:
+                plan["u1"] = torch.zeros(M, max(64, C // 2), dtype=self._tdt, device=x.device)
+                plan["u2"] = torch.zeros(M, max(64, C // 4), dtype=self._tdt, device=x.device)
+            t_act, u1, u2 = plan["att"], plan["u1"], plan["u2"]
+            lib.call("toc3d_layernorm_rows", dt, x, C, None, mask_prev, q["ln_w"], q["ln_b"], self.SCORER_LN_EPS, plan["a"], C, M, C, s)
+            lib.call("toc3d_linear", dt, lib.EPI_GELU, plan["a"], C, q["w_ic"], q["w_ic"].shape[1], q["b_ic"], t_act, C, None, 0, 0, None, 0, M, C, C, 0, s)
+            lib.call("toc3d_global_mean_half", dt, t_act, C, V, T, C, s)
+            lib.call("toc3d_linear", dt, lib.EPI_GELU, t_act, C, q["w_o0"], q["w_o0"].shape[1], q["b_o0"], u1, u1.shape[1], None, 0, 0, None, 0,
+                     M, C // 2, C, 0, s)
+            lib.call("toc3d_linear", dt, lib.EPI_GELU, u1, u1.shape[1], q["w_o2"], q["w_o2"].shape[1], q["b_o2"], u2, u2.shape[1], None, 0, 0, None, 0,
+                     M, C // 4, q["w_o2"].shape[1], 0, s)
+            lib.call("toc3d_score_head", dt, u2, u2.shape[1], C // 4, q["w_o4"], q["b_o4"], g, M, pred, score, mask, s)
+        lib.call("toc3d_rank_desc", score, V, T, plan["order"][st], s)
+        for L in {self.window_size, self.global_window_size}:
+            sel = plan["sel"][(st, L)]
+            lib.call("toc3d_window_topk", score, V, plan["h"], plan["w"], L, sel["k"], sel["order"], sel["tok"], sel["wgt"], sel["arows"],
+                     sel["aslots"], sel["acount"], s)
+
+    def _accel_block(self, i, st, plan, P):
+        """ToC3DEVAViTBlock.forward (toc3d_eva_vit.py:395-477)."""
+        s = lib.stream_ptr()
+        bp = P["blocks"][i]
+        C, dt = self.embed_dim, self._dt
+        sel = plan["sel"][(st, self._block_side(i))]
+        nW, N, k = sel["nW"], sel["N"], sel["k"]
+        rows = nW * (k + 1)
+        slow = plan["slow"]
+        lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], nW, N, k, bp["ln1_w"], bp["ln1_b"], self.LN_EPS,
+                 slow, plan["a"], C, s)
+        lib.call("toc3d_linear", dt, lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, 0,
+                 rows, 3 * C, C, 0, s)
+        lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount"], None,
+                 k + 1, nW, k + 1, self.num_heads, bp["cos"], bp["sin"], None, 64 ** -0.5, s)
+        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0,
+                 plan["rep1"], k + 1, rows, C, C, 0, s)
+        self._mlp(bp, plan, rows, slow, plan["rep2"], k + 1)
+        lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], nW, N, k, slow, plan["rep1"], plan["rep2"], s)
+
+    @torch.no_grad()
+    def forward(self, x, temp_queries=None, prev_exists=None, temp_ref_points=None, temp_vel=None, temp_timestamp=None,
+                temp_ego_pose=None, ego_pose_inv=None, *args, gumbel_noise=None, **kwargs):
+        x = self._check_input(x)
+        if self._packed is None:
+            self._packed = self._pack()
+        P = self._packed
+        dev = x.device
+        V = x.shape[0]
+        prev = bool(prev_exists.bool().flatten()[0].item()) if isinstance(prev_exists, torch.Tensor) else bool(prev_exists)
+        inputs = None
+        B = 1
+        if temp_queries is not None:
+            B = temp_queries.shape[0]
+        if prev:
+            assert temp_queries is not None and ego_pose_inv is not None, "prev_exists=True needs the memory-bank tensors"
+            f = lambda t: t.to(dev).float().contiguous()
+            ts = temp_timestamp.to(dev)
+            ts = ts.contiguous() if ts.dtype == torch.float64 else ts.float().contiguous()
+            inputs = (f(temp_queries), f(temp_ref_points), f(temp_vel), ts, f(temp_ego_pose), f(ego_pose_inv))
+        assert V % B == 0
+        key = (tuple(x.shape), B)
+        if key not in self._plans:
+            self._plans[key] = self._plan(V, x.shape[2], x.shape[3], B, dev)
+        plan = self._plans[key]
+        T = plan["T"]
+        ns = len(self.pruning_loc)
+        if gumbel_noise is None:
+            # F.gumbel_softmax's own sampling (-log of Exp(1) draws), toc3d_utils.py:147
+            gumbel = [-torch.empty(V * T, 2, device=dev, dtype=torch.float32).exponential_().log() for _ in range(ns)]
+        else:
+            gumbel = [g.to(dev).float().reshape(V * T, 2).contiguous() for g in gumbel_noise]
+
+        self._stem(plan, x, P)
+        st = -1
+        for i in range(self.depth):
+            if i in self.pruning_loc:
+                st += 1
+                self._score_stage(st, plan, P, inputs, prev, gumbel)
+            if self._accelerated(i):
+                self._accel_block(i, st, plan, P)
+            else:
+                self._dense_block(i, plan, P)
+
+        h, w = plan["h"], plan["w"]
+        cl = (lambda t: t) if self.alias_outputs else (lambda t: t.clone())
+        masks = [cl(plan["mask"][s]).view(V, h, w, 1) for s in range(ns)]
+        keep, drop = [], []
+        for s in range(ns):
+            kimg = int(T * self.token_ratio[s])
+            order = cl(plan["order"][s])
+            keep.append(order[:, :kimg])
+            drop.append(order[:, kimg:])
+        return ToC3DViTReturnType({self._out_features[0]: self._feature_view(plan)}, masks or None, None,
+                                  keep_idx=keep or None, drop_idx=drop or None, aux_outputs=None)

@@ -1,0 +1,112 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the ToC3D backbone hot path.
+// Wavefront = 64 lanes everywhere; MFMA fragments follow the 16x16 shapes:
+//   bf16: v_mfma_f32_16x16x32_bf16   (A/B: 8 consecutive K elements per lane, lane = (row|col) + 16*kgroup)
+//   f32 : v_mfma_f32_16x16x4_f32     (A/B: 1 element per lane, k = lane>>4), issued 8x per 32-wide K step
+// Both element types use the same "8 consecutive K elements per lane" fragment so one tile loader /
+// LDS layout serves the bf16 (throughput) and f32 (strict-parity) instantiations: the K order inside
+// a step is permuted identically for A and B, which leaves the dot product unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define TOC3D_DEV __device__ __forceinline__
+
+enum { TOC3D_F32 = 0, TOC3D_BF16 = 1 };
+
+// ---- element traits -------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 v; };
+template <> struct Frag<float> { f32x4 lo, hi; };
+
+template <typename T> TOC3D_DEV T to_act(float x);
+template <> TOC3D_DEV float to_act<float>(float x) { return x; }
+template <> TOC3D_DEV bf16_t to_act<bf16_t>(float x) { return (bf16_t)x; }   // RNE, lowers to v_cvt_pk_bf16_f32
+
+TOC3D_DEV float from_act(float x) { return x; }
+TOC3D_DEV float from_act(bf16_t x) { return (float)x; }
+
+// 8 consecutive elements <-> 8 floats (16-byte aligned for bf16, 32-byte for f32)
+TOC3D_DEV void load8(const float* p, float (&o)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+TOC3D_DEV void load8(const bf16_t* p, float (&o)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)a[i];
+}
+TOC3D_DEV void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+TOC3D_DEV void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+TOC3D_DEV Frag<float> make_frag(const float (&v)[8], float) {
+    Frag<float> f; f.lo = f32x4{v[0], v[1], v[2], v[3]}; f.hi = f32x4{v[4], v[5], v[6], v[7]}; return f;
+}
+TOC3D_DEV Frag<bf16_t> make_frag(const float (&v)[8], bf16_t) {
+    Frag<bf16_t> f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.v[i] = (bf16_t)v[i];
+    return f;
+}
+// read a fragment (8 consecutive elements) from LDS/global at a 16-byte aligned address
+TOC3D_DEV Frag<bf16_t> read_frag(const bf16_t* p) { Frag<bf16_t> f; f.v = *reinterpret_cast<const bf16x8*>(p); return f; }
+TOC3D_DEV Frag<float> read_frag(const float* p) {
+    Frag<float> f; f.lo = *reinterpret_cast<const f32x4*>(p); f.hi = *reinterpret_cast<const f32x4*>(p + 4); return f;
+}
+
+// one 32-wide K step of a 16x16 output tile
+TOC3D_DEV void mma_step(f32x4& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+TOC3D_DEV void mma_step(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[s], b.lo[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[s], b.hi[s], acc, 0, 0, 0);
+}
+
+// ---- wave / block reductions ----------------------------------------------------------------------
+TOC3D_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+TOC3D_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce across the 16 lanes that share lane>>4 (one MFMA C-row group)
+TOC3D_DEV float row16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+TOC3D_DEV float row16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md T1): blocks that land on one XCD
+// (bid % 8) get a contiguous chunk of work ids so neighbouring tiles share that XCD's L2.
+TOC3D_DEV int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    if (nwg < nx) return bid;
+    int xcd = bid % nx, idx = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

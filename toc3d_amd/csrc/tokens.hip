@@ -1,0 +1,445 @@
+// Token-level (HBM-bound) kernels of the ToC3D backbone: LayerNorm, per-window top-k ranking with index
+// compaction in LDS, gather + merge + LayerNorm of the kept set, scatter back (gfx950).
+//
+// Reference: Block.norm1/norm2 (backbones/eva_vit.py:249,263; toc3d_eva_vit.py:372,382), SwiGLU.ffn_ln
+// (eva_vit.py:48), ScoreBasedTokenSelector.sample (backbones/toc3d_utils.py:131-143), window_partition with
+// pad -1e6 (toc3d_eva_vit.py:412-415), batch_index_select / merge_tokens / batch_index_fill
+// (toc3d_utils.py:28-70), fast-token update (toc3d_eva_vit.py:449-467).
+//
+// All arithmetic is f32; rows are moved with 16-byte accesses, one wavefront (64 lanes) per token row.
+#include "capi.h"
+#include "common.h"
+
+namespace {
+
+constexpr float PAD_SCORE = -1.0e6f;        // toc3d_eva_vit.py:415
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm of one row held by one wavefront.  v[i] = float4 #(lane + 64 i) of the row (nvec valid).
+// Two-pass statistics (mean, then centred variance), biased variance, like torch.nn.LayerNorm.
+// ---------------------------------------------------------------------------------------------------
+template <int MAXV>
+TOC3D_DEV void wave_ln_stats(const f32x4 (&v)[MAXV], int nvec, int lane, int C, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nvec) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nvec) {
+            const float d0 = v[i][0] - mean, d1 = v[i][1] - mean, d2 = v[i][2] - mean, d3 = v[i][3] - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+}
+
+template <typename T> TOC3D_DEV void store4(T* p, f32x4 v);
+template <> TOC3D_DEV void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> TOC3D_DEV void store4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 b;
+    b[0] = (bf16_t)v[0]; b[1] = (bf16_t)v[1]; b[2] = (bf16_t)v[2]; b[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = b;
+}
+
+template <typename T, int MAXV>
+TOC3D_DEV void wave_ln_write(const f32x4 (&v)[MAXV], int nvec, int lane, float mean, float rstd, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, T* __restrict__ out) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * vi);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 4 * vi);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+            store4<T>(out + 4 * vi, y);
+        }
+    }
+}
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ row_index,
+                                                      const float* __restrict__ row_scale, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, T* __restrict__ out, int64_t ldo,
+                                                      int M, int C) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int src = row_index ? row_index[row] : row;
+    const float sc = (row_scale && src >= 0) ? row_scale[src] : 1.f;
+    const int nvec = C >> 2;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vi < nvec && src >= 0) {
+            v[i] = *reinterpret_cast<const f32x4*>(x + (int64_t)src * ldx + 4 * vi);
+            if (row_scale) v[i] *= sc;
+        }
+    }
+    float mean, rstd;
+    wave_ln_stats<MAXV>(v, nvec, lane, C, eps, mean, rstd);
+    wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, out + (int64_t)row * ldo);
+}
+
+// LayerNorm over an act row with n valid columns of ld (ffn_ln over the SwiGLU hidden): chunks of 8 elements.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void ln_act_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ out, int64_t ldo,
+                                                     int M, int n) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int nch = (int)(ldo >> 3);
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ci = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        if (ci < nch && ci * 8 < n) {
+            load8(x + (int64_t)row * ldx + ci * 8, v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (ci * 8 + e >= n) v[i][e] = 0.f;
+                s += v[i][e];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ci = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (ci < nch && ci * 8 + e < n) { const float d = v[i][e] - mean; q += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ci = lane + 64 * i;
+        if (ci < nch) {
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = ci * 8 + e;
+                y[e] = c < n ? (v[i][e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+            }
+            store8(out + (int64_t)row * ldo + ci * 8, y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ranking.  rank_j = #{i : s_i > s_j  or (s_i == s_j and i < j)}  == position of j in a stable descending sort.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rank_desc_kernel(const float* __restrict__ scores, int n, int64_t* __restrict__ order) {
+    extern __shared__ float s_sc[];
+    const int b = blockIdx.y;
+    const float* sc = scores + (int64_t)b * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_sc[i] = sc[i];
+    __syncthreads();
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float sj = s_sc[j];
+    int rank = 0;
+    for (int i = 0; i < n; ++i) {
+        const float si = s_sc[i];
+        rank += (si > sj || (si == sj && i < j)) ? 1 : 0;
+    }
+    order[(int64_t)b * n + rank] = j;
+}
+
+__global__ __launch_bounds__(256) void window_topk_kernel(const float* __restrict__ scores, int V, int h, int w, int L, int k,
+                                                          int32_t* __restrict__ order, int32_t* __restrict__ tok, float* __restrict__ wgt,
+                                                          int32_t* __restrict__ arows, int32_t* __restrict__ aslots, int32_t* __restrict__ acount) {
+    extern __shared__ char s_raw[];
+    const int N = L * L;
+    float* s_sc = reinterpret_cast<float*>(s_raw);              // [N] score by slot
+    int32_t* s_tok = reinterpret_cast<int32_t*>(s_sc + N);       // [N] token row by slot
+    int32_t* s_ord = s_tok + N;                                  // [N] slot by rank
+    float* s_red = reinterpret_cast<float*>(s_ord + N);          // [4] wave partials
+    const int nWh = (h + L - 1) / L, nWw = (w + L - 1) / L;
+    const int win = blockIdx.x;
+    const int v = win / (nWh * nWw), wr = (win / nWw) % nWh, wc = win % nWw;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const int r = wr * L + j / L, c = wc * L + j % L;
+        const bool real = r < h && c < w;
+        const int t = (v * h + r) * w + c;
+        s_sc[j] = real ? scores[t] : PAD_SCORE;
+        s_tok[j] = real ? t : -1;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const float sj = s_sc[j];
+        int rank = 0;
+        for (int i = 0; i < N; ++i) {
+            const float si = s_sc[i];
+            rank += (si > sj || (si == sj && i < j)) ? 1 : 0;
+        }
+        s_ord[rank] = j;
+    }
+    __syncthreads();
+    // denominator of merge_tokens: sum of the fast (dropped) scores, pads included (toc3d_utils.py:68)
+    float part = 0.f;
+    for (int p = k + threadIdx.x; p < N; p += blockDim.x) part += s_sc[s_ord[p]];
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float denom = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    const int kk = k < N ? k + 1 : k;
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        const int slot = s_ord[p];
+        order[(int64_t)win * N + p] = slot;
+        tok[(int64_t)win * N + p] = s_tok[slot];
+        wgt[(int64_t)win * N + p] = p >= k ? s_sc[slot] / denom : 0.f;
+    }
+    for (int j = threadIdx.x; j < kk; j += blockDim.x) {
+        arows[(int64_t)win * kk + j] = win * kk + j;
+        aslots[(int64_t)win * kk + j] = j < k ? s_ord[j] : k;     // representative token -> slot k (toc3d_eva_vit.py:434)
+    }
+    if (threadIdx.x == 0) acount[win] = kk;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gather + merge + LN1.  1024-thread workgroups (16 waves):
+//   blocks [0, nW)           : representative token of window i (only when k < N): 16 waves stride over the
+//                              fast set, LDS tree (fixed order -> deterministic), wave 0 normalises it;
+//   blocks [nW, nW + ceil(nW*k/16)) : one wave per kept row: copy + LayerNorm.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __restrict__ x, int C, const int32_t* __restrict__ tok,
+                                                               const float* __restrict__ wgt, int nW, int N, int k,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               float* __restrict__ shortcut, T* __restrict__ a_out, int64_t lda) {
+    extern __shared__ __attribute__((aligned(16))) float s_part[];        // [16][C]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nvec = C >> 2;
+    const bool has_rep = k < N;
+    const int kk = has_rep ? k + 1 : k;
+    const int rep_blocks = has_rep ? nW : 0;
+    if ((int)blockIdx.x < rep_blocks) {
+        const int win = blockIdx.x;
+        f32x4 acc[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = k + wave; p < N; p += 16) {
+            const int src = tok[(int64_t)win * N + p];
+            if (src < 0) continue;                       // padded slot: x = 0 contributes nothing (its weight is in the denominator)
+            const float wg = wgt[(int64_t)win * N + p];
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int vi = lane + 64 * i;
+                if (vi < nvec) acc[i] += wg * *reinterpret_cast<const f32x4*>(x + (int64_t)src * C + 4 * vi);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) *reinterpret_cast<f32x4*>(s_part + (int64_t)wave * C + 4 * vi) = acc[i];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 1024) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 16; ++wv) s += s_part[wv * C + c];
+            s_part[c] = s;                               // column c of partial 0 is only read by this thread
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        f32x4 v[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            v[i] = vi < nvec ? *reinterpret_cast<const f32x4*>(s_part + 4 * vi) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int64_t orow = (int64_t)win * kk + k;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) *reinterpret_cast<f32x4*>(shortcut + orow * C + 4 * vi) = v[i];
+        }
+        float mean, rstd;
+        wave_ln_stats<MAXV>(v, nvec, lane, C, eps, mean, rstd);
+        wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
+        return;
+    }
+    const int64_t id = (int64_t)(blockIdx.x - rep_blocks) * 16 + wave;
+    if (id >= (int64_t)nW * k) return;
+    const int win = (int)(id / k), j = (int)(id % k);
+    const int src = tok[(int64_t)win * N + j];
+    const int64_t orow = (int64_t)win * kk + j;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vi < nvec) {
+            if (src >= 0) v[i] = *reinterpret_cast<const f32x4*>(x + (int64_t)src * C + 4 * vi);
+            *reinterpret_cast<f32x4*>(shortcut + orow * C + 4 * vi) = v[i];
+        }
+    }
+    float mean, rstd;
+    wave_ln_stats<MAXV>(v, nvec, lane, C, eps, mean, rstd);
+    wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
+}
+
+// scatter the slow rows back and add the representative token's branch outputs to the fast rows, in place.
+__global__ __launch_bounds__(256) void scatter_update_kernel(float* __restrict__ x, int C, const int32_t* __restrict__ tok, int nW, int N, int k,
+                                                             const float* __restrict__ slow_out, const float* __restrict__ r1,
+                                                             const float* __restrict__ r2) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    if (id >= (int64_t)nW * N) return;
+    const int win = (int)(id / N), p = (int)(id % N);
+    const int dst = tok[id];
+    if (dst < 0) return;
+    const int kk = k < N ? k + 1 : k;
+    const int nvec = C >> 2;
+    float* xr = x + (int64_t)dst * C;
+    if (p < k) {
+        const float* s = slow_out + ((int64_t)win * kk + p) * C;
+        for (int vi = lane; vi < nvec; vi += 64) *reinterpret_cast<f32x4*>(xr + 4 * vi) = *reinterpret_cast<const f32x4*>(s + 4 * vi);
+    } else {
+        const float* a = r1 + (int64_t)win * C;
+        const float* b = r2 + (int64_t)win * C;
+        for (int vi = lane; vi < nvec; vi += 64) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * vi);
+            v = (v + *reinterpret_cast<const f32x4*>(a + 4 * vi)) + *reinterpret_cast<const f32x4*>(b + 4 * vi);   // toc3d_eva_vit.py:454-456
+            *reinterpret_cast<f32x4*>(xr + 4 * vi) = v;
+        }
+    }
+}
+
+// [V, T, C] -> [V, C, T] through a 32x32 LDS tile (materialised permute(0,3,1,2), toc3d_eva_vit.py:294)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C) {
+    __shared__ float tile[32][33];
+    const int v = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        tile[i][tx] = (t < T && c < C) ? x[((int64_t)v * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        if (t < T && c < C) out[((int64_t)v * C + c) * T + t] = tile[tx][i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int toc3d_layernorm_rows(int dtype, const float* x, int64_t ldx, const int32_t* row_index, const float* row_scale,
+                         const float* gamma, const float* beta, float eps, void* out, int64_t ldo, int64_t M, int64_t C,
+                         toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && gamma && beta && out, "toc3d_layernorm_rows: null buffer");
+    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 2048, "toc3d_layernorm_rows: C=%lld must be a multiple of 4 and <= 2048", (long long)C);
+    TOC3D_REQUIRE(ldx >= C && ldo >= C && ldx % 4 == 0 && ldo % 4 == 0, "toc3d_layernorm_rows: bad leading dims");
+    if (M <= 0) return TOC3D_OK;
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    hipStream_t s = as_stream(stream);
+#define LNR(T, MV) hipLaunchKernelGGL((ln_rows_kernel<T, MV>), grid, block, 0, s, x, ldx, row_index, row_scale, gamma, beta, eps, (T*)out, ldo, (int)M, (int)C)
+    if (dtype == TOC3D_BF16) { if (C <= 1024) LNR(bf16_t, 4); else LNR(bf16_t, 8); }
+    else if (dtype == TOC3D_F32) { if (C <= 1024) LNR(float, 4); else LNR(float, 8); }
+    else { toc3d_set_error("toc3d_layernorm_rows: bad dtype"); return TOC3D_ERR_ARG; }
+#undef LNR
+    TOC3D_LAUNCH_CHECK("toc3d_layernorm_rows");
+    return TOC3D_OK;
+}
+
+int toc3d_layernorm_act(int dtype, const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* out,
+                        int64_t ldo, int64_t M, int64_t n, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && gamma && beta && out, "toc3d_layernorm_act: null buffer");
+    TOC3D_REQUIRE(n > 0 && ldo % 8 == 0 && ldx % 8 == 0 && ldo >= n && ldx >= ldo, "toc3d_layernorm_act: need n <= ldo <= ldx, multiples of 8");
+    TOC3D_REQUIRE(ldo <= 64 * 8 * 12, "toc3d_layernorm_act: row too long (%lld > 6144)", (long long)ldo);
+    if (M <= 0) return TOC3D_OK;
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    hipStream_t s = as_stream(stream);
+#define LNA(T, MC) hipLaunchKernelGGL((ln_act_kernel<T, MC>), grid, block, 0, s, (const T*)x, ldx, gamma, beta, eps, (T*)out, ldo, (int)M, (int)n)
+    const int mc = (int)((ldo / 8 + 63) / 64);
+    if (dtype == TOC3D_BF16) { if (mc <= 2) LNA(bf16_t, 2); else if (mc <= 6) LNA(bf16_t, 6); else LNA(bf16_t, 12); }
+    else if (dtype == TOC3D_F32) { if (mc <= 2) LNA(float, 2); else if (mc <= 6) LNA(float, 6); else LNA(float, 12); }
+    else { toc3d_set_error("toc3d_layernorm_act: bad dtype"); return TOC3D_ERR_ARG; }
+#undef LNA
+    TOC3D_LAUNCH_CHECK("toc3d_layernorm_act");
+    return TOC3D_OK;
+}
+
+int toc3d_rank_desc(const float* scores, int64_t B, int64_t n, int64_t* order, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(scores && order, "toc3d_rank_desc: null buffer");
+    TOC3D_REQUIRE(n >= 0 && n <= 16000, "toc3d_rank_desc: n=%lld exceeds the LDS-resident limit 16000", (long long)n);
+    if (B <= 0 || n == 0) return TOC3D_OK;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(rank_desc_kernel, grid, dim3(256), (size_t)n * 4, as_stream(stream), scores, (int)n, order);
+    TOC3D_LAUNCH_CHECK("toc3d_rank_desc");
+    return TOC3D_OK;
+}
+
+int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int64_t L, int64_t k, int32_t* order,
+                      int32_t* tok, float* wgt, int32_t* arows, int32_t* aslots, int32_t* acount, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(scores && order && tok && wgt && arows && aslots && acount, "toc3d_window_topk: null buffer");
+    TOC3D_REQUIRE(V > 0 && h > 0 && w > 0 && L > 0 && L <= 64, "toc3d_window_topk: bad dims");
+    const int64_t N = L * L;
+    TOC3D_REQUIRE(k >= 0 && k <= N, "toc3d_window_topk: k=%lld outside [0, %lld]", (long long)k, (long long)N);
+    const int nW = (int)(V * ((h + L - 1) / L) * ((w + L - 1) / L));
+    hipLaunchKernelGGL(window_topk_kernel, dim3(nW), dim3(256), (size_t)N * 12 + 16, as_stream(stream), scores, (int)V, (int)h, (int)w,
+                       (int)L, (int)k, order, tok, wgt, arows, aslots, acount);
+    TOC3D_LAUNCH_CHECK("toc3d_window_topk");
+    return TOC3D_OK;
+}
+
+int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, int64_t nW, int64_t N,
+                          int64_t k, const float* gamma, const float* beta, float eps, float* shortcut, void* a_out,
+                          int64_t lda, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && tok && wgt && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln: null buffer");
+    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
+    TOC3D_REQUIRE(k >= 0 && k <= N && lda >= C && lda % 4 == 0, "toc3d_gather_merge_ln: bad k / lda");
+    if (nW <= 0) return TOC3D_OK;
+    const int rep_blocks = k < N ? (int)nW : 0;
+    const int row_blocks = (int)((nW * k + 15) / 16);
+    if (rep_blocks + row_blocks == 0) return TOC3D_OK;
+    dim3 grid((unsigned)(rep_blocks + row_blocks)), block(1024);
+    const size_t lds = (size_t)16 * C * 4;
+    hipStream_t s = as_stream(stream);
+    if (dtype == TOC3D_BF16) {
+        static bool set = false;
+        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_merge_ln_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); set = true; }
+        hipLaunchKernelGGL((gather_merge_ln_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, (int)nW, (int)N, (int)k, gamma, beta, eps, shortcut, (bf16_t*)a_out, lda);
+    } else if (dtype == TOC3D_F32) {
+        static bool set = false;
+        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_merge_ln_kernel<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); set = true; }
+        hipLaunchKernelGGL((gather_merge_ln_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, (int)nW, (int)N, (int)k, gamma, beta, eps, shortcut, (float*)a_out, lda);
+    } else { toc3d_set_error("toc3d_gather_merge_ln: bad dtype"); return TOC3D_ERR_ARG; }
+    TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln");
+    return TOC3D_OK;
+}
+
+int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, int64_t nW, int64_t N, int64_t k, const float* slow_out,
+                         const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && tok && slow_out, "toc3d_scatter_update: null buffer");
+    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && k >= 0 && k <= N, "toc3d_scatter_update: bad dims");
+    TOC3D_REQUIRE(k == N || (rep_raw1 && rep_raw2), "toc3d_scatter_update: representative-token deltas missing");
+    if (nW <= 0 || N <= 0) return TOC3D_OK;
+    dim3 grid((unsigned)((nW * N + 3) / 4));
+    hipLaunchKernelGGL(scatter_update_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)C, tok, (int)nW, (int)N, (int)k, slow_out, rep_raw1, rep_raw2);
+    TOC3D_LAUNCH_CHECK("toc3d_scatter_update");
+    return TOC3D_OK;
+}
+
+int toc3d_nhwc_to_nchw(const float* x, float* out, int64_t V, int64_t T, int64_t C, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && out && V > 0 && T > 0 && C > 0, "toc3d_nhwc_to_nchw: bad arguments");
+    dim3 grid((unsigned)((T + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)V);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(stream), x, out, (int)T, (int)C);
+    TOC3D_LAUNCH_CHECK("toc3d_nhwc_to_nchw");
+    return TOC3D_OK;
+}
+
+}  // extern "C"

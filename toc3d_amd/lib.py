@@ -1,0 +1,98 @@
+"""ctypes binding of ``libtoc3d_gfx950.so`` (the C ABI declared in ``include/toc3d.h``).
+
+There is deliberately no fallback: if the shared library is missing the import of any compute entry
+point raises, so a GPU box can never silently run a CPU / eager path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtoc3d_gfx950.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU = 0, 1, 2, 3
+
+_P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes, in header order.  'p' pointer, 'l' int64, 'i' int, 'f' float
+_SIGS = {
+    "toc3d_linear": "iiplplpplpllplllllp",
+    "toc3d_pack_weight": "ipllpllp",
+    "toc3d_pack_swiglu": "ippppllppllp",
+    "toc3d_im2col_patches": "ippllllllp",
+    "toc3d_abs_pos_bicubic": "pllpllp",
+    "toc3d_layernorm_rows": "iplppppfplllp",
+    "toc3d_layernorm_act": "iplppfplllp",
+    "toc3d_window_map_dense": "llllppppp",
+    "toc3d_window_attention": "iplplppppllllpppfp",
+    "toc3d_rank_desc": "pllpp",
+    "toc3d_window_topk": "plllllppppppp",
+    "toc3d_gather_merge_ln": "iplpplllppfpplp",
+    "toc3d_scatter_update": "plplllpppp",
+    "toc3d_pack_motion_weights": "p" * 24 + "p",
+    "toc3d_motion_queries": "pppppippllpp",
+    "toc3d_collapse_query_scorer": "ppppplllfppp",
+    "toc3d_score_tokens": "plpppplllpppp",
+    "toc3d_global_mean_half": "ipllllp",
+    "toc3d_score_head": "ipllppplpppp",
+    "toc3d_nhwc_to_nchw": "pplllp",
+    "toc3d_im2col_3x3": "ipplllllp",
+}
+_CT = {"p": _P, "l": _I64, "i": _I, "f": _F}
+
+_lib = None
+
+
+def header_functions():
+    """Names of all functions declared in include/toc3d.h (used by the symbol-export test)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(toc3d_\w+)\s*\(", txt)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C toc3d_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.toc3d_abi_version.restype = _I
+    lib.toc3d_last_error.restype = ctypes.c_char_p
+    lib.toc3d_motion_weights_floats.restype = _I64
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = _I
+        fn.argtypes = [_CT[c] for c in sig]
+    if lib.toc3d_abi_version() != 1:
+        raise RuntimeError("libtoc3d_gfx950.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _conv(a):
+    import torch
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+def call(name: str, *args):
+    """Invoke a C-ABI entry point; tensors are passed as device pointers; raises on a non-zero return."""
+    lib = load()
+    rc = getattr(lib, name)(*[_conv(a) for a in args])
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.toc3d_last_error().decode()}")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

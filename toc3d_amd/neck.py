@@ -1,0 +1,114 @@
+"""Drop-in ``CPFPN`` neck (reference ``projects/mmdet3d_plugin/models/necks/cp_fpn.py:16-208``) on the HIP kernels.
+
+Built for the configuration every shipped config uses (``ToC3D_faster.py:70-74``): one input level,
+``num_outs=2``, no norm / activation, no extra convs: 1x1 lateral conv -> 3x3 conv (pad 1) -> stride-2
+subsample as the extra level.  Both convs run as MFMA GEMMs on the NHWC buffer the backbone already holds
+(no permute); the output is materialised as contiguous NCHW f32 because ``Petr3D.extract_img_feat`` calls
+``.view(B, N, C, H, W)`` on it (``petr3d.py:239``).  State-dict names follow mmcv's ConvModule
+(``lateral_convs.0.conv.weight`` ...).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import lib
+from .backbone import _round_up
+
+
+class _ConvModule(nn.Module):
+    def __init__(self, cin, cout, k, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding)
+
+
+class CPFPN(nn.Module):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 upsample_cfg=dict(mode="nearest"), init_cfg=None, precision="bf16", **unused):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        if (len(in_channels) != 1 or start_level != 0 or end_level != -1 or add_extra_convs or norm_cfg is not None
+                or act_cfg is not None or conv_cfg is not None or num_outs not in (1, 2)):
+            raise NotImplementedError("CPFPN is built for the shipped single-level configuration (in_channels=[C], num_outs<=2)")
+        assert precision in ("bf16", "fp32")
+        self.in_channels, self.out_channels, self.num_outs = in_channels, out_channels, num_outs
+        self.precision = precision
+        self.fp16_enabled = False
+        self.lateral_convs = nn.ModuleList([_ConvModule(in_channels[0], out_channels, 1)])
+        self.fpn_convs = nn.ModuleList([_ConvModule(out_channels, out_channels, 3, padding=1)])
+        for m in self.modules():                                    # init_cfg Xavier uniform (cp_fpn.py:80-81)
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.zeros_(m.bias)
+        self._packed = None
+        self._ws = {}
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._ws = {}
+        return super()._apply(fn, *a, **k)
+
+    def _pack(self, dev):
+        dt = lib.BF16 if self.precision == "bf16" else lib.F32
+        tdt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        s = lib.stream_ptr()
+
+        def pack(w2d):
+            w2d = w2d.detach().float().contiguous()
+            N, K = w2d.shape
+            out = torch.empty(_round_up(N, 128), _round_up(K, 64), dtype=tdt, device=dev)
+            lib.call("toc3d_pack_weight", dt, w2d, N, K, out, out.shape[0], out.shape[1], s)
+            return out
+
+        lw = self.lateral_convs[0].conv
+        fw = self.fpn_convs[0].conv
+        P = dict(dt=dt, tdt=tdt,
+                 w_lat=pack(lw.weight.reshape(self.out_channels, -1)), b_lat=lw.bias.detach().float().contiguous(),
+                 # (Cout, Cin, ky, kx) -> (Cout, ky, kx, Cin) to match toc3d_im2col_3x3's column order
+                 w_fpn=pack(fw.weight.permute(0, 2, 3, 1).reshape(self.out_channels, -1)), b_fpn=fw.bias.detach().float().contiguous())
+        torch.cuda.current_stream().synchronize()
+        return P
+
+    @torch.no_grad()
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        feat = inputs[0]
+        if not feat.is_cuda:
+            raise RuntimeError("toc3d_amd.CPFPN: input must be a CUDA/HIP tensor (no CPU fallback)")
+        V, Cin, h, w = feat.shape
+        nhwc = feat.permute(0, 2, 3, 1)
+        nhwc = nhwc if nhwc.is_contiguous() else nhwc.contiguous()      # zero-copy when fed by the toc3d_amd backbone
+        nhwc = nhwc.float()
+        dev = feat.device
+        if self._packed is None:
+            self._packed = self._pack(dev)
+        P = self._packed
+        dt, tdt = P["dt"], P["tdt"]
+        M, Co = V * h * w, self.out_channels
+        key = (V, h, w)
+        if key not in self._ws:
+            Kl, Kf = P["w_lat"].shape[1], P["w_fpn"].shape[1]
+            self._ws[key] = dict(a=torch.zeros(M, Kl, dtype=tdt, device=dev), lat=torch.empty(M, Co, dtype=torch.float32, device=dev),
+                                 col=torch.zeros(M, Kf, dtype=tdt, device=dev), o0=torch.empty(M, Co, dtype=torch.float32, device=dev))
+        ws = self._ws[key]
+        s = lib.stream_ptr()
+        Kl, Kf = ws["a"].shape[1], ws["col"].shape[1]
+        if dt == lib.F32 and Kl == Cin:
+            a = nhwc.reshape(M, Cin)
+        else:
+            a = ws["a"]
+            lib.call("toc3d_pack_weight", dt, nhwc, M, Cin, a, M, Kl, s)           # f32 -> act conversion with K padding
+        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, 0, M, Co, Kl, 0, s)
+        lib.call("toc3d_im2col_3x3", dt, ws["lat"], ws["col"], Kf, V, h, w, Co, s)
+        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, ws["col"], Kf, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, 0, M, Co, Kf, 0, s)
+        out0 = torch.empty(V, Co, h, w, dtype=torch.float32, device=dev)
+        lib.call("toc3d_nhwc_to_nchw", ws["o0"], out0, V, h * w, Co, s)
+        outs = [out0]
+        if self.num_outs > 1:
+            outs.append(out0[:, :, ::2, ::2])          # F.max_pool2d(k=1, stride=2) == strided subsample (cp_fpn.py:187)
+        return tuple(outs)

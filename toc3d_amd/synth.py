@@ -1,0 +1,245 @@
+"""Deterministic synthetic weights and inputs, keyed by tensor name.
+
+There is no network in the build/bench environment (no checkpoints, no nuScenes), so the
+benchmark and the parity fixtures use random-init weights of the reference architecture.
+Every tensor is drawn from ``numpy.random.Generator(Philox(key=crc32(name) ^ seed))`` so the
+golden-vector generator (build container, runs the real reference) and the tests / bench
+(GPU box) regenerate bit-identical values without shipping gigabytes.
+
+State-dict names and shapes follow the reference modules:
+``toc3d_eva_vit.py:96-206`` (backbone), ``eva_vit.py:35-40,72-84,216-233`` (block),
+``toc3d_utils.py:99-112,216-224,321-332`` (scorers), ``misc.py:161-173`` (MLN),
+``cp_fpn.py:114-135`` (neck).
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+QUERY_DIM = 256           # toc3d_utils.py:198 (query_dim default, never overridden)
+MOTION_DIM = 180          # toc3d_utils.py:327  MLN(180): 15 ego-motion scalars x 6 freqs x (sin, cos)
+
+
+def _rng(name: str, seed: int = 0) -> np.random.Generator:
+    key = (zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF
+    return np.random.Generator(np.random.Philox(key=key))
+
+
+def rope_tables(window_side: int, half_head_dim: int = 32, pt_seq_len: int = 16, theta: float = 10000.0):
+    """cos/sin tables of VisionRotaryEmbeddingFast (``eva_utils.py:341,364-371``): shape (L*L, 2*half_head_dim).
+
+    Built with torch ops in the same order as the reference so the buffers are bit-identical.
+    """
+    dim = half_head_dim
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    t = torch.arange(window_side) / window_side * pt_seq_len
+    f = t[:, None] * freqs[None, :]                      # einsum('..., f -> ... f')
+    f = f.repeat_interleave(2, dim=-1)                   # repeat '... n -> ... (n r)', r=2
+    L = window_side
+    full = torch.cat([f[:, None, :].expand(L, L, dim), f[None, :, :].expand(L, L, dim)], dim=-1)
+    return full.cos().reshape(-1, 2 * dim), full.sin().reshape(-1, 2 * dim)
+
+
+def hidden_dim(cfg) -> int:
+    return int(cfg["embed_dim"] * cfg.get("mlp_ratio", 4 * 2 / 3))   # eva_vit.py:230
+
+
+def is_toc3d(cfg) -> bool:
+    return cfg.get("type", "ToC3DEVAViT") == "ToC3DEVAViT"
+
+
+def state_dict_spec(cfg) -> "OrderedDict[str, tuple]":
+    """name -> shape for the backbone described by ``cfg`` (reference naming)."""
+    C = cfg["embed_dim"]
+    Hd = hidden_dim(cfg)
+    p = cfg.get("patch_size", 16)
+    pre = cfg.get("pretrain_img_size", 224) // p
+    npos = pre * pre + (1 if cfg.get("pretrain_use_cls_token", True) else 0)
+    hd = C // cfg["num_heads"]
+    Lw = cfg["window_size"]
+    Lg = cfg["img_size"] // p
+    spec = OrderedDict()
+    spec["pos_embed"] = (1, npos, C)
+    spec["patch_embed.proj.weight"] = (C, cfg.get("in_chans", 3), p, p)
+    spec["patch_embed.proj.bias"] = (C,)
+    ropes = ["rope_win", "rope_glb"]
+    if is_toc3d(cfg) and cfg.get("rope_acc", False):
+        ropes += ["rope_win_acc", "rope_glb_acc"]
+    for r in ropes:
+        L = Lw if "win" in r else Lg
+        spec[f"{r}.freqs_cos"] = (L * L, hd)
+        spec[f"{r}.freqs_sin"] = (L * L, hd)
+    for i in range(cfg["depth"]):
+        b = f"blocks.{i}."
+        L = Lg if i in cfg["global_attn_indexes"] else Lw
+        for n in ("norm1", "norm2"):
+            spec[b + n + ".weight"] = (C,)
+            spec[b + n + ".bias"] = (C,)
+        spec[b + "attn.q_bias"] = (C,)
+        spec[b + "attn.v_bias"] = (C,)
+        for n in ("q_proj", "k_proj", "v_proj"):
+            spec[b + f"attn.{n}.weight"] = (C, C)
+        spec[b + "attn.rope.freqs_cos"] = (L * L, hd)
+        spec[b + "attn.rope.freqs_sin"] = (L * L, hd)
+        spec[b + "attn.proj.weight"] = (C, C)
+        spec[b + "attn.proj.bias"] = (C,)
+        spec[b + "mlp.w1.weight"] = (Hd, C)
+        spec[b + "mlp.w1.bias"] = (Hd,)
+        spec[b + "mlp.w2.weight"] = (Hd, C)
+        spec[b + "mlp.w2.bias"] = (Hd,)
+        spec[b + "mlp.ffn_ln.weight"] = (Hd,)
+        spec[b + "mlp.ffn_ln.bias"] = (Hd,)
+        spec[b + "mlp.w3.weight"] = (C, Hd)
+        spec[b + "mlp.w3.bias"] = (C,)
+    if is_toc3d(cfg):
+        Q = QUERY_DIM
+        nq = cfg["pruning_num_queries"]
+        for s in range(len(cfg["pruning_loc"])):
+            sp = f"score_predictor.{s}."
+            spec[sp + "pc_range"] = (6,)
+            spec[sp + "in_conv.0.weight"] = (C,)
+            spec[sp + "in_conv.0.bias"] = (C,)
+            spec[sp + "in_conv.1.weight"] = (C, C)
+            spec[sp + "in_conv.1.bias"] = (C,)
+            spec[sp + "out_conv.0.weight"] = (C // 2, C)
+            spec[sp + "out_conv.0.bias"] = (C // 2,)
+            spec[sp + "out_conv.2.weight"] = (C // 4, C // 2)
+            spec[sp + "out_conv.2.bias"] = (C // 4,)
+            spec[sp + "out_conv.4.weight"] = (2, C // 4)
+            spec[sp + "out_conv.4.bias"] = (2,)
+            spec[sp + "input_proj.0.weight"] = (Q, C)
+            spec[sp + "input_proj.0.bias"] = (Q,)
+            spec[sp + "aggregate.0.weight"] = (2, nq)
+            spec[sp + "aggregate.0.bias"] = (2,)
+            spec[sp + "query_embedding.0.weight"] = (Q, Q * 3 // 2)
+            spec[sp + "query_embedding.0.bias"] = (Q,)
+            spec[sp + "query_embedding.2.weight"] = (Q, Q)
+            spec[sp + "query_embedding.2.bias"] = (Q,)
+            for mln in ("ego_pose_pe", "ego_pose_queries"):
+                spec[sp + mln + ".reduce.0.weight"] = (Q, MOTION_DIM)
+                spec[sp + mln + ".reduce.0.bias"] = (Q,)
+                spec[sp + mln + ".gamma.weight"] = (Q, Q)
+                spec[sp + mln + ".gamma.bias"] = (Q,)
+                spec[sp + mln + ".beta.weight"] = (Q, Q)
+                spec[sp + mln + ".beta.bias"] = (Q,)
+            spec[sp + "time_embedding.0.weight"] = (Q, Q)
+            spec[sp + "time_embedding.0.bias"] = (Q,)
+            spec[sp + "time_embedding.1.weight"] = (Q,)
+            spec[sp + "time_embedding.1.bias"] = (Q,)
+    return spec
+
+
+def _draw(name: str, shape, seed: int) -> np.ndarray:
+    g = _rng(name, seed)
+    leaf = name.rsplit(".", 1)[-1]
+    if name.endswith("pc_range"):
+        raise AssertionError
+    is_norm = (".norm1." in name or ".norm2." in name or ".ffn_ln." in name
+               or ".in_conv.0." in name or ".time_embedding.1." in name)
+    if is_norm:
+        if leaf == "weight":
+            return (1.0 + 0.1 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        return (0.1 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    if name == "pos_embed":
+        return (0.1 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    if leaf in ("bias", "q_bias", "v_bias"):
+        # non-zero biases on purpose: the reference's zero-bias init (toc3d_eva_vit.py:219-228)
+        # would hide pad-row / bias bugs
+        return (0.05 * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    # weight matrices / conv kernels: N(0, (0.64 / sqrt(fan_in))^2) clipped at 2 sigma
+    fan_in = int(np.prod(shape[1:]))
+    std = 0.64 / math.sqrt(fan_in)
+    if ".q_proj." in name or ".k_proj." in name:
+        std *= 2.0                                        # peakier attention logits -> sharper RoPE/softmax test
+    if ".aggregate." in name or ".out_conv.4." in name:
+        std *= 4.0                                        # spread the keep/drop log-probs
+    w = g.standard_normal(shape, dtype=np.float32) * np.float32(std)
+    np.clip(w, -2 * std, 2 * std, out=w)
+    return w.astype(np.float32)
+
+
+def make_state_dict(cfg, seed: int = 0, device="cpu") -> "OrderedDict[str, torch.Tensor]":
+    spec = state_dict_spec(cfg)
+    hd = cfg["embed_dim"] // cfg["num_heads"]
+    p = cfg.get("patch_size", 16)
+    tables = {}
+    for L in {cfg["window_size"], cfg["img_size"] // p}:
+        tables[L * L] = rope_tables(L, hd // 2, cfg.get("pt_hw_seq_len", 16))
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        if name.endswith("freqs_cos"):
+            t = tables[shape[0]][0].clone()
+        elif name.endswith("freqs_sin"):
+            t = tables[shape[0]][1].clone()
+        elif name.endswith("pc_range"):
+            t = torch.tensor(cfg["pc_range"], dtype=torch.float32)
+        else:
+            t = torch.from_numpy(_draw(name, shape, seed))
+        sd[name] = t.to(device)
+    return sd
+
+
+def neck_state_dict(cfg, seed: int = 0, device="cpu"):
+    """CPFPN parameters (``cp_fpn.py:114-135``; ConvModule keeps the conv under ``.conv``)."""
+    cin, cout = cfg["in_channels"][0], cfg["out_channels"]
+    spec = OrderedDict([
+        ("lateral_convs.0.conv.weight", (cout, cin, 1, 1)), ("lateral_convs.0.conv.bias", (cout,)),
+        ("fpn_convs.0.conv.weight", (cout, cout, 3, 3)), ("fpn_convs.0.conv.bias", (cout,)),
+    ])
+    return OrderedDict((k, torch.from_numpy(_draw("img_neck." + k, s, seed)).to(device)) for k, s in spec.items())
+
+
+def make_inputs(cfg, n_frames: int = 1, views_per_frame: int = 6, hw=(320, 800), seed: int = 0,
+                epoch_timestamps: bool = False, device="cpu"):
+    """Synthetic backbone inputs in the shapes ``Petr3D.extract_img_feat`` passes (``petr3d.py:145-157``).
+
+    Returns a dict: x (B*Nv,3,H,W) f32 ~ N(0,1) (post-normalisation statistics); temp_queries (B,Q,256);
+    temp_ref_points (B,Q,3) in the global frame; temp_vel (B,Q,2); temp_timestamp (B,Q,1) float64
+    (U(0,1), or epoch-scale -(1.5e9+0.5 j) as left by ``streampetr_head.py:376``);
+    temp_ego_pose (B,Q,4,4); ego_pose_inv (B,4,4); gumbel (3 x (B*Nv, T, 2)) f32.
+    """
+    B, V = n_frames, n_frames * views_per_frame
+    H, W = hw
+    Q = cfg.get("pruning_num_queries", 64)
+    p = cfg.get("patch_size", 16)
+    T = (H // p) * (W // p)
+    tag = f"in/{B}/{views_per_frame}/{H}x{W}/"
+    out = {}
+    out["x"] = torch.from_numpy(_rng(tag + "x", seed).standard_normal((V, 3, H, W), dtype=np.float32))
+    out["temp_queries"] = torch.from_numpy(_rng(tag + "q", seed).standard_normal((B, Q, QUERY_DIM), dtype=np.float32))
+    pc = np.asarray(cfg.get("pc_range", [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]), dtype=np.float32)
+    u = _rng(tag + "ref", seed).random((B, Q, 3), dtype=np.float32)
+    out["temp_ref_points"] = torch.from_numpy(pc[:3] + u * (pc[3:] - pc[:3]))
+    out["temp_vel"] = torch.from_numpy(_rng(tag + "vel", seed).standard_normal((B, Q, 2), dtype=np.float32))
+    if epoch_timestamps:
+        ts = -(1.5e9 + 0.5 * np.arange(Q, dtype=np.float64))[None, :, None].repeat(B, 0)
+    else:
+        ts = _rng(tag + "ts", seed).random((B, Q, 1)).astype(np.float64)
+    out["temp_timestamp"] = torch.from_numpy(ts)
+
+    def se3(g, n):
+        yaw = 0.2 * g.standard_normal(n)
+        pitch = 0.02 * g.standard_normal(n)
+        t = g.standard_normal((n, 3)) * np.array([3.0, 3.0, 0.1])
+        M = np.zeros((n, 4, 4), dtype=np.float64)
+        cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+        M[:, 0, 0], M[:, 0, 1], M[:, 0, 2] = cy * cp, -sy, cy * sp
+        M[:, 1, 0], M[:, 1, 1], M[:, 1, 2] = sy * cp, cy, sy * sp
+        M[:, 2, 0], M[:, 2, 1], M[:, 2, 2] = -sp, 0.0, cp
+        M[:, :3, 3] = t
+        M[:, 3, 3] = 1.0
+        return M
+
+    out["temp_ego_pose"] = torch.from_numpy(se3(_rng(tag + "pose", seed), B * Q).reshape(B, Q, 4, 4).astype(np.float32))
+    cur = se3(_rng(tag + "cur", seed), B)
+    out["ego_pose_inv"] = torch.from_numpy(np.linalg.inv(cur).astype(np.float32))
+    gum = []
+    for s in range(3):
+        e = _rng(tag + f"gumbel{s}", seed).exponential(size=(V, T, 2)).astype(np.float32)
+        gum.append(torch.from_numpy(-np.log(e)))
+    out["gumbel"] = gum
+    return {k: ([t.to(device) for t in v] if isinstance(v, list) else v.to(device)) for k, v in out.items()}
