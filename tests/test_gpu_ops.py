@@ -1,0 +1,427 @@
+"""GPU: every C-ABI entry point against the oracle / plain torch fp32 on the same seeded inputs.
+
+Tolerances: index outputs bit-exact; f32 path 1e-5..1e-4 relative (summation order only); bf16 path is
+compared with a reference that sees the same bf16-rounded operands, so only accumulation order and the
+final bf16 rounding (2^-8 relative) differ.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import toc3d_oracle as O
+from toc3d_amd import configs, lib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DTYPES = [("fp32", lib.F32, torch.float32), ("bf16", lib.BF16, torch.bfloat16)]
+
+
+def S():
+    return lib.stream_ptr()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def ru(a, b):
+    return (a + b - 1) // b * b
+
+
+def pack(w, dt, tdt):
+    N, K = w.shape
+    out = torch.empty(ru(N, 128), ru(K, 64), dtype=tdt, device=DEV)
+    lib.call("toc3d_pack_weight", dt, w.to(DEV).contiguous(), N, K, out, out.shape[0], out.shape[1], S())
+    return out
+
+
+def as_act(x, tdt, Kp=None):
+    """f32 CPU [M,K] -> act on device with K zero-padded to Kp."""
+    M, K = x.shape
+    Kp = Kp or ru(K, 64)
+    out = torch.zeros(M, Kp, dtype=tdt, device=DEV)
+    out[:, :K] = x.to(DEV).to(tdt)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (128, 128, 64), (1000, 384, 192), (6000, 1024, 768), (37, 3072, 1024)])
+def test_linear_bias_gelu_residual(name, dt, tdt, M, N, K):
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    Ar, Wr = (A.to(tdt).float(), W.to(tdt).float())           # what the kernel sees
+    ref = Ar.double() @ Wr.double().T + b.double()
+    a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
+    Kp = a_d.shape[1]
+    tol_out = 1e-5 if dt == lib.F32 else 6e-3
+    out = torch.full((M, N + 8), 7.0, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_BIAS, a_d, Kp, w_d, Kp, b.to(DEV), out, N + 8, None, 0, 0, None, 0, M, N, Kp, 0, S())
+    assert relerr(out[:, :N].float(), ref) < tol_out
+    assert (out[:, N:].float() == 7.0).all(), "wrote outside [0, N)"
+    lib.call("toc3d_linear", dt, lib.EPI_GELU, a_d, Kp, w_d, Kp, b.to(DEV), out, N + 8, None, 0, 0, None, 0, M, N, Kp, 0, S())
+    assert relerr(out[:, :N].float(), torch.nn.functional.gelu(ref)) < tol_out
+    # residual epilogue, in place, with representative-row capture (period 5) and modular residual rows
+    o32 = res.to(DEV).clone()
+    period = 5
+    rep = torch.zeros(M // period + 1, N, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, b.to(DEV), o32, N, o32, N, 0, rep, period, M, N, Kp, 0, S())
+    assert relerr(o32, res.double() + ref) < 2e-5
+    rows = torch.arange(period - 1, M, period)
+    assert relerr(rep[: len(rows)], ref[rows]) < 2e-5
+    pos = rnd(7, N, seed=5)
+    o2 = torch.empty(M, N, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, b.to(DEV), o2, N, pos.to(DEV), N, 7, None, 0, M, N, Kp, 0, S())
+    assert relerr(o2, ref + pos.double()[torch.arange(M) % 7]) < 2e-5
+    o3 = torch.empty(M, N, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, None, o3, N, None, 0, 0, None, 0, M, N, Kp, 0, S())
+    assert relerr(o3, ref - b.double()) < 2e-5
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+@pytest.mark.parametrize("M,Hd,K", [(257, 341, 128), (700, 2730, 1024)])
+def test_linear_swiglu(name, dt, tdt, M, Hd, K):
+    A = rnd(M, K, seed=1)
+    w1, w2 = rnd(Hd, K, seed=2, scale=K ** -0.5), rnd(Hd, K, seed=3, scale=K ** -0.5)
+    b1, b2 = rnd(Hd, seed=4), rnd(Hd, seed=5)
+    Hp = ru(Hd, 64)
+    w12 = torch.empty(2 * Hp, K, dtype=tdt, device=DEV)
+    b12 = torch.empty(2 * Hp, device=DEV)
+    lib.call("toc3d_pack_swiglu", dt, w1.to(DEV), w2.to(DEV), b1.to(DEV), b2.to(DEV), Hd, K, w12, b12, Hp, K, S())
+    a_d = as_act(A, tdt)
+    out = torch.full((M, Hp), 3.0, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_SWIGLU, a_d, K, w12, K, b12, out, Hp, None, 0, 0, None, 0, M, 2 * Hp, K, Hd, S())
+    Ar = A.to(tdt).double()
+    x1 = Ar @ w1.to(tdt).double().T + b1.double()
+    x2 = Ar @ w2.to(tdt).double().T + b2.double()
+    ref = torch.nn.functional.silu(x1) * x2
+    assert relerr(out[:, :Hd].float(), ref) < (1e-5 if dt == lib.F32 else 6e-3)
+    assert (out[:, Hd:].float() == 0).all(), "hidden padding must be written as zeros"
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+def test_patch_embed_and_abs_pos(name, dt, tdt, golden_dir):
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    img = synth.make_inputs(cfg, views_per_frame=2)["x"]
+    V, C = 2, cfg["embed_dim"]
+    h, w = 20, 50
+    pe = sd["pos_embed"][0, 1:].contiguous().to(DEV)
+    pos = torch.empty(h * w, C, device=DEV)
+    lib.call("toc3d_abs_pos_bicubic", pe, 14, C, pos, h, w, S())
+    ref_pos = O.abs_pos(sd["pos_embed"], True, (h, w)).reshape(h * w, C)
+    assert relerr(pos, ref_pos) < 1e-5
+    g = np.load(os.path.join(golden_dir, "units.npz"))
+    for hh, ww in ((20, 50), (40, 100), (50, 100)):
+        o = torch.empty(hh * ww, 16, device=DEV)
+        lib.call("toc3d_abs_pos_bicubic", torch.from_numpy(g["abs_pos.in"])[0, 1:].contiguous().to(DEV), 14, 16, o, hh, ww, S())
+        assert relerr(o.view(1, hh, ww, 16), torch.from_numpy(g[f"abs_pos.{hh}x{ww}"])) < 1e-5
+    col = torch.empty(V * h * w, 768, dtype=tdt, device=DEV)
+    lib.call("toc3d_im2col_patches", dt, img.to(DEV), col, 768, V, 3, 320, 800, 16, S())
+    wp = pack(sd["patch_embed.proj.weight"].reshape(C, -1), dt, tdt)
+    x = torch.empty(V * h * w, C, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, col, 768, wp, 768, sd["patch_embed.proj.bias"].to(DEV), x, C, pos, C, h * w, None, 0,
+             V * h * w, C, 768, 0, S())
+    ref = O.stem(sd, cfg, img).reshape(-1, C)
+    assert relerr(x, ref) < (1e-5 if dt == lib.F32 else 1e-2)
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+@pytest.mark.parametrize("C", [128, 1024])
+def test_layernorm_rows(name, dt, tdt, C):
+    M = 203
+    x, gw, gb = rnd(M + 5, C, seed=1) * 3 + 0.5, 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    idx = torch.randint(0, M + 5, (M,), generator=torch.Generator().manual_seed(4)).int()
+    idx[::17] = -1
+    scale = torch.rand(M + 5, generator=torch.Generator().manual_seed(5))
+    out = torch.empty(M, C, dtype=tdt, device=DEV)
+    tol = 2e-5 if dt == lib.F32 else 5e-3
+    lib.call("toc3d_layernorm_rows", dt, x.to(DEV), C, None, None, gw.to(DEV), gb.to(DEV), 1e-6, out, C, M, C, S())
+    assert relerr(out.float(), O.layer_norm(x[:M], gw, gb)) < tol
+    lib.call("toc3d_layernorm_rows", dt, x.to(DEV), C, idx.to(DEV), scale.to(DEV), gw.to(DEV), gb.to(DEV), 1e-5, out, C, M, C, S())
+    src = torch.where(idx[:, None] >= 0, x[idx.clamp_min(0).long()] * scale[idx.clamp_min(0).long()][:, None], torch.zeros(M, C))
+    assert relerr(out.float(), O.layer_norm(src, gw, gb, 1e-5)) < tol
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+@pytest.mark.parametrize("n,ld", [(341, 384), (2730, 2752), (100, 128)])
+def test_layernorm_act(name, dt, tdt, n, ld):
+    M = 131
+    x, gw, gb = rnd(M, n, seed=1) * 2 + 0.3, 1 + 0.1 * rnd(n, seed=2), 0.1 * rnd(n, seed=3)
+    xd = as_act(x, tdt, ld)
+    out = torch.full((M, ld), 5.0, dtype=tdt, device=DEV)
+    lib.call("toc3d_layernorm_act", dt, xd, ld, gw.to(DEV), gb.to(DEV), 1e-6, out, ld, M, n, S())
+    ref = O.layer_norm(x.to(tdt).float(), gw, gb)
+    assert relerr(out[:, :n].float(), ref) < (2e-5 if dt == lib.F32 else 5e-3)
+    assert (out[:, n:].float() == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+def _attention_ref(x_rows, sd, pre, heads, cos, sin):
+    return O.attention(x_rows[None], sd, pre, heads, cos, sin)[0]
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+@pytest.mark.parametrize("L", [16, 20])
+def test_window_attention_dense_with_virtual_pads(name, dt, tdt, L):
+    """Block.forward attention part (eva_vit.py:249-262): LN -> zero-pad -> window attention; pads folded analytically."""
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    C, heads, V, h, w = cfg["embed_dim"], cfg["num_heads"], 2, 20, 50
+    pre = "blocks.2.attn." if L == 20 else "blocks.0.attn."
+    y = rnd(V, h, w, C, seed=7)                                     # stands for LN1(x)
+    yw, pad_hw = O.window_partition(y, L)
+    nB = yw.shape[0]
+    # reference up to (not including) proj: recompute attention core with identity proj
+    sd2 = dict(sd)
+    sd2[pre + "proj.weight"], sd2[pre + "proj.bias"] = torch.eye(C), torch.zeros(C)
+    ref = O.attention(yw.reshape(nB, L * L, C), sd2, pre, heads, sd[pre + "rope.freqs_cos"], sd[pre + "rope.freqs_sin"])
+    ref = O.window_unpartition(ref.reshape(nB, L, L, C), L, pad_hw, (h, w)).reshape(-1, C)
+    # device: qkv of the real tokens only
+    wqkv = torch.cat([sd[pre + "q_proj.weight"], sd[pre + "k_proj.weight"], sd[pre + "v_proj.weight"]])
+    bqkv = torch.cat([sd[pre + "q_bias"], torch.zeros(C), sd[pre + "v_bias"]])
+    M = V * h * w
+    a_d = as_act(y.reshape(M, C), tdt)
+    qkv = torch.empty(M, 3 * C, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_BIAS, a_d, C, pack(wqkv, dt, tdt), C, bqkv.to(DEV), qkv, 3 * C, None, 0, 0, None, 0, M, 3 * C, C, 0, S())
+    nW, N = nB, L * L
+    rows = torch.empty(nW, N, dtype=torch.int32, device=DEV)
+    slots, count, npad = torch.empty_like(rows), torch.empty(nW, dtype=torch.int32, device=DEV), torch.empty(nW, dtype=torch.int32, device=DEV)
+    lib.call("toc3d_window_map_dense", V, h, w, L, rows, slots, count, npad, S())
+    assert int(count.sum()) == M and int((count + npad).min()) == N
+    out = torch.zeros(M, C, dtype=tdt, device=DEV)
+    lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots, count, npad, N, nW, int(count.max()), heads,
+             sd[pre + "rope.freqs_cos"].to(DEV), sd[pre + "rope.freqs_sin"].to(DEV), sd[pre + "v_bias"].to(DEV), 64 ** -0.5, S())
+    err = relerr(out.float(), ref)
+    assert err < (5e-5 if dt == lib.F32 else 3e-2), err
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+@pytest.mark.parametrize("n", [77, 129, 201])
+def test_window_attention_selected_slots(name, dt, tdt, n):
+    """ToC3DEVAAttention (toc3d_eva_vit.py:484-518): compact rows, RoPE rows gathered by slot index."""
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    C, heads, nW = cfg["embed_dim"], cfg["num_heads"], 5
+    pre = "blocks.5.attn."
+    cosT, sinT = sd[pre + "rope.freqs_cos"], sd[pre + "rope.freqs_sin"]        # 400-row table
+    y = rnd(nW, n, C, seed=11)
+    g = torch.Generator().manual_seed(12)
+    slots = torch.stack([torch.randperm(400, generator=g)[:n] for _ in range(nW)])
+    sd2 = dict(sd)
+    sd2[pre + "proj.weight"], sd2[pre + "proj.bias"] = torch.eye(C), torch.zeros(C)
+    ref = O.attention(y, sd2, pre, heads, cosT[slots], sinT[slots]).reshape(-1, C)
+    wqkv = torch.cat([sd[pre + "q_proj.weight"], sd[pre + "k_proj.weight"], sd[pre + "v_proj.weight"]])
+    bqkv = torch.cat([sd[pre + "q_bias"], torch.zeros(C), sd[pre + "v_bias"]])
+    M = nW * n
+    qkv = torch.empty(M, 3 * C, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_BIAS, as_act(y.reshape(M, C), tdt), C, pack(wqkv, dt, tdt), C, bqkv.to(DEV), qkv, 3 * C, None, 0, 0,
+             None, 0, M, 3 * C, C, 0, S())
+    rows = torch.arange(M, dtype=torch.int32).reshape(nW, n).to(DEV)
+    count = torch.full((nW,), n, dtype=torch.int32, device=DEV)
+    out = torch.zeros(M, C, dtype=tdt, device=DEV)
+    lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots.int().to(DEV), count, None, n, nW, n, heads, cosT.to(DEV), sinT.to(DEV),
+             None, 64 ** -0.5, S())
+    err = relerr(out.float(), ref)
+    assert err < (5e-5 if dt == lib.F32 else 3e-2), err
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_rank_desc_is_a_stable_descending_sort():
+    g = torch.Generator().manual_seed(3)
+    for B, n in ((6, 1000), (2, 5000), (3, 17)):
+        sc = torch.randn(B, n, generator=g)
+        sc[:, ::7] = sc[:, 3:4]                                   # plenty of exact ties
+        sc[0, : n // 2] = -1e6
+        order = torch.empty(B, n, dtype=torch.int64, device=DEV)
+        lib.call("toc3d_rank_desc", sc.to(DEV), B, n, order, S())
+        ref = torch.sort(sc, dim=1, descending=True, stable=True)[1]
+        assert torch.equal(order.cpu(), ref)
+
+
+@pytest.mark.parametrize("L,ratio", [(16, 0.5), (16, 0.3), (20, 0.4), (20, 0.7)])
+def test_window_topk_matches_oracle(L, ratio):
+    V, h, w = 3, 20, 50
+    g = torch.Generator().manual_seed(5)
+    scores = -torch.rand(V, h, w, generator=g) * 4
+    scores[1, :5] = scores[1, 0, 0]                                  # ties among real tokens
+    N = L * L
+    k = int(N * ratio)
+    sw, _ = O.window_partition(scores[..., None], L, pad_value=O.PAD_SCORE)
+    nW = sw.shape[0]
+    sw = sw.reshape(nW, N)
+    s_sorted, ref_order = O.sort_desc_stable(sw)
+    order = torch.empty(nW, N, dtype=torch.int32, device=DEV)
+    tok, wgt = torch.empty_like(order), torch.empty(nW, N, device=DEV)
+    arows, aslots = torch.empty(nW, k + 1, dtype=torch.int32, device=DEV), torch.empty(nW, k + 1, dtype=torch.int32, device=DEV)
+    acount = torch.empty(nW, dtype=torch.int32, device=DEV)
+    lib.call("toc3d_window_topk", scores.to(DEV), V, h, w, L, k, order, tok, wgt, arows, aslots, acount, S())
+    assert torch.equal(order.cpu().long(), ref_order)
+    # token rows: window-partition an index image
+    idx_img = torch.arange(V * h * w, dtype=torch.float32).reshape(V, h, w, 1)
+    iw, _ = O.window_partition(idx_img, L, pad_value=-1)
+    ref_tok = torch.gather(iw.reshape(nW, N), 1, ref_order).long()
+    assert torch.equal(tok.cpu().long(), ref_tok)
+    fast = s_sorted[:, k:]
+    ref_w = fast / fast.sum(dim=1, keepdim=True)
+    assert (wgt[:, :k] == 0).all()
+    assert relerr(wgt[:, k:], ref_w) < 1e-5
+    assert torch.equal(aslots.cpu().long(), torch.cat([ref_order[:, :k], torch.full((nW, 1), k)], 1))
+    assert torch.equal(arows.cpu().long(), torch.arange(nW * (k + 1)).reshape(nW, k + 1))
+    assert (acount == k + 1).all()
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+@pytest.mark.parametrize("C,L,ratio", [(128, 16, 0.5), (1024, 20, 0.3)])
+def test_gather_merge_ln_and_scatter(name, dt, tdt, C, L, ratio):
+    V, h, w = 2, 20, 50
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(V, h, w, C, generator=g)
+    scores = -torch.rand(V, h, w, generator=g) * 3 - 0.1
+    gw, gb = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    N = L * L
+    k = int(N * ratio)
+    xw, pad_hw = O.window_partition(x, L)
+    sw, _ = O.window_partition(scores[..., None], L, pad_value=O.PAD_SCORE)
+    nW = xw.shape[0]
+    xw, sw = xw.reshape(nW, N, C), sw.reshape(nW, N)
+    s_sorted, order = O.sort_desc_stable(sw)
+    slow = O.gather_rows(xw, order[:, :k])
+    rep = O.merge_tokens(O.gather_rows(xw, order[:, k:]), s_sorted[:, k:])
+    ref_short = torch.cat([slow, rep], 1).reshape(-1, C)
+    ref_ln = O.layer_norm(ref_short, gw, gb)
+    bufs = dict(order=torch.empty(nW, N, dtype=torch.int32, device=DEV), tok=torch.empty(nW, N, dtype=torch.int32, device=DEV),
+                wgt=torch.empty(nW, N, device=DEV), arows=torch.empty(nW, k + 1, dtype=torch.int32, device=DEV),
+                aslots=torch.empty(nW, k + 1, dtype=torch.int32, device=DEV), acount=torch.empty(nW, dtype=torch.int32, device=DEV))
+    lib.call("toc3d_window_topk", scores.to(DEV), V, h, w, L, k, bufs["order"], bufs["tok"], bufs["wgt"], bufs["arows"], bufs["aslots"], bufs["acount"], S())
+    xd = x.reshape(-1, C).to(DEV).contiguous()
+    short = torch.empty(nW * (k + 1), C, device=DEV)
+    a = torch.empty(nW * (k + 1), C, dtype=tdt, device=DEV)
+    lib.call("toc3d_gather_merge_ln", dt, xd, C, bufs["tok"], bufs["wgt"], nW, N, k, gw.to(DEV), gb.to(DEV), 1e-6, short, a, C, S())
+    assert relerr(short, ref_short) < 1e-5
+    assert relerr(a.float(), ref_ln) < (2e-5 if dt == lib.F32 else 5e-3)
+    # scatter: slow rows replaced, fast rows += r1 + r2, pads dropped (toc3d_eva_vit.py:449-467)
+    slow_out = torch.randn(nW, k + 1, C, generator=g)
+    r1, r2 = torch.randn(nW, C, generator=g), torch.randn(nW, C, generator=g)
+    fast = O.gather_rows(xw, order[:, k:]) + r1[:, None] + r2[:, None]
+    outw = torch.zeros_like(xw)
+    outw.scatter_(1, order[:, :k, None].expand(-1, -1, C), slow_out[:, :k])
+    outw.scatter_(1, order[:, k:, None].expand(-1, -1, C), fast)
+    ref_x = O.window_unpartition(outw.reshape(nW, L, L, C), L, pad_hw, (h, w)).reshape(-1, C)
+    lib.call("toc3d_scatter_update", xd, C, bufs["tok"], nW, N, k, slow_out.reshape(-1, C).to(DEV), r1.to(DEV), r2.to(DEV), S())
+    assert relerr(xd, ref_x) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+def _pack_scorer(sd, pre):
+    f = lambda k: sd[pre + k].to(DEV).float().contiguous()
+    l = lib.load()
+    mw = torch.empty(l.toc3d_motion_weights_floats(), device=DEV)
+    d3 = torch.arange(128, dtype=torch.float32)
+    d3 = (10000 ** (2 * torch.div(d3, 2, rounding_mode="floor") / 128)).to(DEV)
+    d1 = torch.arange(256, dtype=torch.float32)
+    d1 = (10000 ** (2 * torch.div(d1, 2, rounding_mode="floor") / 256)).to(DEV)
+    srcs = [f("query_embedding.0.weight"), f("query_embedding.0.bias"), f("query_embedding.2.weight"), f("query_embedding.2.bias")]
+    for m in ("ego_pose_pe.", "ego_pose_queries."):
+        srcs += [f(m + "reduce.0.weight"), f(m + "reduce.0.bias"), f(m + "gamma.weight"), f(m + "gamma.bias"), f(m + "beta.weight"), f(m + "beta.bias")]
+    srcs += [f("time_embedding.0.weight"), f("time_embedding.0.bias"), f("time_embedding.1.weight"), f("time_embedding.1.bias"), f("pc_range"), d3, d1]
+    lib.call("toc3d_pack_motion_weights", *srcs, mw, S())
+    torch.cuda.synchronize()
+    return mw
+
+
+@pytest.mark.parametrize("epoch", [False, True])
+def test_query_scorer_against_reference_fixture(golden_dir, epoch):
+    """Motion-aware queries + collapsed cross-attention scorer + Gumbel mask vs the REAL reference's outputs."""
+    g = np.load(os.path.join(golden_dir, "scorer_toc3d_tiny.npz"))
+    fl = "epoch" if epoch else "u01"
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    pre = "score_predictor.1."
+    C = cfg["embed_dim"]
+    inp = synth.make_inputs(cfg, views_per_frame=2, epoch_timestamps=epoch)
+    mw = _pack_scorer(sd, pre)
+    B, Q = 1, 64
+    d = lambda t: t.to(DEV).contiguous()
+    mq = torch.empty(B, Q, 256, device=DEV)
+    lib.call("toc3d_motion_queries", mw, d(inp["temp_queries"]), d(inp["temp_ref_points"]), d(inp["temp_vel"]), d(inp["temp_timestamp"]), 1,
+             d(inp["temp_ego_pose"]), d(inp["ego_pose_inv"]), B, Q, mq, S())
+    ref_mq = torch.from_numpy(g[f"{fl}.mq"])
+    err = (mq.cpu() - ref_mq).abs().max().item()
+    assert err < 2e-4, f"motion-aware queries max abs err {err}"
+    # f32 timestamps take the other branch; must agree with the oracle run on f32 timestamps
+    if not epoch:
+        mq32 = torch.empty_like(mq)
+        lib.call("toc3d_motion_queries", mw, d(inp["temp_queries"]), d(inp["temp_ref_points"]), d(inp["temp_vel"]), d(inp["temp_timestamp"].float()), 0,
+                 d(inp["temp_ego_pose"]), d(inp["ego_pose_inv"]), B, Q, mq32, S())
+        r32 = O.motion_aware_queries(sd, pre, inp["temp_queries"], inp["temp_ref_points"], inp["temp_vel"], inp["temp_timestamp"].float(),
+                                     inp["temp_ego_pose"], inp["ego_pose_inv"])
+        assert (mq32.cpu() - r32).abs().max().item() < 2e-4
+    x = torch.from_numpy(synth._rng("scorer/x").standard_normal((2, 20, 50, C), dtype=np.float32))
+    m = torch.from_numpy(synth._rng("scorer/m").random((2, 20, 50, 1), dtype=np.float32))
+    wc, bc = torch.empty(B, C, 2, device=DEV), torch.empty(B, 2, device=DEV)
+    lib.call("toc3d_collapse_query_scorer", d(ref_mq), d(sd[pre + "input_proj.0.weight"]), d(sd[pre + "input_proj.0.bias"]),
+             d(sd[pre + "aggregate.0.weight"]), d(sd[pre + "aggregate.0.bias"]), B, Q, C, 256 ** -0.5, wc, bc, S())
+    M, T = 2000, 1000
+    pred, score, mask = torch.empty(M, 2, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    lib.call("toc3d_score_tokens", d(x.reshape(M, C)), C, d(m.reshape(M)), wc, bc, d(inp["gumbel"][1].reshape(M, 2)), 2, T, 2, pred, score, mask, S())
+    ref_pred = torch.from_numpy(g[f"{fl}.pred_query"]).reshape(M, 2)
+    assert (pred.cpu() - ref_pred).abs().max().item() < 5e-5
+    assert torch.equal(score.cpu(), pred.cpu()[:, 0])
+    assert (mask.cpu() - torch.from_numpy(g[f"{fl}.mask"]).reshape(M)).abs().max().item() < 5e-5
+    order = torch.empty(2, T, dtype=torch.int64, device=DEV)
+    lib.call("toc3d_rank_desc", d(ref_pred[:, 0].contiguous()), 2, T, order, S())
+    k = int(T * cfg["token_ratio"][1])
+    assert np.array_equal(order[:, :k].cpu().numpy(), g[f"{fl}.keep_idx"]) and np.array_equal(order[:, k:].cpu().numpy(), g[f"{fl}.drop_idx"])
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+def test_first_frame_scorer(name, dt, tdt, golden_dir):
+    """ScoreBasedTokenSelector.score (toc3d_utils.py:114-129) through the C ABI vs the reference fixture."""
+    g = np.load(os.path.join(golden_dir, "scorer_toc3d_tiny.npz"))
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    pre = "score_predictor.1."
+    C, V, T = cfg["embed_dim"], 2, 1000
+    M = V * T
+    x = torch.from_numpy(synth._rng("scorer/x").standard_normal((V, 20, 50, C), dtype=np.float32)).reshape(M, C).to(DEV)
+    m = torch.from_numpy(synth._rng("scorer/m").random((V, 20, 50, 1), dtype=np.float32)).reshape(M).to(DEV)
+    f = lambda k: sd[pre + k].to(DEV)
+    a = torch.empty(M, C, dtype=tdt, device=DEV)
+    t_act = torch.empty(M, C, dtype=tdt, device=DEV)
+    u1 = torch.zeros(M, 64, dtype=tdt, device=DEV)
+    u2 = torch.zeros(M, 64, dtype=tdt, device=DEV)
+    lib.call("toc3d_layernorm_rows", dt, x, C, None, m, f("in_conv.0.weight"), f("in_conv.0.bias"), 1e-5, a, C, M, C, S())
+    w_ic, w_o0, w_o2 = pack(sd[pre + "in_conv.1.weight"], dt, tdt), pack(sd[pre + "out_conv.0.weight"], dt, tdt), pack(sd[pre + "out_conv.2.weight"], dt, tdt)
+    lib.call("toc3d_linear", dt, lib.EPI_GELU, a, C, w_ic, C, f("in_conv.1.bias"), t_act, C, None, 0, 0, None, 0, M, C, C, 0, S())
+    lib.call("toc3d_global_mean_half", dt, t_act, C, V, T, C, S())
+    lib.call("toc3d_linear", dt, lib.EPI_GELU, t_act, C, w_o0, C, f("out_conv.0.bias"), u1, 64, None, 0, 0, None, 0, M, C // 2, C, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_GELU, u1, 64, w_o2, 64, f("out_conv.2.bias"), u2, 64, None, 0, 0, None, 0, M, C // 4, 64, 0, S())
+    pred, score, mask = torch.empty(M, 2, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    lib.call("toc3d_score_head", dt, u2, 64, C // 4, f("out_conv.4.weight"), f("out_conv.4.bias"), None, M, pred, score, mask, S())
+    ref = torch.from_numpy(g["u01.pred_score"]).reshape(M, 2)
+    err = (pred.cpu() - ref).abs().max().item()
+    assert err < (5e-5 if dt == lib.F32 else 3e-2), err
+    assert (mask.cpu() - torch.softmax(pred.cpu(), -1)[:, 0]).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+def test_nhwc_to_nchw_and_im2col3x3(name, dt, tdt):
+    V, h, w, C = 2, 20, 50, 32
+    x = rnd(V, h, w, C, seed=3)
+    out = torch.empty(V, C, h * w, device=DEV)
+    lib.call("toc3d_nhwc_to_nchw", x.to(DEV), out, V, h * w, C, S())
+    assert torch.equal(out.cpu().view(V, C, h, w), x.permute(0, 3, 1, 2))
+    col = torch.zeros(V * h * w, 320, dtype=tdt, device=DEV)
+    lib.call("toc3d_im2col_3x3", dt, x.to(DEV), col, 320, V, h, w, C, S())
+    ref = torch.nn.functional.unfold(x.permute(0, 3, 1, 2), 3, padding=1)              # (V, C*9, T) ordered (c, ky, kx)
+    ref = ref.view(V, C, 9, h * w).permute(0, 3, 2, 1).reshape(V * h * w, 9 * C)       # -> (ky,kx,c)
+    assert relerr(col[:, : 9 * C].float(), ref.to(tdt).float()) == 0

@@ -258,6 +258,7 @@ class _BackboneBase(nn.Module):
         P["w_patch"] = self._pack_linear(self.patch_embed.proj.weight.reshape(C, -1))
         P["b_patch"] = self._f32(self.patch_embed.proj.bias)
         P["blocks"] = self._pack_blocks(dev)
+        P["pos"] = {}                                   # (h, w) -> bicubic-resized abs-pos, built on first use
         return P
 
     def _pos_for(self, h, w, dev):
@@ -297,7 +298,7 @@ class _BackboneBase(nn.Module):
                     hid=torch.zeros(R, Hp, dtype=tdt, device=dev),
                     hln=torch.zeros(R, Hp, dtype=tdt, device=dev),
                     col=torch.zeros(M, _round_up(Kc, 64), dtype=tdt, device=dev),
-                    pos=self._pos_for(h, w, dev), Kc=Kc)
+                    Kc=Kc)
         plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
         return plan
 
@@ -308,9 +309,13 @@ class _BackboneBase(nn.Module):
         C, V = self.embed_dim, plan["V"]
         H, W = img.shape[2], img.shape[3]
         Kp = plan["col"].shape[1]
+        hw = (plan["h"], plan["w"])
+        if hw not in P["pos"]:
+            P["pos"][hw] = self._pos_for(hw[0], hw[1], img.device)
+        pos = P["pos"][hw]
         lib.call("toc3d_im2col_patches", self._dt, img, plan["col"], Kp, V, self.in_chans, H, W, self.patch_size, s)
         lib.call("toc3d_linear", self._dt, lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
-                 plan["x"], C, plan["pos"], C, plan["T"] if plan["pos"] is not None else 0, None, 0, plan["M"], C, Kp, 0, s)
+                 plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, 0, plan["M"], C, Kp, 0, s)
 
     def _mlp(self, bp, plan, rows, res, rep_out, rep_period):
         """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
