@@ -70,6 +70,14 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
                  float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                  toc3d_stream_t stream);
 
+/* Same with an explicit tile / pipeline variant (0 = the heuristic toc3d_linear uses): 1 = 128x128 tile, 2-deep
+ * LDS ring; 2 = 128x128, 3-deep; 3 = 128x128, 4-deep; 4 = 128x64, 3-deep; 5 = 128x64, 4-deep; 6 = 64x128, 3-deep;
+ * 7 = 64x64, 4-deep.  Results do not depend on the variant beyond f32 summation order (none: K order is fixed). */
+int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
+                    const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                    float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                    toc3d_stream_t stream);
+
 /* f32 [N, K] state-dict weight -> act [Np, Kp], zero padded (Np multiple of 128, Kp multiple of 64). */
 int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out, int64_t Np, int64_t Kp, toc3d_stream_t stream);
 /* mlp.w1 / mlp.w2 (eva_vit.py:35-36) -> interleaved [2*Hp, Kp] + bias [2*Hp]; packed row 32b+i = w1 row 16b+i,
@@ -163,7 +171,9 @@ int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, int64_t nW, in
 /* ---------------------------------------------------------------------------------------------------
  * Motion-aware query-guided scorer (backbones/toc3d_utils.py:232-252, 334-360; utils/misc.py:154-200;
  * utils/positional_encoding.py:14-81).
- * toc3d_motion_queries: get_motion_aware_queries for B frames x Q queries (query dim 256):
+ * toc3d_motion_queries: get_motion_aware_queries for B frames x Q queries (query dim 256), for n_stages scorers in one
+ *   launch (the three scorers see identical inputs but own separate weights: packed weight sets w + s*w_stride, outputs
+ *   out + s*B*Q*256):
  *   queries f32 [B,Q,256], ref_points f32 [B,Q,3], vel f32 [B,Q,2], timestamp f64 [B,Q] (timestamp_is_f64=1) or
  *   f32, ego_pose f32 [B,Q,4,4], ego_pose_inv f32 [B,4,4]; `w` = the scorer's parameters packed by
  *   toc3d_motion_weights_floats()/toc3d_pack_motion_weights (transposed [in,out] for coalescing; dimt3 [128] and
@@ -186,9 +196,9 @@ int toc3d_pack_motion_weights(const float* qe0_w, const float* qe0_b, const floa
                               const float* te_w, const float* te_b, const float* te_ln_w, const float* te_ln_b,
                               const float* pc_range, const float* dimt3, const float* dimt1, float* out,
                               toc3d_stream_t stream);
-int toc3d_motion_queries(const float* w, const float* queries, const float* ref_points, const float* vel, const void* timestamp,
-                         int timestamp_is_f64, const float* ego_pose, const float* ego_pose_inv, int64_t B, int64_t Q,
-                         float* out, toc3d_stream_t stream);
+int toc3d_motion_queries(const float* w, int64_t n_stages, int64_t w_stride, const float* queries, const float* ref_points,
+                         const float* vel, const void* timestamp, int timestamp_is_f64, const float* ego_pose,
+                         const float* ego_pose_inv, int64_t B, int64_t Q, float* out, toc3d_stream_t stream);
 int toc3d_collapse_query_scorer(const float* mq, const float* w_in, const float* b_in, const float* w_agg, const float* b_agg,
                                 int64_t B, int64_t Q, int64_t C, float scale, float* wc, float* bc, toc3d_stream_t stream);
 int toc3d_score_tokens(const float* x, int64_t C, const float* mask, const float* wc, const float* bc, const float* gumbel,

@@ -352,7 +352,7 @@ def test_query_scorer_against_reference_fixture(golden_dir, epoch):
     B, Q = 1, 64
     d = lambda t: t.to(DEV).contiguous()
     mq = torch.empty(B, Q, 256, device=DEV)
-    lib.call("toc3d_motion_queries", mw, d(inp["temp_queries"]), d(inp["temp_ref_points"]), d(inp["temp_vel"]), d(inp["temp_timestamp"]), 1,
+    lib.call("toc3d_motion_queries", mw, 1, 0, d(inp["temp_queries"]), d(inp["temp_ref_points"]), d(inp["temp_vel"]), d(inp["temp_timestamp"]), 1,
              d(inp["temp_ego_pose"]), d(inp["ego_pose_inv"]), B, Q, mq, S())
     ref_mq = torch.from_numpy(g[f"{fl}.mq"])
     err = (mq.cpu() - ref_mq).abs().max().item()
@@ -360,7 +360,7 @@ def test_query_scorer_against_reference_fixture(golden_dir, epoch):
     # f32 timestamps take the other branch; must agree with the oracle run on f32 timestamps
     if not epoch:
         mq32 = torch.empty_like(mq)
-        lib.call("toc3d_motion_queries", mw, d(inp["temp_queries"]), d(inp["temp_ref_points"]), d(inp["temp_vel"]), d(inp["temp_timestamp"].float()), 0,
+        lib.call("toc3d_motion_queries", mw, 1, 0, d(inp["temp_queries"]), d(inp["temp_ref_points"]), d(inp["temp_vel"]), d(inp["temp_timestamp"].float()), 0,
                  d(inp["temp_ego_pose"]), d(inp["ego_pose_inv"]), B, Q, mq32, S())
         r32 = O.motion_aware_queries(sd, pre, inp["temp_queries"], inp["temp_ref_points"], inp["temp_vel"], inp["temp_timestamp"].float(),
                                      inp["temp_ego_pose"], inp["ego_pose_inv"])
@@ -425,3 +425,22 @@ def test_nhwc_to_nchw_and_im2col3x3(name, dt, tdt):
     ref = torch.nn.functional.unfold(x.permute(0, 3, 1, 2), 3, padding=1)              # (V, C*9, T) ordered (c, ky, kx)
     ref = ref.view(V, C, 9, h * w).permute(0, 3, 2, 1).reshape(V * h * w, 9 * C)       # -> (ky,kx,c)
     assert relerr(col[:, : 9 * C].float(), ref.to(tdt).float()) == 0
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+def test_linear_variants_are_bit_identical(name, dt, tdt):
+    """Every tile / pipeline variant of toc3d_linear_ex accumulates K in the same order: outputs must be bit-equal."""
+    M, N, K = 777, 640, 320
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
+    ref = None
+    for v in ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14] + ([11, 12] if dt == lib.BF16 else [])):
+        out = torch.zeros(M, N, dtype=tdt, device=DEV)
+        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, 0, M, N, K, 0, S())
+        if ref is None:
+            ref = out.clone()
+            assert relerr(ref.float(), A.to(tdt).double() @ W.to(tdt).double().T + b.double()) < (1e-5 if dt == lib.F32 else 6e-3)
+        else:
+            assert torch.equal(out, ref), f"variant {v} differs"
+    with pytest.raises(RuntimeError, match="variant"):
+        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, 99, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, 0, M, N, K, 0, S())

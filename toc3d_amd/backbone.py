@@ -179,7 +179,10 @@ class _BackboneBase(nn.Module):
         self._out_feature_strides = {out_feature: patch_size}
         self._packed = None
         self._plans: Dict[tuple, dict] = {}
+        self._tuned: Dict[tuple, int] = {}
+        self.autotune = True            # pick the GEMM tile variant per shape by measurement (first eager forward)
         self.alias_outputs = False      # True: returned tensors alias the reused workspace (benchmarks)
+        self._side = None               # side stream: query-side scorer prep / image-level ranking overlap the blocks
 
     # -- state-dict hook: re-pack after new weights arrive ------------------------------------------
     def _load_from_state_dict(self, *a, **k):
@@ -302,6 +305,40 @@ class _BackboneBase(nn.Module):
         plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
         return plan
 
+    # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
+    _VARIANTS = {lib.BF16: (1, 4, 8, 9, 10, 11, 13, 14), lib.F32: (1, 8, 9, 10, 13, 14)}
+
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_period, M, N, K, n_valid):
+        """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
+        real operands the first time the shape is seen (never during hipGraph capture: shapes are warmed up eagerly).
+        All variants accumulate K in the same order, so the choice does not change results."""
+        key = (epi, M, N, K)
+        var = self._tuned.get(key)
+        s = lib.stream_ptr()
+        if var is None:
+            var = 0
+            if self.autotune and not torch.cuda.is_current_stream_capturing():
+                o = out
+                if epi == lib.EPI_RESIDUAL:                 # in-place residual add: tune into scratch
+                    o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
+                rep_s = torch.empty_like(rep_out) if rep_out is not None else None
+                best = None
+                for v in self._VARIANTS[self._dt]:
+                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_period, M, N, K, n_valid, s)
+                    lib.call("toc3d_linear_ex", *args)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        lib.call("toc3d_linear_ex", *args)
+                    e1.record()
+                    e1.synchronize()
+                    t = e0.elapsed_time(e1)
+                    if best is None or t < best[0]:
+                        best = (t, v)
+                var = best[1]
+            self._tuned[key] = var
+        lib.call("toc3d_linear_ex", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_period, M, N, K, n_valid, s)
+
     # -- launch sequences -----------------------------------------------------------------------------
     def _stem(self, plan, img, P):
         """PatchEmbed + abs-pos add (toc3d_eva_vit.py:243-247) -> residual stream x f32 [V*T, C]."""
@@ -314,8 +351,8 @@ class _BackboneBase(nn.Module):
             P["pos"][hw] = self._pos_for(hw[0], hw[1], img.device)
         pos = P["pos"][hw]
         lib.call("toc3d_im2col_patches", self._dt, img, plan["col"], Kp, V, self.in_chans, H, W, self.patch_size, s)
-        lib.call("toc3d_linear", self._dt, lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
-                 plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, 0, plan["M"], C, Kp, 0, s)
+        self._linear(lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
+                     plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, 0, plan["M"], C, Kp, 0)
 
     def _mlp(self, bp, plan, rows, res, rep_out, rep_period):
         """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
@@ -324,11 +361,10 @@ class _BackboneBase(nn.Module):
         Hp = plan["hid"].shape[1]
         dt = self._dt
         lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
-        lib.call("toc3d_linear", dt, lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, 0,
-                 rows, 2 * Hp, C, Hd, s)
+        self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, 0, rows, 2 * Hp, C, Hd)
         lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
-        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,
-                 rep_out, rep_period, rows, C, Hp, 0, s)
+        self._linear(lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,
+                     rep_out, rep_period, rows, C, Hp, 0)
 
     def _dense_block(self, i, plan, P):
         """Block.forward (eva_vit.py:247-268): LN -> window attention (pads folded analytically) -> +res; MLP -> +res."""
@@ -338,11 +374,10 @@ class _BackboneBase(nn.Module):
         x = plan["x"]
         dm = plan["dense"][self._block_side(i)]
         lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
-        lib.call("toc3d_linear", dt, lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, 0,
-                 M, 3 * C, C, 0, s)
+        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, 0, M, 3 * C, C, 0)
         lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], dm["npad"],
                  dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["v_bias"], 64 ** -0.5, s)
-        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, 0, M, C, C, 0, s)
+        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, 0, M, C, C, 0)
         self._mlp(bp, plan, M, x, None, 0)
 
     def _check_input(self, x):
@@ -470,9 +505,11 @@ class ToC3DEVAViT(_BackboneBase):
         f = self._f32
         P["scorers"] = []
         keep = []
-        for sp in self.score_predictor:
+        P["motion_all"] = torch.empty(len(self.score_predictor), nfl, dtype=torch.float32, device=dev)
+        P["motion_stride"] = nfl
+        for si, sp in enumerate(self.score_predictor):
             q = {}
-            mw = torch.empty(nfl, dtype=torch.float32, device=dev)
+            mw = P["motion_all"][si]
             srcs = [f(sp.query_embedding[0].weight), f(sp.query_embedding[0].bias), f(sp.query_embedding[2].weight), f(sp.query_embedding[2].bias)]
             for mln in (sp.ego_pose_pe, sp.ego_pose_queries):
                 srcs += [f(mln.reduce[0].weight), f(mln.reduce[0].bias), f(mln.gamma.weight), f(mln.gamma.bias), f(mln.beta.weight), f(mln.beta.bias)]
@@ -521,10 +558,10 @@ class ToC3DEVAViT(_BackboneBase):
                                     wgt=torch.empty(nW, N, **f32), arows=torch.empty(nW, k + 1, **i32),
                                     aslots=torch.empty(nW, k + 1, **i32), acount=torch.empty(nW, **i32))
         Q = self.pruning_num_queries
-        plan["mq"] = torch.empty(B, Q, QUERY_DIM, **f32)
-        plan["wc"] = torch.empty(B, C, 2, **f32)
-        plan["bc"] = torch.empty(B, 2, **f32)
         ns = len(self.pruning_loc)
+        plan["mq"] = torch.empty(ns, B, Q, QUERY_DIM, **f32)
+        plan["wc"] = torch.empty(ns, B, C, 2, **f32)
+        plan["bc"] = torch.empty(ns, B, 2, **f32)
         plan["pred"] = [torch.empty(M, 2, **f32) for _ in range(ns)]
         plan["score"] = [torch.empty(M, **f32) for _ in range(ns)]
         plan["mask"] = [torch.empty(M, **f32) for _ in range(ns)]
@@ -543,12 +580,9 @@ class ToC3DEVAViT(_BackboneBase):
         g = gumbel[st] if gumbel is not None else None
         pred, score, mask = plan["pred"][st], plan["score"][st], plan["mask"][st]
         if prev_exists:
-            tq, rp, vel, ts, pose, inv = inputs
-            Q = tq.shape[1]
-            lib.call("toc3d_motion_queries", q["motion"], tq, rp, vel, ts, 1 if ts.dtype == torch.float64 else 0, pose, inv, B, Q, plan["mq"], s)
-            lib.call("toc3d_collapse_query_scorer", plan["mq"], q["w_in"], q["b_in"], q["w_agg"], q["b_agg"], B, Q, C, float(q["scale"]),
-                     plan["wc"], plan["bc"], s)
-            lib.call("toc3d_score_tokens", x, C, mask_prev, plan["wc"], plan["bc"], g, V, T, V // B, pred, score, mask, s)
+            if st == 0:
+                self._join_side(plan)          # query-side prep (all stages) ran on the side stream since forward() began
+            lib.call("toc3d_score_tokens", x, C, mask_prev, plan["wc"][st], plan["bc"][st], g, V, T, V // B, pred, score, mask, s)
         else:
             # ScoreBasedTokenSelector.score (toc3d_utils.py:114-129); the reference also evaluates the motion-aware
             # queries here and discards them (:376-385) -- skipped, no observable effect
@@ -557,18 +591,52 @@ class ToC3DEVAViT(_BackboneBase):
                 plan["u2"] = torch.zeros(M, max(64, C // 4), dtype=self._tdt, device=x.device)
             t_act, u1, u2 = plan["att"], plan["u1"], plan["u2"]
             lib.call("toc3d_layernorm_rows", dt, x, C, None, mask_prev, q["ln_w"], q["ln_b"], self.SCORER_LN_EPS, plan["a"], C, M, C, s)
-            lib.call("toc3d_linear", dt, lib.EPI_GELU, plan["a"], C, q["w_ic"], q["w_ic"].shape[1], q["b_ic"], t_act, C, None, 0, 0, None, 0, M, C, C, 0, s)
+            self._linear(lib.EPI_GELU, plan["a"], C, q["w_ic"], q["w_ic"].shape[1], q["b_ic"], t_act, C, None, 0, 0, None, 0, M, C, C, 0)
             lib.call("toc3d_global_mean_half", dt, t_act, C, V, T, C, s)
-            lib.call("toc3d_linear", dt, lib.EPI_GELU, t_act, C, q["w_o0"], q["w_o0"].shape[1], q["b_o0"], u1, u1.shape[1], None, 0, 0, None, 0,
-                     M, C // 2, C, 0, s)
-            lib.call("toc3d_linear", dt, lib.EPI_GELU, u1, u1.shape[1], q["w_o2"], q["w_o2"].shape[1], q["b_o2"], u2, u2.shape[1], None, 0, 0, None, 0,
-                     M, C // 4, q["w_o2"].shape[1], 0, s)
+            self._linear(lib.EPI_GELU, t_act, C, q["w_o0"], q["w_o0"].shape[1], q["b_o0"], u1, u1.shape[1], None, 0, 0, None, 0, M, C // 2, C, 0)
+            self._linear(lib.EPI_GELU, u1, u1.shape[1], q["w_o2"], q["w_o2"].shape[1], q["b_o2"], u2, u2.shape[1], None, 0, 0, None, 0,
+                         M, C // 4, q["w_o2"].shape[1], 0)
             lib.call("toc3d_score_head", dt, u2, u2.shape[1], C // 4, q["w_o4"], q["b_o4"], g, M, pred, score, mask, s)
-        lib.call("toc3d_rank_desc", score, V, T, plan["order"][st], s)
+        # image-level keep/drop lists are only returned to the caller (vis / loss): rank them beside the blocks
+        self._fork_side(plan)
+        with torch.cuda.stream(self._side):
+            lib.call("toc3d_rank_desc", score, V, T, plan["order"][st], lib.stream_ptr())
         for L in {self.window_size, self.global_window_size}:
             sel = plan["sel"][(st, L)]
             lib.call("toc3d_window_topk", score, V, plan["h"], plan["w"], L, sel["k"], sel["order"], sel["tok"], sel["wgt"], sel["arows"],
                      sel["aslots"], sel["acount"], s)
+
+    # -- side stream: work that does not gate the block chain --------------------------------------------
+    def _fork_side(self, plan):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
+        plan["side_pending"] = True
+
+    def _join_side(self, plan):
+        if plan.get("side_pending"):
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            torch.cuda.current_stream().wait_event(ev)
+            plan["side_pending"] = False
+
+    def _query_prep(self, plan, P, inputs):
+        """get_motion_aware_queries + the collapse of input_proj/einsum/aggregate for all stages (identical inputs,
+        per-stage weights; toc3d_utils.py:376-385), launched on the side stream at the start of forward()."""
+        tq, rp, vel, ts, pose, inv = inputs
+        B, Q, C = plan["B"], tq.shape[1], self.embed_dim
+        ns = len(self.pruning_loc)
+        self._fork_side(plan)
+        with torch.cuda.stream(self._side):
+            s = lib.stream_ptr()
+            lib.call("toc3d_motion_queries", P["motion_all"], ns, P["motion_stride"], tq, rp, vel, ts, 1 if ts.dtype == torch.float64 else 0,
+                     pose, inv, B, Q, plan["mq"], s)
+            for st in range(ns):
+                q = P["scorers"][st]
+                lib.call("toc3d_collapse_query_scorer", plan["mq"][st], q["w_in"], q["b_in"], q["w_agg"], q["b_agg"], B, Q, C, float(q["scale"]),
+                         plan["wc"][st], plan["bc"][st], s)
 
     def _accel_block(self, i, st, plan, P):
         """ToC3DEVAViTBlock.forward (toc3d_eva_vit.py:395-477)."""
@@ -581,12 +649,10 @@ class ToC3DEVAViT(_BackboneBase):
         slow = plan["slow"]
         lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], nW, N, k, bp["ln1_w"], bp["ln1_b"], self.LN_EPS,
                  slow, plan["a"], C, s)
-        lib.call("toc3d_linear", dt, lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, 0,
-                 rows, 3 * C, C, 0, s)
+        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, 0, rows, 3 * C, C, 0)
         lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount"], None,
                  k + 1, nW, k + 1, self.num_heads, bp["cos"], bp["sin"], None, 64 ** -0.5, s)
-        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0,
-                 plan["rep1"], k + 1, rows, C, C, 0, s)
+        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0, plan["rep1"], k + 1, rows, C, C, 0)
         self._mlp(bp, plan, rows, slow, plan["rep2"], k + 1)
         lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], nW, N, k, slow, plan["rep1"], plan["rep2"], s)
 
@@ -623,6 +689,8 @@ class ToC3DEVAViT(_BackboneBase):
         else:
             gumbel = [g.to(dev).float().reshape(V * T, 2).contiguous() for g in gumbel_noise]
 
+        if prev and ns:
+            self._query_prep(plan, P, inputs)
         self._stem(plan, x, P)
         st = -1
         for i in range(self.depth):
@@ -634,6 +702,7 @@ class ToC3DEVAViT(_BackboneBase):
             else:
                 self._dense_block(i, plan, P)
 
+        self._join_side(plan)
         h, w = plan["h"], plan["w"]
         cl = (lambda t: t) if self.alias_outputs else (lambda t: t.clone())
         masks = [cl(plan["mask"][s]).view(V, h, w, 1) for s in range(ns)]

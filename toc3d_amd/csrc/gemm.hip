@@ -21,9 +21,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128;          // ROWB: bytes of K per LDS row per stage
-constexpr int TILE_BYTES = BM * ROWB;                   // 16 KiB per operand per stage
-constexpr int GEMM_LDS = 2 * 2 * TILE_BYTES;            // 2 stages x (A + B) = 64 KiB
+// RB = bytes of K per LDS row per stage: 128 (64 bf16 / 32 f32 per K-tile) or 64 (32 bf16, bf16 only)
 
 struct GemmArgs {
     const void* A; int64_t lda;
@@ -38,44 +36,60 @@ struct GemmArgs {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// stage one 128-row x 128-byte operand tile: 1024 16-byte chunks, 4 per thread.
-template <typename T>
+// LDS swizzle: 16-byte chunk c of row r is stored at chunk position c ^ swz(r).  128-byte rows: swz = r & 7;
+// 64-byte rows (4 rows per 256-byte bank row): swz = (-(r >> 2)) & 3.  Both make every ds_read_b128 lane group
+// of the MFMA fragment reads hit 16 distinct 16-byte slots.
+template <int RB> TOC3D_DEV int swz(int r) { return RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3); }
+
+// stage one R-row x RB-byte operand tile with 16-byte global_load_lds: R*RB/16 chunks over 256 threads.
+template <typename T, int R, int RB>
 TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max_row, int k0, char* lds_tile, int wave, int lane) {
+    constexpr int CPR = RB / 16;                        // chunks per row
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < R * CPR / 256; ++t) {
         const int cidx = t * 256 + wave * 64 + lane;
-        const int r = cidx >> 3, p = cidx & 7;
+        const int r = cidx / CPR, p = cidx % CPR;
         int gr = row0 + r;
         gr = gr < max_row ? gr : max_row;
-        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ (r & 7)) << 4);
+        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB>(r)) << 4);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + (t * 256 + wave * 64) * 16), 16, 0, 0);
     }
 }
 
-template <typename T> struct KSteps;                    // 32-wide K steps per 128-byte stage row
-template <> struct KSteps<bf16_t> { static constexpr int n = 2; };
-template <> struct KSteps<float> { static constexpr int n = 1; };
-
-// fragment of row r (tile-local) for K step s, lane group g = lane >> 4
+// fragment of row r (tile-local) for the 32-wide K step s, lane group g = lane >> 4
+template <int RB>
 TOC3D_DEV Frag<bf16_t> lds_frag(const char* tile, int r, int s, int g, bf16_t) {
     const int cc = s * 4 + g;
     Frag<bf16_t> f;
-    f.v = *reinterpret_cast<const bf16x8*>(tile + r * ROWB + ((cc ^ (r & 7)) << 4));
+    f.v = *reinterpret_cast<const bf16x8*>(tile + r * RB + ((cc ^ swz<RB>(r)) << 4));
     return f;
 }
+template <int RB>
 TOC3D_DEV Frag<float> lds_frag(const char* tile, int r, int /*s*/, int g, float) {
+    static_assert(RB == 128, "f32 tiles use 128-byte rows");
     Frag<float> f;
-    f.lo = *reinterpret_cast<const f32x4*>(tile + r * ROWB + (((2 * g) ^ (r & 7)) << 4));
-    f.hi = *reinterpret_cast<const f32x4*>(tile + r * ROWB + (((2 * g + 1) ^ (r & 7)) << 4));
+    f.lo = *reinterpret_cast<const f32x4*>(tile + r * RB + (((2 * g) ^ (r & 7)) << 4));
+    f.hi = *reinterpret_cast<const f32x4*>(tile + r * RB + (((2 * g + 1) ^ (r & 7)) << 4));
     return f;
 }
 
 TOC3D_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 TOC3D_DEV float silu(float x) { return x / (1.0f + expf(-x)); }
 
-template <typename T, int EPI>
+template <int N> TOC3D_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Multi-stage pipeline: the LDS ring holds STAGES K-tiles; tile t+STAGES-1 is requested while tile t is
+// multiplied, so a K step no longer exposes an HBM/L2 round trip.  The in-flight global_load_lds are
+// tracked with a *counted* s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain them to
+// vmcnt(0), cdna_hip_programming.md "Pipelining across barriers").  One barrier per K-tile:
+//   wait(tile t landed) -> s_barrier -> request tile t+STAGES-1 into the slot tile t-1 just left -> MFMAs on tile t
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = BM / 32, NT = BN / 32;           // 16x16 MFMA tiles per wave (2x2 waves)
+    constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;
+    constexpr int LOADS = (BM + BN) * (RB / 16) / 256;  // global_load_lds per thread per K-tile
+    constexpr int KS = RB / 32 / (int)sizeof(T);        // 32-wide K steps per K-tile
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, g = lane >> 4;
@@ -87,44 +101,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
     const T* A = reinterpret_cast<const T*>(a.A);
     const T* W = reinterpret_cast<const T*>(a.W);
-    constexpr int BK = ROWB / (int)sizeof(T);
+    constexpr int BK = RB / (int)sizeof(T);
     const int nk = a.K / BK;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // W rows are padded to a multiple of 128 at pack time, A rows are clamped to M-1
-    const int w_max = tiles_n * BN - 1;
-    stage_tile<T>(A, a.lda, m0, a.M - 1, 0, smem, wave, lane);
-    stage_tile<T>(W, a.ldw, n0, w_max, 0, smem + TILE_BYTES, wave, lane);
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        char* sA = smem + cur * 2 * TILE_BYTES;
-        char* sB = sA + TILE_BYTES;
-        if (kt + 1 < nk) {
-            char* nA = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile<T>(A, a.lda, m0, a.M - 1, (kt + 1) * BK, nA, wave, lane);
-            stage_tile<T>(W, a.ldw, n0, w_max, (kt + 1) * BK, nA + TILE_BYTES, wave, lane);
+    const int w_max = ((a.N + 127) / 128) * 128 - 1;
+    auto request = [&](int t) {
+        char* slot = smem + (t % STAGES) * STAGE_BYTES;
+        stage_tile<T, BM, RB>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
+        stage_tile<T, BN, RB>(W, a.ldw, n0, w_max, t * BK, slot + A_BYTES, wave, lane);
+    };
+    auto multiply = [&](int t) {
+        const char* sA = smem + (t % STAGES) * STAGE_BYTES;
+        const char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Frag<T> fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * (BM / 2) + i * 16 + r16, s, g, T());
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * (BN / 2) + j * 16 + r16, s, g, T());
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mma_step(acc[i][j], fa[i], fb[j]);
         }
-#pragma unroll
-        for (int s = 0; s < KSteps<T>::n; ++s) {
-            Frag<T> fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = lds_frag(sA, wm * 64 + i * 16 + r16, s, g, T());
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = lds_frag(sB, wn * 64 + j * 16 + r16, s, g, T());
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mma_step(acc[i][j], fa[i], fb[j]);
+    };
+    if (STAGES == 1) {
+        // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
+        for (int kt = 0; kt < nk; ++kt) {
+            request(kt);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(kt);
+            __builtin_amdgcn_s_barrier();
         }
-        __syncthreads();          // drains the in-flight global_load_lds (vmcnt(0)) and frees `cur`
-        cur ^= 1;
+    } else {
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) request(t);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
+            else wait_vmcnt<0>();                                                                   // pipeline tail
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);
+            multiply(kt);
+        }
     }
 
     // ---- epilogue: lane holds C[row = .. + g*4 + r][col = .. + r16] ----
@@ -132,16 +162,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
         T* out = reinterpret_cast<T*>(a.out);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                const int pc = n0 + wn * 64 + jp * 32 + r16;      // packed col of the w1 half
+            for (int jp = 0; jp < NT / 2; ++jp) {
+                const int pc = n0 + wn * (BN / 2) + jp * 32 + r16;      // packed col of the w1 half
                 const int unit = (pc >> 5) * 16 + r16;
                 if (pc < a.N) {
                     const float b1 = a.bias[pc], b2 = a.bias[pc + 16];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = m0 + wm * 64 + i * 16 + g * 4 + r;
+                        const int row = m0 + wm * (BM / 2) + i * 16 + g * 4 + r;
                         if (row < a.M) {
                             const float x1 = acc[i][2 * jp][r] + b1, x2 = acc[i][2 * jp + 1][r] + b2;
                             const float h = unit < a.n_valid ? silu(x1) * x2 : 0.f;
@@ -153,56 +183,100 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
         return;
     }
+    // rows first: the modular residual row and the representative-row test cost an integer division each,
+    // so they are evaluated once per row (16 per lane), not once per element (64 per lane)
+    float bcol[NT];
+    bool cok[NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 16 + r16;
+        cok[j] = col < a.N;
+        bcol[j] = (a.bias && cok[j]) ? a.bias[col] : 0.f;
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + r16;
-            if (col >= a.N) continue;
-            const float b = a.bias ? a.bias[col] : 0.f;
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + g * 4 + r;
-                if (row >= a.M) continue;
-                const float raw = acc[i][j][r] + b;
-                if (EPI == TOC3D_EPI_BIAS) {
-                    reinterpret_cast<T*>(a.out)[(int64_t)row * a.ldo + col] = to_act<T>(raw);
-                } else if (EPI == TOC3D_EPI_GELU) {
-                    reinterpret_cast<T*>(a.out)[(int64_t)row * a.ldo + col] = to_act<T>(gelu_erf(raw));
-                } else {   // TOC3D_EPI_RESIDUAL: f32 out = residual + (acc + bias)
-                    const int rr = a.res_mod > 0 ? row % a.res_mod : row;
-                    const float base = a.res ? a.res[(int64_t)rr * a.ldr + col] : 0.f;
-                    reinterpret_cast<float*>(a.out)[(int64_t)row * a.ldo + col] = base + raw;
-                    if (a.rep_period > 0 && (row % a.rep_period) == a.rep_period - 1)
-                        a.rep_out[(int64_t)(row / a.rep_period) * a.N + col] = raw;
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * (BM / 2) + i * 16 + g * 4 + r;
+            if (row >= a.M) continue;
+            if (EPI == TOC3D_EPI_RESIDUAL) {
+                const int rr = a.res_mod > 0 ? row % a.res_mod : row;
+                const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
+                float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
+                float* reprow = nullptr;
+                if (a.rep_period > 0 && (row % a.rep_period) == a.rep_period - 1) reprow = a.rep_out + (int64_t)(row / a.rep_period) * a.N;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (!cok[j]) continue;
+                    const int col = n0 + wn * (BN / 2) + j * 16 + r16;
+                    const float raw = acc[i][j][r] + bcol[j];
+                    orow[col] = (resrow ? resrow[col] : 0.f) + raw;
+                    if (reprow) reprow[col] = raw;
+                }
+            } else {
+                T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (!cok[j]) continue;
+                    const int col = n0 + wn * (BN / 2) + j * 16 + r16;
+                    const float raw = acc[i][j][r] + bcol[j];
+                    orow[col] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
                 }
             }
         }
     }
 }
 
-template <typename T, int EPI>
-void launch_one(dim3 grid, const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;      // 64 KiB of dynamic LDS: raise the per-kernel limit once
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128>
+void launch_cfg(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds = STAGES * (BM + BN) * RB;
+    static bool attr_set = false;      // > 64 KiB of dynamic LDS: raise the per-kernel limit once
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, EPI>), grid, dim3(256), GEMM_LDS, s, a);
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB>), dim3(tiles), dim3(256), lds, s, a);
 }
 
-template <typename T>
-int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    dim3 grid(tiles);
-    switch (epi) {
-        case TOC3D_EPI_BIAS: launch_one<T, TOC3D_EPI_BIAS>(grid, a, s); break;
-        case TOC3D_EPI_RESIDUAL: launch_one<T, TOC3D_EPI_RESIDUAL>(grid, a, s); break;
-        case TOC3D_EPI_SWIGLU: launch_one<T, TOC3D_EPI_SWIGLU>(grid, a, s); break;
-        case TOC3D_EPI_GELU: launch_one<T, TOC3D_EPI_GELU>(grid, a, s); break;
+// tile / pipeline variants (toc3d_linear_ex `variant`); 0 = heuristic
+template <typename T, int EPI>
+int launch_epi(int variant, const GemmArgs& a, hipStream_t s) {
+    if (variant == 0) {
+        // measured on MI355X (tools/gemm_sweep.py): occupancy beats ring depth on these shapes -- single-buffer tiles
+        // (24-32 KiB LDS, >= 3 workgroups per CU); the narrower tile when there are few 128x128 tiles
+        const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+        variant = t128 < 700 ? 13 : 8;
+    }
+    switch (variant) {
+        case 1: launch_cfg<T, EPI, 128, 128, 2>(a, s); break;
+        case 2: launch_cfg<T, EPI, 128, 128, 3>(a, s); break;
+        case 3: launch_cfg<T, EPI, 128, 128, 4>(a, s); break;
+        case 4: launch_cfg<T, EPI, 128, 64, 3>(a, s); break;
+        case 5: launch_cfg<T, EPI, 128, 64, 4>(a, s); break;
+        case 6: launch_cfg<T, EPI, 64, 128, 3>(a, s); break;
+        case 7: launch_cfg<T, EPI, 64, 64, 4>(a, s); break;
+        case 8: launch_cfg<T, EPI, 128, 128, 1>(a, s); break;
+        case 9: launch_cfg<T, EPI, 128, 64, 2>(a, s); break;
+        case 10: launch_cfg<T, EPI, 64, 128, 2>(a, s); break;
+        case 11: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 2, 64>(a, s); else return TOC3D_ERR_ARG; break;
+        case 12: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64>(a, s); else return TOC3D_ERR_ARG; break;
+        case 13: launch_cfg<T, EPI, 128, 64, 1>(a, s); break;
+        case 14: launch_cfg<T, EPI, 64, 64, 2>(a, s); break;
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;
+}
+
+template <typename T>
+int launch_gemm(int epi, int variant, const GemmArgs& a, hipStream_t s) {
+    switch (epi) {
+        case TOC3D_EPI_BIAS: return launch_epi<T, TOC3D_EPI_BIAS>(variant, a, s);
+        case TOC3D_EPI_RESIDUAL: return launch_epi<T, TOC3D_EPI_RESIDUAL>(variant, a, s);
+        case TOC3D_EPI_SWIGLU: return launch_epi<T, TOC3D_EPI_SWIGLU>(variant, a, s);
+        case TOC3D_EPI_GELU: return launch_epi<T, TOC3D_EPI_GELU>(variant, a, s);
+        default: return TOC3D_ERR_ARG;
+    }
 }
 
 // ---- weight packing ---------------------------------------------------------------------------------
@@ -257,14 +331,14 @@ __global__ void im2col_kernel(const float* __restrict__ img, T* __restrict__ out
 
 extern "C" {
 
-int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                 void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                 float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                 toc3d_stream_t stream) {
+int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                    void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                    float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                    toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && K > 0, "toc3d_linear: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
-    const int bk = dtype == TOC3D_BF16 ? 64 : 32;
+    const int bk = 64;
     TOC3D_REQUIRE(K % bk == 0, "toc3d_linear: K=%lld must be a multiple of %d (pad at pack time)", (long long)K, bk);
     TOC3D_REQUIRE(lda >= K && ldw >= K, "toc3d_linear: leading dims smaller than K");
     TOC3D_REQUIRE((lda * (dtype == TOC3D_BF16 ? 2 : 4)) % 16 == 0 && (ldw * (dtype == TOC3D_BF16 ? 2 : 4)) % 16 == 0,
@@ -283,10 +357,18 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
     if (M == 0) return TOC3D_OK;
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, (int)rep_period,
                (int)M, (int)N, (int)K, (int)n_valid};
-    int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, a, as_stream(stream)) : launch_gemm<float>(epilogue, a, as_stream(stream));
-    if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d", epilogue); return rc; }
+    int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
+    if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
     return TOC3D_OK;
+}
+
+int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                 void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                 float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                 toc3d_stream_t stream) {
+    return toc3d_linear_ex(dtype, epilogue, 0, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_period,
+                           M, N, K, n_valid, stream);
 }
 
 int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out, int64_t Np, int64_t Kp, toc3d_stream_t stream) {

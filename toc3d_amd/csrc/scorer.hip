@@ -63,80 +63,102 @@ TOC3D_DEV float block_sum256(float v, float* s_red) {
     return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// y[t] = sum_i in[i] * Wt[i][t] + b[t]   (t = threadIdx.x, 256 outputs, `in` in LDS)
-TOC3D_DEV float matvec256(const float* __restrict__ Wt, const float* __restrict__ b, const float* in, int n_in, int t) {
+// ---- motion-aware queries: one 1024-thread workgroup per query.  Thread (t, part): t = output feature (256),
+// part = quarter of the input range it accumulates; the four partial dot products are combined through LDS in a
+// fixed order, so the result is deterministic.  The matvecs are L2-latency bound; the 4-way split cuts the
+// dependent chain 4x.
+TOC3D_DEV float matvec256(const float* __restrict__ Wt, const float* __restrict__ b, const float* in, int n_in, int t, int part,
+                          float (*s_mv)[QD]) {
     float acc = 0.f;
-    for (int i = 0; i < n_in; ++i) acc = fmaf(in[i], Wt[(int64_t)i * QD + t], acc);
-    return acc + b[t];
+    for (int i = part; i < n_in; i += 4) acc = fmaf(in[i], Wt[(int64_t)i * QD + t], acc);
+    __syncthreads();
+    s_mv[part][t] = acc;
+    __syncthreads();
+    return ((s_mv[0][t] + s_mv[1][t]) + (s_mv[2][t] + s_mv[3][t])) + b[t];
 }
 
-TOC3D_DEV float ln256_noaffine(float v, float eps, float* s_red) {
-    const float mean = block_sum256(v, s_red) * (1.0f / QD);
+// sum over the 256 features (each held identically by the 4 `part` copies; only part 0 contributes)
+TOC3D_DEV float feat_sum(float v, int part, float* s_red) {
+    v = wave_sum(part == 0 ? v : 0.f);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);       // part 0 = waves 0..3
+}
+
+TOC3D_DEV float ln256_noaffine(float v, float eps, int part, float* s_red) {
+    const float mean = feat_sum(v, part, s_red) * (1.0f / QD);
     const float d = v - mean;
-    const float var = block_sum256(d * d, s_red) * (1.0f / QD);
+    const float var = feat_sum(d * d, part, s_red) * (1.0f / QD);
     return d * (1.0f / sqrtf(var + eps));
 }
 
-__global__ __launch_bounds__(256) void motion_queries_kernel(const float* __restrict__ w, const float* __restrict__ queries,
-                                                             const float* __restrict__ ref, const float* __restrict__ vel,
-                                                             const void* __restrict__ ts, int ts_f64, const float* __restrict__ pose,
-                                                             const float* __restrict__ pose_inv, int Q, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void motion_queries_kernel(const float* __restrict__ w_all, int64_t w_stride, const float* __restrict__ queries,
+                                                              const float* __restrict__ ref, const float* __restrict__ vel,
+                                                              const void* __restrict__ ts, int ts_f64, const float* __restrict__ pose,
+                                                              const float* __restrict__ pose_inv, int Q, int BQ, float* __restrict__ out) {
     __shared__ float s_emb[PE3];
     __shared__ float s_h[QD];
     __shared__ float s_e[MD + 12];
-    __shared__ float s_red[4];
+    __shared__ float s_mv[4][QD];
+    __shared__ float s_red[16];
     __shared__ float s_pts[4];
-    const int bq = blockIdx.x, b = bq / Q, t = threadIdx.x;
+    const int stage = blockIdx.x / BQ, bq = blockIdx.x % BQ, b = bq / Q;
+    const int t = threadIdx.x & 255, part = threadIdx.x >> 8;
+    const float* w = w_all + (int64_t)stage * w_stride;
+    out += (int64_t)stage * BQ * QD;
     const float kTorchLnEps = 1e-5f;
     const float two_pi = 6.283185307179586f;              // float(2 * math.pi)
 
     // 1. reference points -> current ego frame -> normalised by pc_range (misc.py:191-200, toc3d_utils.py:346-348)
-    if (t < 3) {
-        const float* m = pose_inv + (int64_t)b * 16 + t * 4;
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        const float* m = pose_inv + (int64_t)b * 16 + c * 4;
         const float* p = ref + (int64_t)bq * 3;
         const float v = ((m[0] * p[0] + m[1] * p[1]) + m[2] * p[2]) + m[3];
         const float* pc = w + MW::pc_range;
-        s_pts[t] = (v - pc[t]) / (pc[3 + t] - pc[t]);
+        s_pts[c] = (v - pc[c]) / (pc[3 + c] - pc[c]);
     }
-    // 3a. ego-motion vector [vel(2), t(1), pose[:3,:](12)] as f32 (toc3d_utils.py:351)
-    if (t >= 64 && t < 64 + 15) {
-        const int j = t - 64;
+    // 3a. ego-motion vector [vel(2), t(1), pose[:3,:](12)] as f32 (toc3d_utils.py:351), staged in s_h[0..14]
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 15) {
+        const int j = threadIdx.x - 64;
         float v;
         if (j < 2) v = vel[(int64_t)bq * 2 + j];
         else if (j == 2) v = ts_f64 ? (float)reinterpret_cast<const double*>(ts)[bq] : reinterpret_cast<const float*>(ts)[bq];
         else v = pose[(int64_t)bq * 16 + (j - 3)];
-        s_h[j] = v;                                       // staged in s_h[0..14] until the encoding below
+        s_h[j] = v;
     }
     __syncthreads();
     // 2. pos2posemb3d, concatenated (y, x, z) (positional_encoding.py:14-26)
-    for (int i = t; i < PE3; i += 256) {
+    for (int i = threadIdx.x; i < PE3; i += 1024) {
         const int blk = i >> 7, f = i & 127;
         const int coord = blk == 0 ? 1 : (blk == 1 ? 0 : 2);
         const float a = (s_pts[coord] * two_pi) / w[MW::dimt3 + f];
         s_emb[i] = (f & 1) ? cosf(a) : sinf(a);
     }
     // 3b. NeRF encoding, frequency-major: [sin(2^k e), cos(2^k e)] for k = 0..5 (positional_encoding.py:73-75)
-    if (t < MD) {
-        const int k = t / 30, r = t % 30;
+    if (threadIdx.x >= 512 && threadIdx.x < 512 + MD) {
+        const int i = threadIdx.x - 512;
+        const int k = i / 30, r = i % 30;
         const float a = s_h[r % 15] * (float)(1 << k);
-        s_e[t] = r < 15 ? sinf(a) : cosf(a);
+        s_e[i] = r < 15 ? sinf(a) : cosf(a);
     }
     __syncthreads();
     // query_embedding: Linear(384,256) - ReLU - Linear(256,256) (toc3d_utils.py:322-326,349)
-    const float h1 = fmaxf(matvec256(w + MW::qe0_w, w + MW::qe0_b, s_emb, PE3, t), 0.f);
+    const float h1 = fmaxf(matvec256(w + MW::qe0_w, w + MW::qe0_b, s_emb, PE3, t, part, s_mv), 0.f);
     __syncthreads();
     s_h[t] = h1;
     __syncthreads();
-    float pos = matvec256(w + MW::qe2_w, w + MW::qe2_b, s_h, QD, t);
+    float pos = matvec256(w + MW::qe2_w, w + MW::qe2_b, s_h, QD, t, part, s_mv);
     // MLN over pos (misc.py:181-188)
     {
-        const float hr = fmaxf(matvec256(w + MW::pe_red_w, w + MW::pe_red_b, s_e, MD, t), 0.f);
+        const float hr = fmaxf(matvec256(w + MW::pe_red_w, w + MW::pe_red_b, s_e, MD, t, part, s_mv), 0.f);
         __syncthreads();
         s_h[t] = hr;
         __syncthreads();
-        const float gam = matvec256(w + MW::pe_gam_w, w + MW::pe_gam_b, s_h, QD, t);
-        const float bet = matvec256(w + MW::pe_bet_w, w + MW::pe_bet_b, s_h, QD, t);
-        pos = gam * ln256_noaffine(pos, kTorchLnEps, s_red) + bet;
+        const float gam = matvec256(w + MW::pe_gam_w, w + MW::pe_gam_b, s_h, QD, t, part, s_mv);
+        const float bet = matvec256(w + MW::pe_bet_w, w + MW::pe_bet_b, s_h, QD, t, part, s_mv);
+        pos = gam * ln256_noaffine(pos, kTorchLnEps, part, s_red) + bet;
     }
     // time embedding: pos2posemb1d in the timestamp's dtype (f64 when the head promoted it), then .float()
     {
@@ -152,19 +174,19 @@ __global__ __launch_bounds__(256) void motion_queries_kernel(const float* __rest
         __syncthreads();
         s_emb[t] = e;
         __syncthreads();
-        const float te = matvec256(w + MW::te_w, w + MW::te_b, s_emb, QD, t);
-        pos += ln256_noaffine(te, kTorchLnEps, s_red) * w[MW::te_ln_w + t] + w[MW::te_ln_b + t];
+        const float te = matvec256(w + MW::te_w, w + MW::te_b, s_emb, QD, t, part, s_mv);
+        pos += ln256_noaffine(te, kTorchLnEps, part, s_red) * w[MW::te_ln_w + t] + w[MW::te_ln_b + t];
     }
     // MLN over the memory queries, then add pos (toc3d_utils.py:356-358)
     {
-        const float hr = fmaxf(matvec256(w + MW::q_red_w, w + MW::q_red_b, s_e, MD, t), 0.f);
+        const float hr = fmaxf(matvec256(w + MW::q_red_w, w + MW::q_red_b, s_e, MD, t, part, s_mv), 0.f);
         __syncthreads();
         s_h[t] = hr;
         __syncthreads();
-        const float gam = matvec256(w + MW::q_gam_w, w + MW::q_gam_b, s_h, QD, t);
-        const float bet = matvec256(w + MW::q_bet_w, w + MW::q_bet_b, s_h, QD, t);
-        const float qn = ln256_noaffine(queries[(int64_t)bq * QD + t], kTorchLnEps, s_red);
-        out[(int64_t)bq * QD + t] = (gam * qn + bet) + pos;
+        const float gam = matvec256(w + MW::q_gam_w, w + MW::q_gam_b, s_h, QD, t, part, s_mv);
+        const float bet = matvec256(w + MW::q_bet_w, w + MW::q_bet_b, s_h, QD, t, part, s_mv);
+        const float qn = ln256_noaffine(queries[(int64_t)bq * QD + t], kTorchLnEps, part, s_red);
+        if (part == 0) out[(int64_t)bq * QD + t] = (gam * qn + bet) + pos;
     }
 }
 
@@ -363,13 +385,14 @@ int toc3d_pack_motion_weights(const float* qe0_w, const float* qe0_b, const floa
     return TOC3D_OK;
 }
 
-int toc3d_motion_queries(const float* w, const float* queries, const float* ref_points, const float* vel, const void* timestamp,
-                         int timestamp_is_f64, const float* ego_pose, const float* ego_pose_inv, int64_t B, int64_t Q,
+int toc3d_motion_queries(const float* w, int64_t n_stages, int64_t w_stride, const float* queries, const float* ref_points, const float* vel,
+                         const void* timestamp, int timestamp_is_f64, const float* ego_pose, const float* ego_pose_inv, int64_t B, int64_t Q,
                          float* out, toc3d_stream_t stream) {
     TOC3D_REQUIRE(w && queries && ref_points && vel && timestamp && ego_pose && ego_pose_inv && out, "toc3d_motion_queries: null buffer");
+    TOC3D_REQUIRE(n_stages >= 1 && (n_stages == 1 || w_stride >= MW::total), "toc3d_motion_queries: bad n_stages / w_stride");
     if (B <= 0 || Q <= 0) return TOC3D_OK;
-    hipLaunchKernelGGL(motion_queries_kernel, dim3((unsigned)(B * Q)), dim3(256), 0, as_stream(stream), w, queries, ref_points, vel, timestamp,
-                       timestamp_is_f64, ego_pose, ego_pose_inv, (int)Q, out);
+    hipLaunchKernelGGL(motion_queries_kernel, dim3((unsigned)(n_stages * B * Q)), dim3(1024), 0, as_stream(stream), w, w_stride, queries, ref_points, vel,
+                       timestamp, timestamp_is_f64, ego_pose, ego_pose_inv, (int)Q, (int)(B * Q), out);
     TOC3D_LAUNCH_CHECK("toc3d_motion_queries");
     return TOC3D_OK;
 }

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
     wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, out + (int64_t)row * ldo);
 }
 
-// LayerNorm over an act row with n valid columns of ld (ffn_ln over the SwiGLU hidden): chunks of 8 elements.
+// LayerNorm over an act row with n valid columns of ld (ffn_ln over the SwiGLU hidden): chunks of 8 elements,
+// one wavefront per row, row cached in registers, gamma/beta read as 16-byte vectors.
 template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void ln_act_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ out, int64_t ldo,
@@ -100,39 +101,54 @@ __global__ __launch_bounds__(256) void ln_act_kernel(const T* __restrict__ x, in
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int ci = lane + 64 * i;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
         if (ci < nch && ci * 8 < n) {
             load8(x + (int64_t)row * ldx + ci * 8, v[i]);
+            if (ci * 8 + 8 > n) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (ci * 8 + e >= n) v[i][e] = 0.f;
-                s += v[i][e];
+                for (int e = 0; e < 8; ++e)
+                    if (ci * 8 + e >= n) v[i][e] = 0.f;
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
         }
+        s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
     }
     const float mean = wave_sum(s) / (float)n;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int ci = lane + 64 * i;
+        float qq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (ci < nch && ci * 8 + e < n) { const float d = v[i][e] - mean; q += d * d; }
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; qq += d * d; }
+        if (ci * 8 + 8 <= n) q += qq;
+        else if (ci * 8 < n) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (ci * 8 + e < n) { const float d = v[i][e] - mean; q += d * d; }
+        }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + eps);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int ci = lane + 64 * i;
-        if (ci < nch) {
-            float y[8];
+        if (ci >= nch) continue;
+        float y[8];
+        if (ci * 8 + 8 <= n) {
+            float gm[8], bt[8];
+            load8(gamma + ci * 8, gm);
+            load8(beta + ci * 8, bt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+        } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = ci * 8 + e;
                 y[e] = c < n ? (v[i][e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
             }
-            store8(out + (int64_t)row * ldo + ci * 8, y);
         }
+        store8(out + (int64_t)row * ldo + ci * 8, y);
     }
 }
 
@@ -229,15 +245,35 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
         f32x4 acc[MAXV];
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int p = k + wave; p < N; p += 16) {
-            const int src = tok[(int64_t)win * N + p];
-            if (src < 0) continue;                       // padded slot: x = 0 contributes nothing (its weight is in the denominator)
-            const float wg = wgt[(int64_t)win * N + p];
+        // this wave owns fast positions p = k + wave + 16 j; lane j prefetches index/weight j, then rows are
+        // fetched four at a time so the tok -> x dependency is paid once per four rows, not per row
+        const int mine = (N - k - wave + 15) / 16;
+        int my_src = -1;
+        float my_w = 0.f;
+        if (lane < mine) {
+            my_src = tok[(int64_t)win * N + k + wave + 16 * lane];
+            my_w = wgt[(int64_t)win * N + k + wave + 16 * lane];
+        }
+        for (int j0 = 0; j0 < mine; j0 += 4) {
+            int src[4];
+            float wg[4];
+            f32x4 row[4][MAXV];
 #pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int vi = lane + 64 * i;
-                if (vi < nvec) acc[i] += wg * *reinterpret_cast<const f32x4*>(x + (int64_t)src * C + 4 * vi);
+            for (int u = 0; u < 4; ++u) {
+                src[u] = __shfl(my_src, (j0 + u) & 63, 64);
+                wg[u] = __shfl(my_w, (j0 + u) & 63, 64);
+                if (j0 + u >= mine) src[u] = -1;         // padded slots (src < 0) contribute x = 0; their weight is in the denominator
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int vi = lane + 64 * i;
+                    row[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (vi < nvec && src[u] >= 0) row[u][i] = *reinterpret_cast<const f32x4*>(x + (int64_t)src[u] * C + 4 * vi);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) acc[i] += wg[u] * row[u][i];
         }
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {

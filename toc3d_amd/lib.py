@@ -21,6 +21,7 @@ _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 # name -> argtypes, in header order.  'p' pointer, 'l' int64, 'i' int, 'f' float
 _SIGS = {
     "toc3d_linear": "iiplplpplpllplllllp",
+    "toc3d_linear_ex": "iiiplplpplpllplllllp",
     "toc3d_pack_weight": "ipllpllp",
     "toc3d_pack_swiglu": "ippppllppllp",
     "toc3d_im2col_patches": "ippllllllp",
@@ -34,7 +35,7 @@ _SIGS = {
     "toc3d_gather_merge_ln": "iplpplllppfpplp",
     "toc3d_scatter_update": "plplllpppp",
     "toc3d_pack_motion_weights": "p" * 24 + "p",
-    "toc3d_motion_queries": "pppppippllpp",
+    "toc3d_motion_queries": "pllppppippllpp",
     "toc3d_collapse_query_scorer": "ppppplllfppp",
     "toc3d_score_tokens": "plpppplllpppp",
     "toc3d_global_mean_half": "ipllllp",
