@@ -117,6 +117,7 @@ def main():
     inp_cpu = synth.make_inputs(cfg, n_frames=1, views_per_frame=6, hw=(H, W), seed=rank)
     inp = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in inp_cpu.items()}
     V, h, w = 6, H // 16, W // 16
+    from toc3d_amd import dist as tdist
     gathered = torch.empty(world, V, 256, h, w, dtype=torch.bfloat16, device=dev) if world > 1 else None
 
     def step():
@@ -129,7 +130,7 @@ def main():
             feat = model(inp["x"])["last_feat"]
         n0 = neck([feat])[0]
         if world > 1:
-            dist.all_gather_into_tensor(gathered, n0.to(torch.bfloat16))
+            tdist.all_gather_features(n0, gathered)          # the one exchange: per-frame neck features for the head (RCCL)
         return n0
 
     def barrier():
