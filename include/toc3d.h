@@ -72,7 +72,11 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
 
 /* Same with an explicit tile / pipeline variant (0 = the heuristic toc3d_linear uses): 1 = 128x128 tile, 2-deep
  * LDS ring; 2 = 128x128, 3-deep; 3 = 128x128, 4-deep; 4 = 128x64, 3-deep; 5 = 128x64, 4-deep; 6 = 64x128, 3-deep;
- * 7 = 64x64, 4-deep.  Results do not depend on the variant beyond f32 summation order (none: K order is fixed). */
+ * 7 = 64x64, 4-deep; 8 = 128x128 single LDS buffer; 9 = 128x64, 2-deep; 10 = 64x128, 2-deep; 11/12 = 128x128 with 32-wide
+ * K tiles, 2-/3-deep (bf16 only); 13 = 128x64 single buffer; 14 = 64x64, 2-deep; 15 = variant 8 limited to 128 registers;
+ * 16/17 = 128x128 on 8 wavefronts, single / double buffer; 18/19 = 256x128 on 8 wavefronts, double / single buffer;
+ * 20 = 128x256, 21 = 256x256 (8 wavefronts, double buffer).  (1-7, 9-14: 4 wavefronts.)  Every variant accumulates K in the
+ * same order, so outputs are bit-identical across variants. */
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
                     const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                     float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,

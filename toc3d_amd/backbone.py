@@ -306,7 +306,7 @@ class _BackboneBase(nn.Module):
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
-    _VARIANTS = {lib.BF16: (1, 4, 8, 9, 10, 11, 13, 14), lib.F32: (1, 8, 9, 10, 13, 14)}
+    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19), lib.F32: (1, 8, 9, 10, 13, 14, 16, 17)}
 
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_period, M, N, K, n_valid):
         """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the

@@ -42,17 +42,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int RB> TOC3D_DEV int swz(int r) { return RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3); }
 
 // stage one R-row x RB-byte operand tile with 16-byte global_load_lds: R*RB/16 chunks over 256 threads.
-template <typename T, int R, int RB>
+template <typename T, int R, int RB, int NTHR>
 TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max_row, int k0, char* lds_tile, int wave, int lane) {
     constexpr int CPR = RB / 16;                        // chunks per row
 #pragma unroll
-    for (int t = 0; t < R * CPR / 256; ++t) {
-        const int cidx = t * 256 + wave * 64 + lane;
+    for (int t = 0; t < R * CPR / NTHR; ++t) {
+        const int cidx = t * NTHR + wave * 64 + lane;
         const int r = cidx / CPR, p = cidx % CPR;
         int gr = row0 + r;
         gr = gr < max_row ? gr : max_row;
         const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB>(r)) << 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + (t * 256 + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + (t * NTHR + wave * 64) * 16), 16, 0, 0);
     }
 }
 
@@ -83,15 +83,17 @@ template <int N> TOC3D_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // tracked with a *counted* s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain them to
 // vmcnt(0), cdna_hip_programming.md "Pipelining across barriers").  One barrier per K-tile:
 //   wait(tile t landed) -> s_barrier -> request tile t+STAGES-1 into the slot tile t-1 just left -> MFMAs on tile t
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int OCC>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MT = BM / 32, NT = BN / 32;           // 16x16 MFMA tiles per wave (2x2 waves)
+    constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
+    constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
+    constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
     constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;
-    constexpr int LOADS = (BM + BN) * (RB / 16) / 256;  // global_load_lds per thread per K-tile
+    constexpr int LOADS = (BM + BN) * (RB / 16) / NTHR; // global_load_lds per thread per K-tile
     constexpr int KS = RB / 32 / (int)sizeof(T);        // 32-wide K steps per K-tile
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, g = lane >> 4;
 
     const int tiles_n = (a.N + BN - 1) / BN;
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     const int w_max = ((a.N + 127) / 128) * 128 - 1;
     auto request = [&](int t) {
         char* slot = smem + (t % STAGES) * STAGE_BYTES;
-        stage_tile<T, BM, RB>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
-        stage_tile<T, BN, RB>(W, a.ldw, n0, w_max, t * BK, slot + A_BYTES, wave, lane);
+        stage_tile<T, BM, RB, NTHR>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
+        stage_tile<T, BN, RB, NTHR>(W, a.ldw, n0, w_max, t * BK, slot + A_BYTES, wave, lane);
     };
     auto multiply = [&](int t) {
         const char* sA = smem + (t % STAGES) * STAGE_BYTES;
@@ -124,13 +126,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         for (int s = 0; s < KS; ++s) {
             Frag<T> fa[MT], fb[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * (BM / 2) + i * 16 + r16, s, g, T());
+            for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, s, g, T());
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * (BN / 2) + j * 16 + r16, s, g, T());
+            for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, s, g, T());
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) mma_step(acc[i][j], fa[i], fb[j]);
+            __builtin_amdgcn_s_setprio(0);
         }
     };
     if (STAGES == 1) {
@@ -165,13 +169,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int jp = 0; jp < NT / 2; ++jp) {
-                const int pc = n0 + wn * (BN / 2) + jp * 32 + r16;      // packed col of the w1 half
+                const int pc = n0 + wn * TN + jp * 32 + r16;      // packed col of the w1 half
                 const int unit = (pc >> 5) * 16 + r16;
                 if (pc < a.N) {
                     const float b1 = a.bias[pc], b2 = a.bias[pc + 16];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = m0 + wm * (BM / 2) + i * 16 + g * 4 + r;
+                        const int row = m0 + wm * TM + i * 16 + g * 4 + r;
                         if (row < a.M) {
                             const float x1 = acc[i][2 * jp][r] + b1, x2 = acc[i][2 * jp + 1][r] + b2;
                             const float h = unit < a.n_valid ? silu(x1) * x2 : 0.f;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     bool cok[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wn * (BN / 2) + j * 16 + r16;
+        const int col = n0 + wn * TN + j * 16 + r16;
         cok[j] = col < a.N;
         bcol[j] = (a.bias && cok[j]) ? a.bias[col] : 0.f;
     }
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * (BM / 2) + i * 16 + g * 4 + r;
+            const int row = m0 + wm * TM + i * 16 + g * 4 + r;
             if (row >= a.M) continue;
             if (EPI == TOC3D_EPI_RESIDUAL) {
                 const int rr = a.res_mod > 0 ? row % a.res_mod : row;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     if (!cok[j]) continue;
-                    const int col = n0 + wn * (BN / 2) + j * 16 + r16;
+                    const int col = n0 + wn * TN + j * 16 + r16;
                     const float raw = acc[i][j][r] + bcol[j];
                     orow[col] = (resrow ? resrow[col] : 0.f) + raw;
                     if (reprow) reprow[col] = raw;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     if (!cok[j]) continue;
-                    const int col = n0 + wn * (BN / 2) + j * 16 + r16;
+                    const int col = n0 + wn * TN + j * 16 + r16;
                     const float raw = acc[i][j][r] + bcol[j];
                     orow[col] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
                 }
@@ -227,16 +231,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
 }
 
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128>
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int lds = STAGES * (BM + BN) * RB;
     static bool attr_set = false;      // > 64 KiB of dynamic LDS: raise the per-kernel limit once
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB>), dim3(tiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
 }
 
 // tile / pipeline variants (toc3d_linear_ex `variant`); 0 = heuristic
@@ -246,7 +250,7 @@ int launch_epi(int variant, const GemmArgs& a, hipStream_t s) {
         // measured on MI355X (tools/gemm_sweep.py): occupancy beats ring depth on these shapes -- single-buffer tiles
         // (24-32 KiB LDS, >= 3 workgroups per CU); the narrower tile when there are few 128x128 tiles
         const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-        variant = t128 < 700 ? 13 : 8;
+        variant = t128 < 700 ? 17 : 16;
     }
     switch (variant) {
         case 1: launch_cfg<T, EPI, 128, 128, 2>(a, s); break;
@@ -263,6 +267,13 @@ int launch_epi(int variant, const GemmArgs& a, hipStream_t s) {
         case 12: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64>(a, s); else return TOC3D_ERR_ARG; break;
         case 13: launch_cfg<T, EPI, 128, 64, 1>(a, s); break;
         case 14: launch_cfg<T, EPI, 64, 64, 2>(a, s); break;
+        case 15: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 2, 4>(a, s); break;      // v8 forced to <= 128 registers: 4 workgroups / CU
+        case 16: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, 1>(a, s); break;      // 8 waves, 64x32 per wave
+        case 17: launch_cfg<T, EPI, 128, 128, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, double buffered (64 KiB)
+        case 18: launch_cfg<T, EPI, 256, 128, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128 tile, double buffered (96 KiB)
+        case 19: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128, single buffer (48 KiB)
+        case 20: launch_cfg<T, EPI, 128, 256, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, 128x256 tile, double buffered
+        case 21: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves 256x256, 128x128... per-wave 64x128
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;

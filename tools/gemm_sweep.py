@@ -16,7 +16,7 @@ shapes = []   # (name, epi, M, N, K)
 for M in (6192, 6000, 4944, 3696, 2178):
     shapes += [("qkv", lib.EPI_BIAS, M, 3072, 1024), ("proj", lib.EPI_RESIDUAL, M, 1024, 1024),
                ("w12", lib.EPI_SWIGLU, M, 2 * Hp, 1024), ("w3", lib.EPI_RESIDUAL, M, 1024, Hp)]
-variants = [1, 4, 6, 8, 9, 10, 11, 12, 13, 14] if dt == lib.BF16 else [1, 4, 6, 8, 9, 10, 13, 14]
+variants = [1, 8, 13, 15, 16, 17, 18, 19, 20, 21]
 res = {}
 for name, epi, M, N, K in shapes:
     A = torch.randn(M, K, device=dev).to(tdt)
