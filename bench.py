@@ -35,7 +35,7 @@ PAPER_FPS = 1000.0 / 209.0      # ToC3D-Faster ViT-L 6x(800x320) ba
 def flop_model(cfg, V, h, w):
     """GEMM FLOPs per frame: (algorithmic, issued).  Algorithmic = as the reference executes (BASELINE.md section 2:
     padded window rows in dense blocks, k+1 rows per window in accelerated blocks); issued = what our launches do
-    (dense blocks skip the zero-padded rows analytically)."""
+    (dense blocks skip the zero-padded rows analytically; accelerated blocks give kept *padded* slots no row)."""
     C, Hd = cfg["embed_dim"], synth.hidden_dim(cfg)
     T = h * w
     per_attn = 2 * 4 * C * C            # q,k,v,proj per row
@@ -49,9 +49,9 @@ def flop_model(cfg, V, h, w):
         if synth.is_toc3d(cfg) and i in cfg["pruning_loc"]:
             stage += 1
         if synth.is_toc3d(cfg) and stage >= 0:
-            rows = nW * (int(L * L * cfg["token_ratio"][stage]) + 1)
-            alg += rows * (per_attn + per_mlp)
-            iss += rows * (per_attn + per_mlp)
+            k = int(L * L * cfg["token_ratio"][stage])
+            alg += nW * (k + 1) * (per_attn + per_mlp)                    # the reference runs k+1 rows per window, pads included
+            iss += int(lib.load().toc3d_window_topk_rows(V, h, w, L, k)) * (per_attn + per_mlp)   # we run kept real tokens + 1
         else:
             alg += nW * L * L * per_attn + V * T * per_mlp
             iss += V * T * (per_attn + per_mlp)

@@ -60,14 +60,14 @@ const char* toc3d_last_error(void); /* thread-local, valid until the next failin
  * A [M, lda] act, W [ceil(N/128)*128, ldw] act (toc3d_pack_weight / toc3d_pack_swiglu), bias [N] f32 or NULL.
  * K must be a multiple of 64 (pad at pack time).  Epilogue-specific arguments:
  *   RESIDUAL: out f32 [M, ldo]; residual f32 [*, ldr] or NULL; residual row = residual_row_mod > 0 ?
- *             m % residual_row_mod : m (patch-embed adds abs-pos[m % T]); if rep_period > 0 the rows with
- *             m % rep_period == rep_period-1 (representative tokens, toc3d_eva_vit.py:452-453) also store
- *             the raw branch output (A.W^T + bias) to rep_out[(m / rep_period), N] f32.
+ *             m % residual_row_mod : m (patch-embed adds abs-pos[m % T]); if rep_index (int32 [M]) is given, rows with
+ *             rep_index[m] >= 0 (representative tokens, toc3d_eva_vit.py:452-453) also store the raw branch output
+ *             (A.W^T + bias) to rep_out[rep_index[m], N] f32.
  *   SWIGLU:   N = 2*Hp packed columns, out act [M, ldo >= Hp]; hidden units >= n_valid are written as 0.
  */
 int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                  void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                 float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                 float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                  toc3d_stream_t stream);
 
 /* Same with an explicit tile / pipeline variant (0 = the heuristic toc3d_linear uses): 1 = 128x128 tile, 2-deep
@@ -79,7 +79,7 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
  * same order, so outputs are bit-identical across variants. */
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
                     const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                    float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                    float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                     toc3d_stream_t stream);
 
 /* f32 [N, K] state-dict weight -> act [Np, Kp], zero padded (Np multiple of 128, Kp multiple of 64). */
@@ -129,13 +129,18 @@ int toc3d_window_map_dense(int64_t V, int64_t h, int64_t w, int64_t L, int32_t* 
  * qkv act [*, ldqkv] = [q | k | v] per row (each C wide, head-major); for window i the participating rows are
  * rows[i*stride + j], j < count[i], with RoPE table rows slots[i*stride + j]; q,k are rotated (pairs 2t,2t+1),
  * q scaled by `scale` after RoPE, softmax over the window's keys plus npad[i] virtual keys with logit 0 and
- * value v_bias (NULL npad = none).  out act [*, ldo]: out[row, head*64 + d].  Flash-style, keys streamed in
- * tiles of 64 through LDS, online softmax in f32.  max_count = max_i count[i] (grid sizing only).
+ * value v_bias (NULL npad = none; dense blocks, where zero-padding follows LayerNorm).  Accelerated blocks pad *before*
+ * LayerNorm (toc3d_eva_vit.py:414,372), so a kept padded slot is the constant row LN(0)=beta: with count_k (keys per
+ * window, >= count) the entries j >= count[i] may carry rows = -1 and take q|k|v from pad_qkv (act [3C], the q|k|v
+ * projection of beta computed at pack time) with RoPE slot slots[i*stride+j]; they are keys only (their outputs are
+ * dropped by window_unpartition).  out act [*, ldo]: out[row, head*64 + d].  Flash-style, keys streamed in tiles of 64
+ * through LDS, online softmax in f32.  max_count = max_i count[i] (grid sizing only).
  */
 int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
-                           const int32_t* slots, const int32_t* count, const int32_t* npad, int64_t stride, int64_t nwin,
-                           int64_t max_count, int64_t num_heads, const float* rope_cos, const float* rope_sin,
-                           const float* v_bias, float scale, toc3d_stream_t stream);
+                           const int32_t* slots, const int32_t* count, const int32_t* count_k, const int32_t* npad,
+                           const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
+                           const float* rope_cos, const float* rope_sin, const float* v_bias, float scale,
+                           toc3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Token selection.
@@ -144,33 +149,43 @@ int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out,
  *   order int64 [B, n] (order[b, rank] = index).  keep_idx = order[:, :k], drop_idx = order[:, k:].
  * toc3d_window_topk: the per-window selection of an accelerated block (backbones/toc3d_eva_vit.py:412-438):
  *   partitions the image-level scores f32 [V, h, w] into windows of side L (pad score -1e6, :415), ranks the
- *   N = L*L slots of every window, keeps k = int(N*ratio) (computed by the caller) and emits
+ *   N = L*L slots of every window, keeps k = int(N*ratio) < N (computed by the caller) and emits
  *     order  [nW, N] int32   slot ids, descending-stable; [:k] slow, [k:] fast
  *     tok    [nW, N] int32   global token row of order[.,j], or -1 for a padded slot
  *     wgt    [nW, N] f32     merge_tokens weight s_j / sum_{fast} s (toc3d_utils.py:68) for j >= k, 0 for j < k
- *     arows  [nW, k+1] int32 compact row ids i*(k+1)+j            } attention descriptors of the slow set
- *     aslots [nW, k+1] int32 RoPE slots: order[., :k] then slot k  } (representative token uses slot k, :434)
- *     acount [nW] = k+1 (k when k == N)
+ *   and the *compact kept set*.  A kept padded slot is the same row for every window (x = 0 -> LN(0) = beta) and its
+ *   block output is discarded, so only real kept tokens get rows: window i owns cap_i = min(k, real_i) + 1 rows
+ *   [off_i, off_i + cap_i) = kept real tokens in sorted order (, explicit zero rows in the pathological case that a
+ *   real token scored <= -1e6), representative token last; total rows = toc3d_window_topk_rows(V,h,w,L,k).
+ *     prow      [nW, N] int32   compact row of sorted position p < k (-1: virtual pad)
+ *     crow_tok  [rows]  int32   source token of each compact row (-1 zero row, -2 representative token)
+ *     rep_index [rows]  int32   window id for representative rows, else -1 (toc3d_linear rep capture)
+ *     rep_row   [nW]    int32   compact row of the window's representative token
+ *     arows/aslots [nW, k+1] int32  attention key list: compact rows first (queries = the first acount_q[i] = cap_i
+ *                      entries; representative token uses RoPE slot k, :434), then the kept pads as virtual keys
+ *                      (arows = -1, aslots = their slot);  acount_k[i] = k + 1
  */
 int toc3d_rank_desc(const float* scores, int64_t B, int64_t n, int64_t* order, toc3d_stream_t stream);
+int64_t toc3d_window_topk_rows(int64_t V, int64_t h, int64_t w, int64_t L, int64_t k);
 int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int64_t L, int64_t k, int32_t* order,
-                      int32_t* tok, float* wgt, int32_t* arows, int32_t* aslots, int32_t* acount, toc3d_stream_t stream);
+                      int32_t* tok, float* wgt, int32_t* prow, int32_t* crow_tok, int32_t* rep_index, int32_t* rep_row,
+                      int32_t* arows, int32_t* aslots, int32_t* acount_q, int32_t* acount_k, toc3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Accelerated block front / back end (backbones/toc3d_eva_vit.py:421-430 and :449-467).
- * toc3d_gather_merge_ln: builds the compact slow set of every window from the residual stream x f32 [V*T, C]:
- *   rows j < k: copy of token tok[i, j] (zeros for pads) -> shortcut f32 [nW*(k+1), C] and LN1 -> a_out act;
- *   row  k   : representative token sum_{j>=k} wgt[i,j] * x[tok[i,j]] (batch_index_select + merge_tokens,
+ * toc3d_gather_merge_ln: builds the compact kept set from the residual stream x f32 [V*T, C]:
+ *   ordinary rows: copy of token crow_tok[r] (zeros for -1) -> shortcut f32 [rows, C] and LN1 -> a_out act;
+ *   representative rows rep_row[i]: sum_{j>=k} wgt[i,j] * x[tok[i,j]] (batch_index_select + merge_tokens,
  *              toc3d_utils.py:28-44,65-70), same two outputs.  One launch; merge reduced deterministically.
  * toc3d_scatter_update: batch_index_fill + window_unpartition (toc3d_utils.py:47-62, eva_utils.py:113-133) done
- *   in place on x: slow tokens <- slow_out rows; fast tokens += rep_raw1[i] + rep_raw2[i] (:452-456); padded
+ *   in place on x: kept tokens <- slow_out[prow]; dropped tokens += rep_raw1[i] + rep_raw2[i] (:452-456); padded
  *   slots are dropped.
  */
-int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, int64_t nW, int64_t N,
-                          int64_t k, const float* gamma, const float* beta, float eps, float* shortcut, void* a_out,
-                          int64_t lda, toc3d_stream_t stream);
-int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, int64_t nW, int64_t N, int64_t k, const float* slow_out,
-                         const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream);
+int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
+                          const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
+                          const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, toc3d_stream_t stream);
+int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k,
+                         const float* slow_out, const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Motion-aware query-guided scorer (backbones/toc3d_utils.py:232-252, 334-360; utils/misc.py:154-200;

@@ -64,25 +64,27 @@ def test_linear_bias_gelu_residual(name, dt, tdt, M, N, K):
     Kp = a_d.shape[1]
     tol_out = 1e-5 if dt == lib.F32 else 6e-3
     out = torch.full((M, N + 8), 7.0, dtype=tdt, device=DEV)
-    lib.call("toc3d_linear", dt, lib.EPI_BIAS, a_d, Kp, w_d, Kp, b.to(DEV), out, N + 8, None, 0, 0, None, 0, M, N, Kp, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_BIAS, a_d, Kp, w_d, Kp, b.to(DEV), out, N + 8, None, 0, 0, None, None, M, N, Kp, 0, S())
     assert relerr(out[:, :N].float(), ref) < tol_out
     assert (out[:, N:].float() == 7.0).all(), "wrote outside [0, N)"
-    lib.call("toc3d_linear", dt, lib.EPI_GELU, a_d, Kp, w_d, Kp, b.to(DEV), out, N + 8, None, 0, 0, None, 0, M, N, Kp, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_GELU, a_d, Kp, w_d, Kp, b.to(DEV), out, N + 8, None, 0, 0, None, None, M, N, Kp, 0, S())
     assert relerr(out[:, :N].float(), torch.nn.functional.gelu(ref)) < tol_out
     # residual epilogue, in place, with representative-row capture (period 5) and modular residual rows
     o32 = res.to(DEV).clone()
     period = 5
     rep = torch.zeros(M // period + 1, N, device=DEV)
-    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, b.to(DEV), o32, N, o32, N, 0, rep, period, M, N, Kp, 0, S())
+    rep_index = torch.full((M,), -1, dtype=torch.int32)
+    rep_index[period - 1::period] = torch.arange(len(rep_index[period - 1::period]), dtype=torch.int32)
+    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, b.to(DEV), o32, N, o32, N, 0, rep, rep_index.to(DEV), M, N, Kp, 0, S())
     assert relerr(o32, res.double() + ref) < 2e-5
     rows = torch.arange(period - 1, M, period)
     assert relerr(rep[: len(rows)], ref[rows]) < 2e-5
     pos = rnd(7, N, seed=5)
     o2 = torch.empty(M, N, device=DEV)
-    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, b.to(DEV), o2, N, pos.to(DEV), N, 7, None, 0, M, N, Kp, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, b.to(DEV), o2, N, pos.to(DEV), N, 7, None, None, M, N, Kp, 0, S())
     assert relerr(o2, ref + pos.double()[torch.arange(M) % 7]) < 2e-5
     o3 = torch.empty(M, N, device=DEV)
-    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, None, o3, N, None, 0, 0, None, 0, M, N, Kp, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a_d, Kp, w_d, Kp, None, o3, N, None, 0, 0, None, None, M, N, Kp, 0, S())
     assert relerr(o3, ref - b.double()) < 2e-5
 
 
@@ -98,7 +100,7 @@ def test_linear_swiglu(name, dt, tdt, M, Hd, K):
     lib.call("toc3d_pack_swiglu", dt, w1.to(DEV), w2.to(DEV), b1.to(DEV), b2.to(DEV), Hd, K, w12, b12, Hp, K, S())
     a_d = as_act(A, tdt)
     out = torch.full((M, Hp), 3.0, dtype=tdt, device=DEV)
-    lib.call("toc3d_linear", dt, lib.EPI_SWIGLU, a_d, K, w12, K, b12, out, Hp, None, 0, 0, None, 0, M, 2 * Hp, K, Hd, S())
+    lib.call("toc3d_linear", dt, lib.EPI_SWIGLU, a_d, K, w12, K, b12, out, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, S())
     Ar = A.to(tdt).double()
     x1 = Ar @ w1.to(tdt).double().T + b1.double()
     x2 = Ar @ w2.to(tdt).double().T + b2.double()
@@ -128,7 +130,7 @@ def test_patch_embed_and_abs_pos(name, dt, tdt, golden_dir):
     lib.call("toc3d_im2col_patches", dt, img.to(DEV), col, 768, V, 3, 320, 800, 16, S())
     wp = pack(sd["patch_embed.proj.weight"].reshape(C, -1), dt, tdt)
     x = torch.empty(V * h * w, C, device=DEV)
-    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, col, 768, wp, 768, sd["patch_embed.proj.bias"].to(DEV), x, C, pos, C, h * w, None, 0,
+    lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, col, 768, wp, 768, sd["patch_embed.proj.bias"].to(DEV), x, C, pos, C, h * w, None, None,
              V * h * w, C, 768, 0, S())
     ref = O.stem(sd, cfg, img).reshape(-1, C)
     assert relerr(x, ref) < (1e-5 if dt == lib.F32 else 1e-2)
@@ -191,14 +193,14 @@ def test_window_attention_dense_with_virtual_pads(name, dt, tdt, L):
     M = V * h * w
     a_d = as_act(y.reshape(M, C), tdt)
     qkv = torch.empty(M, 3 * C, dtype=tdt, device=DEV)
-    lib.call("toc3d_linear", dt, lib.EPI_BIAS, a_d, C, pack(wqkv, dt, tdt), C, bqkv.to(DEV), qkv, 3 * C, None, 0, 0, None, 0, M, 3 * C, C, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_BIAS, a_d, C, pack(wqkv, dt, tdt), C, bqkv.to(DEV), qkv, 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0, S())
     nW, N = nB, L * L
     rows = torch.empty(nW, N, dtype=torch.int32, device=DEV)
     slots, count, npad = torch.empty_like(rows), torch.empty(nW, dtype=torch.int32, device=DEV), torch.empty(nW, dtype=torch.int32, device=DEV)
     lib.call("toc3d_window_map_dense", V, h, w, L, rows, slots, count, npad, S())
     assert int(count.sum()) == M and int((count + npad).min()) == N
     out = torch.zeros(M, C, dtype=tdt, device=DEV)
-    lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots, count, npad, N, nW, int(count.max()), heads,
+    lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots, count, None, npad, None, N, nW, int(count.max()), heads,
              sd[pre + "rope.freqs_cos"].to(DEV), sd[pre + "rope.freqs_sin"].to(DEV), sd[pre + "v_bias"].to(DEV), 64 ** -0.5, S())
     err = relerr(out.float(), ref)
     assert err < (5e-5 if dt == lib.F32 else 3e-2), err
@@ -224,12 +226,12 @@ def test_window_attention_selected_slots(name, dt, tdt, n):
     M = nW * n
     qkv = torch.empty(M, 3 * C, dtype=tdt, device=DEV)
     lib.call("toc3d_linear", dt, lib.EPI_BIAS, as_act(y.reshape(M, C), tdt), C, pack(wqkv, dt, tdt), C, bqkv.to(DEV), qkv, 3 * C, None, 0, 0,
-             None, 0, M, 3 * C, C, 0, S())
+             None, None, M, 3 * C, C, 0, S())
     rows = torch.arange(M, dtype=torch.int32).reshape(nW, n).to(DEV)
     count = torch.full((nW,), n, dtype=torch.int32, device=DEV)
     out = torch.zeros(M, C, dtype=tdt, device=DEV)
-    lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots.int().to(DEV), count, None, n, nW, n, heads, cosT.to(DEV), sinT.to(DEV),
-             None, 64 ** -0.5, S())
+    lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots.int().to(DEV), count, None, None, None, n, nW, n, heads,
+             cosT.to(DEV), sinT.to(DEV), None, 64 ** -0.5, S())
     err = relerr(out.float(), ref)
     assert err < (5e-5 if dt == lib.F32 else 3e-2), err
 
@@ -247,6 +249,24 @@ def test_rank_desc_is_a_stable_descending_sort():
         assert torch.equal(order.cpu(), ref)
 
 
+def _topk_bufs(V, h, w, L, k):
+    N = L * L
+    nW = V * (-(-h // L)) * (-(-w // L))
+    ms = int(lib.load().toc3d_window_topk_rows(V, h, w, L, k))
+    i32 = dict(dtype=torch.int32, device=DEV)
+    return dict(nW=nW, N=N, ms=ms, order=torch.empty(nW, N, **i32), tok=torch.empty(nW, N, **i32), wgt=torch.empty(nW, N, device=DEV),
+                prow=torch.empty(nW, N, **i32), crow_tok=torch.full((ms,), -9, **i32), rep_index=torch.full((ms,), -9, **i32),
+                rep_row=torch.empty(nW, **i32), arows=torch.full((nW, k + 1), -9, **i32), aslots=torch.full((nW, k + 1), -9, **i32),
+                acount_q=torch.empty(nW, **i32), acount_k=torch.empty(nW, **i32))
+
+
+def _run_topk(scores, V, h, w, L, k):
+    b = _topk_bufs(V, h, w, L, k)
+    lib.call("toc3d_window_topk", scores.to(DEV), V, h, w, L, k, b["order"], b["tok"], b["wgt"], b["prow"], b["crow_tok"], b["rep_index"],
+             b["rep_row"], b["arows"], b["aslots"], b["acount_q"], b["acount_k"], S())
+    return b
+
+
 @pytest.mark.parametrize("L,ratio", [(16, 0.5), (16, 0.3), (20, 0.4), (20, 0.7)])
 def test_window_topk_matches_oracle(L, ratio):
     V, h, w = 3, 20, 50
@@ -259,24 +279,34 @@ def test_window_topk_matches_oracle(L, ratio):
     nW = sw.shape[0]
     sw = sw.reshape(nW, N)
     s_sorted, ref_order = O.sort_desc_stable(sw)
-    order = torch.empty(nW, N, dtype=torch.int32, device=DEV)
-    tok, wgt = torch.empty_like(order), torch.empty(nW, N, device=DEV)
-    arows, aslots = torch.empty(nW, k + 1, dtype=torch.int32, device=DEV), torch.empty(nW, k + 1, dtype=torch.int32, device=DEV)
-    acount = torch.empty(nW, dtype=torch.int32, device=DEV)
-    lib.call("toc3d_window_topk", scores.to(DEV), V, h, w, L, k, order, tok, wgt, arows, aslots, acount, S())
-    assert torch.equal(order.cpu().long(), ref_order)
-    # token rows: window-partition an index image
+    b = _run_topk(scores, V, h, w, L, k)
+    assert torch.equal(b["order"].cpu().long(), ref_order)
     idx_img = torch.arange(V * h * w, dtype=torch.float32).reshape(V, h, w, 1)
     iw, _ = O.window_partition(idx_img, L, pad_value=-1)
     ref_tok = torch.gather(iw.reshape(nW, N), 1, ref_order).long()
-    assert torch.equal(tok.cpu().long(), ref_tok)
+    assert torch.equal(b["tok"].cpu().long(), ref_tok)
     fast = s_sorted[:, k:]
-    ref_w = fast / fast.sum(dim=1, keepdim=True)
-    assert (wgt[:, :k] == 0).all()
-    assert relerr(wgt[:, k:], ref_w) < 1e-5
-    assert torch.equal(aslots.cpu().long(), torch.cat([ref_order[:, :k], torch.full((nW, 1), k)], 1))
-    assert torch.equal(arows.cpu().long(), torch.arange(nW * (k + 1)).reshape(nW, k + 1))
-    assert (acount == k + 1).all()
+    assert (b["wgt"][:, :k] == 0).all()
+    assert relerr(b["wgt"][:, k:], fast / fast.sum(dim=1, keepdim=True)) < 1e-5
+    # compact kept set: kept real tokens in sorted order, representative last; kept pads become virtual keys
+    tok, prow, crow, repi = (b[x].cpu().long() for x in ("tok", "prow", "crow_tok", "rep_index"))
+    arows, aslots, cq, ck, rep_row = (b[x].cpu().long() for x in ("arows", "aslots", "acount_q", "acount_k", "rep_row"))
+    off = 0
+    for i in range(nW):
+        real_kept = [p for p in range(k) if ref_tok[i, p] >= 0]
+        n_real = int((ref_tok[i] >= 0).sum())
+        cap = min(k, n_real) + 1
+        assert cq[i] == cap and ck[i] == k + 1 and rep_row[i] == off + cap - 1
+        assert crow[off:off + cap - 1].tolist() == [int(ref_tok[i, p]) for p in real_kept]
+        assert crow[off + cap - 1] == -2 and repi[off + cap - 1] == i and (repi[off:off + cap - 1] == -1).all()
+        assert prow[i, real_kept].tolist() == list(range(off, off + cap - 1))
+        pads_kept = [p for p in range(k) if ref_tok[i, p] < 0]
+        assert (prow[i, pads_kept] == -1).all()
+        assert arows[i, :cap].tolist() == list(range(off, off + cap))
+        assert aslots[i, :cap - 1].tolist() == [int(ref_order[i, p]) for p in real_kept] and aslots[i, cap - 1] == k
+        assert (arows[i, cap:] == -1).all() and aslots[i, cap:].tolist() == [int(ref_order[i, p]) for p in pads_kept]
+        off += cap
+    assert off == b["ms"]
 
 
 @pytest.mark.parametrize("name,dt,tdt", DTYPES)
@@ -296,28 +326,74 @@ def test_gather_merge_ln_and_scatter(name, dt, tdt, C, L, ratio):
     s_sorted, order = O.sort_desc_stable(sw)
     slow = O.gather_rows(xw, order[:, :k])
     rep = O.merge_tokens(O.gather_rows(xw, order[:, k:]), s_sorted[:, k:])
-    ref_short = torch.cat([slow, rep], 1).reshape(-1, C)
+    ref_short = torch.cat([slow, rep], 1)                            # (nW, k+1, C), pads included
     ref_ln = O.layer_norm(ref_short, gw, gb)
-    bufs = dict(order=torch.empty(nW, N, dtype=torch.int32, device=DEV), tok=torch.empty(nW, N, dtype=torch.int32, device=DEV),
-                wgt=torch.empty(nW, N, device=DEV), arows=torch.empty(nW, k + 1, dtype=torch.int32, device=DEV),
-                aslots=torch.empty(nW, k + 1, dtype=torch.int32, device=DEV), acount=torch.empty(nW, dtype=torch.int32, device=DEV))
-    lib.call("toc3d_window_topk", scores.to(DEV), V, h, w, L, k, bufs["order"], bufs["tok"], bufs["wgt"], bufs["arows"], bufs["aslots"], bufs["acount"], S())
+    b = _run_topk(scores, V, h, w, L, k)
+    ms = b["ms"]
     xd = x.reshape(-1, C).to(DEV).contiguous()
-    short = torch.empty(nW * (k + 1), C, device=DEV)
-    a = torch.empty(nW * (k + 1), C, dtype=tdt, device=DEV)
-    lib.call("toc3d_gather_merge_ln", dt, xd, C, bufs["tok"], bufs["wgt"], nW, N, k, gw.to(DEV), gb.to(DEV), 1e-6, short, a, C, S())
-    assert relerr(short, ref_short) < 1e-5
-    assert relerr(a.float(), ref_ln) < (2e-5 if dt == lib.F32 else 5e-3)
-    # scatter: slow rows replaced, fast rows += r1 + r2, pads dropped (toc3d_eva_vit.py:449-467)
-    slow_out = torch.randn(nW, k + 1, C, generator=g)
+    short = torch.empty(ms, C, device=DEV)
+    a = torch.empty(ms, C, dtype=tdt, device=DEV)
+    lib.call("toc3d_gather_merge_ln", dt, xd, C, b["tok"], b["wgt"], b["crow_tok"], b["rep_row"], nW, N, k, ms, gw.to(DEV), gb.to(DEV), 1e-6,
+             short, a, C, S())
+    # map compact rows back to (window, position) of the reference's padded layout
+    prow, rep_row = b["prow"].cpu().long(), b["rep_row"].cpu().long()
+    for i in range(nW):
+        kept = (prow[i, :k] >= 0).nonzero()[:, 0]
+        rows_i = torch.cat([prow[i, kept], rep_row[i:i + 1]])
+        pos_i = torch.cat([kept, torch.tensor([k])])
+        assert relerr(short[rows_i], ref_short[i, pos_i]) < 1e-5
+        assert relerr(a[rows_i].float(), ref_ln[i, pos_i]) < (2e-5 if dt == lib.F32 else 5e-3)
+    # scatter: kept rows replaced, dropped rows += r1 + r2, pads dropped (toc3d_eva_vit.py:449-467)
+    slow_c = torch.randn(ms, C, generator=g)
+    slow_out = torch.zeros(nW, k + 1, C)
+    for i in range(nW):
+        kept = (prow[i, :k] >= 0).nonzero()[:, 0]
+        slow_out[i, kept] = slow_c[prow[i, kept]]
     r1, r2 = torch.randn(nW, C, generator=g), torch.randn(nW, C, generator=g)
     fast = O.gather_rows(xw, order[:, k:]) + r1[:, None] + r2[:, None]
     outw = torch.zeros_like(xw)
     outw.scatter_(1, order[:, :k, None].expand(-1, -1, C), slow_out[:, :k])
     outw.scatter_(1, order[:, k:, None].expand(-1, -1, C), fast)
     ref_x = O.window_unpartition(outw.reshape(nW, L, L, C), L, pad_hw, (h, w)).reshape(-1, C)
-    lib.call("toc3d_scatter_update", xd, C, bufs["tok"], nW, N, k, slow_out.reshape(-1, C).to(DEV), r1.to(DEV), r2.to(DEV), S())
+    lib.call("toc3d_scatter_update", xd, C, b["tok"], b["prow"], nW, N, k, slow_c.to(DEV), r1.to(DEV), r2.to(DEV), S())
     assert relerr(xd, ref_x) < 1e-6
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+def test_attention_virtual_pad_keys_equal_explicit_pad_rows(name, dt, tdt):
+    """toc3d_eva_vit.py:414,421,372: kept padded slots are LN(0)=beta rows.  Feeding them as virtual keys (rows=-1 +
+    pad_qkv) must give the real rows exactly the output they get when the pads are explicit rows."""
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    C, heads, nW, n_real, n_pad = cfg["embed_dim"], cfg["num_heads"], 3, 37, 60
+    pre = "blocks.3.attn."
+    cosT, sinT = sd[pre + "rope.freqs_cos"].to(DEV), sd[pre + "rope.freqs_sin"].to(DEV)
+    beta_row = (0.1 * rnd(1, C, seed=21)).to(tdt).float()                     # stands for LN1(0) = beta
+    y = torch.cat([rnd(nW, n_real, C, seed=22), beta_row.expand(nW, n_pad, C)], 1)
+    n = n_real + n_pad
+    gsl = torch.Generator().manual_seed(23)
+    slots = torch.stack([torch.randperm(256, generator=gsl)[:n] for _ in range(nW)]).int()
+    wqkv = pack(torch.cat([sd[pre + "q_proj.weight"], sd[pre + "k_proj.weight"], sd[pre + "v_proj.weight"]]), dt, tdt)
+    bqkv = torch.cat([sd[pre + "q_bias"], torch.zeros(C), sd[pre + "v_bias"]]).to(DEV)
+    M = nW * n
+    qkv = torch.empty(M, 3 * C, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear", dt, lib.EPI_BIAS, as_act(y.reshape(M, C), tdt), C, wqkv, C, bqkv, qkv, 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0, S())
+    rows = torch.arange(M, dtype=torch.int32).reshape(nW, n).to(DEV)
+    cnt = torch.full((nW,), n, dtype=torch.int32, device=DEV)
+    full = torch.zeros(M, C, dtype=tdt, device=DEV)
+    lib.call("toc3d_window_attention", dt, qkv, 3 * C, full, C, rows, slots.to(DEV), cnt, None, None, None, n, nW, n, heads, cosT, sinT, None, 64 ** -0.5, S())
+    # virtual: only the real rows are queries; pads are keys taken from pad_qkv
+    pad_qkv = qkv[n_real:n_real + 1].clone()
+    rows_v = rows.clone()
+    rows_v[:, n_real:] = -1
+    cq = torch.full((nW,), n_real, dtype=torch.int32, device=DEV)
+    virt = torch.zeros(M, C, dtype=tdt, device=DEV)
+    lib.call("toc3d_window_attention", dt, qkv, 3 * C, virt, C, rows_v, slots.to(DEV), cq, cnt, None, pad_qkv, n, nW, n_real, heads, cosT, sinT, None,
+             64 ** -0.5, S())
+    fr = full.view(nW, n, C)[:, :n_real].float()
+    vr = virt.view(nW, n, C)[:, :n_real].float()
+    assert torch.equal(fr, vr)
+    assert (virt.view(nW, n, C)[:, n_real:] == 0).all(), "pad rows must not be written"
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -401,10 +477,10 @@ def test_first_frame_scorer(name, dt, tdt, golden_dir):
     u2 = torch.zeros(M, 64, dtype=tdt, device=DEV)
     lib.call("toc3d_layernorm_rows", dt, x, C, None, m, f("in_conv.0.weight"), f("in_conv.0.bias"), 1e-5, a, C, M, C, S())
     w_ic, w_o0, w_o2 = pack(sd[pre + "in_conv.1.weight"], dt, tdt), pack(sd[pre + "out_conv.0.weight"], dt, tdt), pack(sd[pre + "out_conv.2.weight"], dt, tdt)
-    lib.call("toc3d_linear", dt, lib.EPI_GELU, a, C, w_ic, C, f("in_conv.1.bias"), t_act, C, None, 0, 0, None, 0, M, C, C, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_GELU, a, C, w_ic, C, f("in_conv.1.bias"), t_act, C, None, 0, 0, None, None, M, C, C, 0, S())
     lib.call("toc3d_global_mean_half", dt, t_act, C, V, T, C, S())
-    lib.call("toc3d_linear", dt, lib.EPI_GELU, t_act, C, w_o0, C, f("out_conv.0.bias"), u1, 64, None, 0, 0, None, 0, M, C // 2, C, 0, S())
-    lib.call("toc3d_linear", dt, lib.EPI_GELU, u1, 64, w_o2, 64, f("out_conv.2.bias"), u2, 64, None, 0, 0, None, 0, M, C // 4, 64, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_GELU, t_act, C, w_o0, C, f("out_conv.0.bias"), u1, 64, None, 0, 0, None, None, M, C // 2, C, 0, S())
+    lib.call("toc3d_linear", dt, lib.EPI_GELU, u1, 64, w_o2, 64, f("out_conv.2.bias"), u2, 64, None, 0, 0, None, None, M, C // 4, 64, 0, S())
     pred, score, mask = torch.empty(M, 2, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
     lib.call("toc3d_score_head", dt, u2, 64, C // 4, f("out_conv.4.weight"), f("out_conv.4.bias"), None, M, pred, score, mask, S())
     ref = torch.from_numpy(g["u01.pred_score"]).reshape(M, 2)
@@ -436,11 +512,11 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
     ref = None
     for v in (list(range(1, 11)) + list(range(13, 22)) + ([11, 12] if dt == lib.BF16 else [])):
         out = torch.zeros(M, N, dtype=tdt, device=DEV)
-        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, 0, M, N, K, 0, S())
+        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, None, M, N, K, 0, S())
         if ref is None:
             ref = out.clone()
             assert relerr(ref.float(), A.to(tdt).double() @ W.to(tdt).double().T + b.double()) < (1e-5 if dt == lib.F32 else 6e-3)
         else:
             assert torch.equal(out, ref), f"variant {v} differs"
     with pytest.raises(RuntimeError, match="variant"):
-        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, 99, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, 0, M, N, K, 0, S())
+        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, 99, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, None, M, N, K, 0, S())

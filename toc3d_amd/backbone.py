@@ -308,7 +308,7 @@ class _BackboneBase(nn.Module):
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
     _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19), lib.F32: (1, 8, 9, 10, 13, 14, 16, 17)}
 
-    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_period, M, N, K, n_valid):
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
         """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
         real operands the first time the shape is seen (never during hipGraph capture: shapes are warmed up eagerly).
         All variants accumulate K in the same order, so the choice does not change results."""
@@ -324,7 +324,7 @@ class _BackboneBase(nn.Module):
                 rep_s = torch.empty_like(rep_out) if rep_out is not None else None
                 best = None
                 for v in self._VARIANTS[self._dt]:
-                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_period, M, N, K, n_valid, s)
+                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, s)
                     lib.call("toc3d_linear_ex", *args)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -337,7 +337,7 @@ class _BackboneBase(nn.Module):
                         best = (t, v)
                 var = best[1]
             self._tuned[key] = var
-        lib.call("toc3d_linear_ex", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_period, M, N, K, n_valid, s)
+        lib.call("toc3d_linear_ex", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, s)
 
     # -- launch sequences -----------------------------------------------------------------------------
     def _stem(self, plan, img, P):
@@ -352,19 +352,19 @@ class _BackboneBase(nn.Module):
         pos = P["pos"][hw]
         lib.call("toc3d_im2col_patches", self._dt, img, plan["col"], Kp, V, self.in_chans, H, W, self.patch_size, s)
         self._linear(lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
-                     plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, 0, plan["M"], C, Kp, 0)
+                     plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, None, plan["M"], C, Kp, 0)
 
-    def _mlp(self, bp, plan, rows, res, rep_out, rep_period):
+    def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
         """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
         s = lib.stream_ptr()
         C, Hd = self.embed_dim, self.hidden_dim
         Hp = plan["hid"].shape[1]
         dt = self._dt
         lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
-        self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, 0, rows, 2 * Hp, C, Hd)
+        self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)
         lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
         self._linear(lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,
-                     rep_out, rep_period, rows, C, Hp, 0)
+                     rep_out, rep_index, rows, C, Hp, 0)
 
     def _dense_block(self, i, plan, P):
         """Block.forward (eva_vit.py:247-268): LN -> window attention (pads folded analytically) -> +res; MLP -> +res."""
@@ -374,11 +374,11 @@ class _BackboneBase(nn.Module):
         x = plan["x"]
         dm = plan["dense"][self._block_side(i)]
         lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
-        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, 0, M, 3 * C, C, 0)
-        lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], dm["npad"],
+        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0)
+        lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None,
                  dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["v_bias"], 64 ** -0.5, s)
-        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, 0, M, C, C, 0)
-        self._mlp(bp, plan, M, x, None, 0)
+        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, None, M, C, C, 0)
+        self._mlp(bp, plan, M, x, None, None)
 
     def _check_input(self, x):
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
@@ -496,6 +496,19 @@ class ToC3DEVAViT(_BackboneBase):
         P = self._pack_common()
         dev = P["dev"]
         s = lib.stream_ptr()
+        # kept padded slots of an accelerated block are the row LN1(0) = beta1 (toc3d_eva_vit.py:414,372): its q|k|v
+        # projection is a per-block constant, produced here by the same LayerNorm + GEMM kernels as a real row
+        C = self.embed_dim
+        minus1 = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        for i, bp in enumerate(P["blocks"]):
+            if not self._accelerated(i):
+                continue
+            a_row = torch.empty(1, C, dtype=self._tdt, device=dev)
+            bp["pad_qkv"] = torch.empty(1, 3 * C, dtype=self._tdt, device=dev)
+            lib.call("toc3d_layernorm_rows", self._dt, bp["ln1_w"], C, minus1, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, a_row, C, 1, C, s)
+            lib.call("toc3d_linear", self._dt, lib.EPI_BIAS, a_row, C, bp["wqkv"], C, bp["bqkv"], bp["pad_qkv"], 3 * C, None, 0, 0, None, None,
+                     1, 3 * C, C, 0, s)
+        torch.cuda.current_stream().synchronize()
         nfl = lib.load().toc3d_motion_weights_floats()
         # positional_encoding.py:18,32 -- same torch expression as the reference, evaluated on the host
         d3 = torch.arange(128, dtype=torch.float32)
@@ -537,13 +550,15 @@ class ToC3DEVAViT(_BackboneBase):
         h, w = H // p, W // p
         sel_geo = {}
         max_rows, max_nw = 0, 0
+        rows_fn = lib.load().toc3d_window_topk_rows
         for L in {self.window_size, self.global_window_size}:
             nW = V * (-(-h // L)) * (-(-w // L))
             max_nw = max(max_nw, nW)
             for st, r in enumerate(self.token_ratio):
                 k = int(L * L * r)                        # toc3d_utils.py:138
-                sel_geo[(st, L)] = (nW, L * L, k)
-                max_rows = max(max_rows, nW * (k + 1))
+                ms = int(rows_fn(V, h, w, L, k))          # compact rows: kept real tokens + one representative per window
+                sel_geo[(st, L)] = (nW, L * L, k, ms)
+                max_rows = max(max_rows, ms)
         plan = self._base_plan(V, H, W, dev, max_rows)
         T, M = plan["T"], plan["M"]
         i32 = dict(dtype=torch.int32, device=dev)
@@ -553,10 +568,13 @@ class ToC3DEVAViT(_BackboneBase):
         plan["rep1"] = torch.empty(max_nw, C, **f32)
         plan["rep2"] = torch.empty(max_nw, C, **f32)
         plan["sel"] = {}
-        for key, (nW, N, k) in sel_geo.items():
-            plan["sel"][key] = dict(nW=nW, N=N, k=k, order=torch.empty(nW, N, **i32), tok=torch.empty(nW, N, **i32),
-                                    wgt=torch.empty(nW, N, **f32), arows=torch.empty(nW, k + 1, **i32),
-                                    aslots=torch.empty(nW, k + 1, **i32), acount=torch.empty(nW, **i32))
+        for key, (nW, N, k, ms) in sel_geo.items():
+            L = key[1]
+            plan["sel"][key] = dict(nW=nW, N=N, k=k, rows=ms, max_q=min(k, min(L, h) * min(L, w)) + 1,
+                                    order=torch.empty(nW, N, **i32), tok=torch.empty(nW, N, **i32), wgt=torch.empty(nW, N, **f32),
+                                    prow=torch.empty(nW, N, **i32), crow_tok=torch.empty(ms, **i32), rep_index=torch.empty(ms, **i32),
+                                    rep_row=torch.empty(nW, **i32), arows=torch.empty(nW, k + 1, **i32),
+                                    aslots=torch.empty(nW, k + 1, **i32), acount_q=torch.empty(nW, **i32), acount_k=torch.empty(nW, **i32))
         Q = self.pruning_num_queries
         ns = len(self.pruning_loc)
         plan["mq"] = torch.empty(ns, B, Q, QUERY_DIM, **f32)
@@ -591,10 +609,10 @@ class ToC3DEVAViT(_BackboneBase):
                 plan["u2"] = torch.zeros(M, max(64, C // 4), dtype=self._tdt, device=x.device)
             t_act, u1, u2 = plan["att"], plan["u1"], plan["u2"]
             lib.call("toc3d_layernorm_rows", dt, x, C, None, mask_prev, q["ln_w"], q["ln_b"], self.SCORER_LN_EPS, plan["a"], C, M, C, s)
-            self._linear(lib.EPI_GELU, plan["a"], C, q["w_ic"], q["w_ic"].shape[1], q["b_ic"], t_act, C, None, 0, 0, None, 0, M, C, C, 0)
+            self._linear(lib.EPI_GELU, plan["a"], C, q["w_ic"], q["w_ic"].shape[1], q["b_ic"], t_act, C, None, 0, 0, None, None, M, C, C, 0)
             lib.call("toc3d_global_mean_half", dt, t_act, C, V, T, C, s)
-            self._linear(lib.EPI_GELU, t_act, C, q["w_o0"], q["w_o0"].shape[1], q["b_o0"], u1, u1.shape[1], None, 0, 0, None, 0, M, C // 2, C, 0)
-            self._linear(lib.EPI_GELU, u1, u1.shape[1], q["w_o2"], q["w_o2"].shape[1], q["b_o2"], u2, u2.shape[1], None, 0, 0, None, 0,
+            self._linear(lib.EPI_GELU, t_act, C, q["w_o0"], q["w_o0"].shape[1], q["b_o0"], u1, u1.shape[1], None, 0, 0, None, None, M, C // 2, C, 0)
+            self._linear(lib.EPI_GELU, u1, u1.shape[1], q["w_o2"], q["w_o2"].shape[1], q["b_o2"], u2, u2.shape[1], None, 0, 0, None, None,
                          M, C // 4, q["w_o2"].shape[1], 0)
             lib.call("toc3d_score_head", dt, u2, u2.shape[1], C // 4, q["w_o4"], q["b_o4"], g, M, pred, score, mask, s)
         # image-level keep/drop lists are only returned to the caller (vis / loss): rank them beside the blocks
@@ -603,8 +621,8 @@ class ToC3DEVAViT(_BackboneBase):
             lib.call("toc3d_rank_desc", score, V, T, plan["order"][st], lib.stream_ptr())
         for L in {self.window_size, self.global_window_size}:
             sel = plan["sel"][(st, L)]
-            lib.call("toc3d_window_topk", score, V, plan["h"], plan["w"], L, sel["k"], sel["order"], sel["tok"], sel["wgt"], sel["arows"],
-                     sel["aslots"], sel["acount"], s)
+            lib.call("toc3d_window_topk", score, V, plan["h"], plan["w"], L, sel["k"], sel["order"], sel["tok"], sel["wgt"], sel["prow"],
+                     sel["crow_tok"], sel["rep_index"], sel["rep_row"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], s)
 
     # -- side stream: work that does not gate the block chain --------------------------------------------
     def _fork_side(self, plan):
@@ -644,17 +662,17 @@ class ToC3DEVAViT(_BackboneBase):
         bp = P["blocks"][i]
         C, dt = self.embed_dim, self._dt
         sel = plan["sel"][(st, self._block_side(i))]
-        nW, N, k = sel["nW"], sel["N"], sel["k"]
-        rows = nW * (k + 1)
+        nW, N, k, rows = sel["nW"], sel["N"], sel["k"], sel["rows"]
         slow = plan["slow"]
-        lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], nW, N, k, bp["ln1_w"], bp["ln1_b"], self.LN_EPS,
-                 slow, plan["a"], C, s)
-        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, 0, rows, 3 * C, C, 0)
-        lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount"], None,
-                 k + 1, nW, k + 1, self.num_heads, bp["cos"], bp["sin"], None, 64 ** -0.5, s)
-        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0, plan["rep1"], k + 1, rows, C, C, 0)
-        self._mlp(bp, plan, rows, slow, plan["rep2"], k + 1)
-        lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], nW, N, k, slow, plan["rep1"], plan["rep2"], s)
+        lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
+                 bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, s)
+        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, rows, 3 * C, C, 0)
+        lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"],
+                 None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], None, 64 ** -0.5, s)
+        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0, plan["rep1"], sel["rep_index"],
+                     rows, C, C, 0)
+        self._mlp(bp, plan, rows, slow, plan["rep2"], sel["rep_index"])
+        lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"], s)
 
     @torch.no_grad()
     def forward(self, x, temp_queries=None, prev_exists=None, temp_ref_points=None, temp_vel=None, temp_timestamp=None,

@@ -24,7 +24,8 @@ constexpr float NEG_BIG = -1.0e30f;
 struct AttnArgs {
     const void* qkv; int64_t ldqkv;
     void* out; int64_t ldo;
-    const int32_t* rows; const int32_t* slots; const int32_t* count; const int32_t* npad;
+    const int32_t* rows; const int32_t* slots; const int32_t* count; const int32_t* count_k; const int32_t* npad;
+    const void* pad_qkv;
     int64_t stride;
     int C;
     const float* cosT; const float* sinT; const float* v_bias;
@@ -58,11 +59,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     T* Ps = Vt + HD * LD;                        // [4 waves][16 q][LD]
 
     const int qt = blockIdx.x, head = blockIdx.y, win = blockIdx.z;
-    const int n = a.count[win];
+    const int n = a.count[win];                  // queries: the window's compact rows
     if (qt * 64 >= n) return;                    // uniform for the workgroup
+    const int nkeys = a.count_k ? a.count_k[win] : n;   // keys: the same rows + virtual kept-pad keys (rows[j] < 0)
     const int32_t* rows = a.rows + (int64_t)win * a.stride;
     const int32_t* slots = a.slots + (int64_t)win * a.stride;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const T* padq = reinterpret_cast<const T*>(a.pad_qkv);
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r16 = lane & 15, g = lane >> 4;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     for (int r = 0; r < 4; ++r) { m[r] = NEG_BIG; l[r] = 0.f; }
 
     T* Pw = Ps + wave * 16 * LD;
-    const int nkt = (n + KT - 1) / KT;
+    const int nkt = (nkeys + KT - 1) / KT;
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                         // previous K/V tile fully consumed
 #pragma unroll
@@ -102,11 +105,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             const int c = tid + it * 256;        // 512 (key, 8-dim chunk) pairs per tile
             const int key = c >> 3, dc = c & 7;
             const int kj = kt * KT + key;
-            const bool ok = kj < n;
+            const bool ok = kj < nkeys;
             const int row = ok ? rows[kj] : 0, slot = ok ? slots[kj] : 0;
+            // a kept padded slot is the row LN(0) = beta for every window: its q|k|v is a per-block constant
+            const T* src = row >= 0 ? qkv + (int64_t)row * a.ldqkv : padq;
             float kx[8], vx[8];
-            load8(qkv + (int64_t)row * a.ldqkv + a.C + head * HD + dc * 8, kx);
-            load8(qkv + (int64_t)row * a.ldqkv + 2 * a.C + head * HD + dc * 8, vx);
+            load8(src + a.C + head * HD + dc * 8, kx);
+            load8(src + 2 * a.C + head * HD + dc * 8, vx);
             rope8(kx, a.cosT + (int64_t)slot * HD + dc * 8, a.sinT + (int64_t)slot * HD + dc * 8);
             if (!ok) {
 #pragma unroll
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         // lane holds S[q = g*4 + r][key = t*16 + r16]; mask keys past the window
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bool kok = kt * KT + t * 16 + r16 < n;
+            const bool kok = kt * KT + t * 16 + r16 < nkeys;
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc[t][r] = kok ? sc[t][r] : NEG_BIG;
         }
@@ -237,12 +242,14 @@ __global__ void window_map_dense_kernel(int V, int h, int w, int L, int32_t* row
 extern "C" {
 
 int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
-                           const int32_t* slots, const int32_t* count, const int32_t* npad, int64_t stride, int64_t nwin,
-                           int64_t max_count, int64_t num_heads, const float* rope_cos, const float* rope_sin,
-                           const float* v_bias, float scale, toc3d_stream_t stream) {
+                           const int32_t* slots, const int32_t* count, const int32_t* count_k, const int32_t* npad,
+                           const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
+                           const float* rope_cos, const float* rope_sin, const float* v_bias, float scale,
+                           toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_window_attention: bad dtype %d", dtype);
     TOC3D_REQUIRE(qkv && out && rows && slots && count && rope_cos && rope_sin, "toc3d_window_attention: null buffer");
     TOC3D_REQUIRE(!npad || v_bias, "toc3d_window_attention: npad given without v_bias");
+    TOC3D_REQUIRE(!count_k || pad_qkv, "toc3d_window_attention: count_k given without pad_qkv");
     TOC3D_REQUIRE(num_heads > 0 && nwin >= 0 && max_count >= 0 && stride >= max_count, "toc3d_window_attention: bad dims");
     const int64_t C = num_heads * HD;
     TOC3D_REQUIRE(ldqkv >= 3 * C && ldo >= C, "toc3d_window_attention: leading dims too small for head_dim 64");
@@ -250,7 +257,7 @@ int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out,
     TOC3D_REQUIRE((ldqkv * esz) % 16 == 0 && ((uintptr_t)qkv % 16) == 0, "toc3d_window_attention: qkv rows must be 16-byte aligned");
     TOC3D_REQUIRE(num_heads <= 65535 && nwin <= 65535, "toc3d_window_attention: grid too large");
     if (nwin == 0 || max_count == 0) return TOC3D_OK;
-    AttnArgs a{qkv, ldqkv, out, ldo, rows, slots, count, npad, stride, (int)C, rope_cos, rope_sin, v_bias, scale};
+    AttnArgs a{qkv, ldqkv, out, ldo, rows, slots, count, count_k, npad, pad_qkv, stride, (int)C, rope_cos, rope_sin, v_bias, scale};
     dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)nwin);
     if (dtype == TOC3D_BF16) launch_attn<bf16_t>(a, grid, as_stream(stream));
     else launch_attn<float>(a, grid, as_stream(stream));

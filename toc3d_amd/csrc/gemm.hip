@@ -29,7 +29,7 @@ struct GemmArgs {
     const float* bias;
     void* out; int64_t ldo;
     const float* res; int64_t ldr; int res_mod;
-    float* rep_out; int rep_period;
+    float* rep_out; const int32_t* rep_index;
     int M, N, K, n_valid;
 };
 
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                 const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
                 float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
                 float* reprow = nullptr;
-                if (a.rep_period > 0 && (row % a.rep_period) == a.rep_period - 1) reprow = a.rep_out + (int64_t)(row / a.rep_period) * a.N;
+                if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     if (!cok[j]) continue;
@@ -344,7 +344,7 @@ extern "C" {
 
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                     void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                    float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                    float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                     toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
@@ -363,10 +363,10 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
     }
     if (epilogue == TOC3D_EPI_RESIDUAL) {
         TOC3D_REQUIRE(!residual || ldr >= N, "toc3d_linear: ldr < N");
-        TOC3D_REQUIRE(rep_period == 0 || rep_out, "toc3d_linear: rep_period set without rep_out");
+        TOC3D_REQUIRE(!rep_index || rep_out, "toc3d_linear: rep_index set without rep_out");
     }
     if (M == 0) return TOC3D_OK;
-    GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, (int)rep_period,
+    GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid};
     int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
@@ -376,9 +376,9 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
 
 int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                  void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                 float* rep_out, int64_t rep_period, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                 float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                  toc3d_stream_t stream) {
-    return toc3d_linear_ex(dtype, epilogue, 0, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_period,
+    return toc3d_linear_ex(dtype, epilogue, 0, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index,
                            M, N, K, n_valid, stream);
 }
 

@@ -172,15 +172,32 @@ __global__ __launch_bounds__(256) void rank_desc_kernel(const float* __restrict_
     order[(int64_t)b * n + rank] = j;
 }
 
+// number of real (non-padded) slots of window `win` of side L over an h x w token grid
+TOC3D_DEV int window_real_count(int win, int h, int w, int L) {
+    const int nWh = (h + L - 1) / L, nWw = (w + L - 1) / L;
+    const int wr = (win / nWw) % nWh, wc = win % nWw;
+    return min(L, h - wr * L) * min(L, w - wc * L);
+}
+
+// Per-window selection + compaction (all in LDS).  The kept ("slow") set of a window is its k best slots; kept
+// *padded* slots are all the same row (x = 0 -> LN(0) = beta) whose block output is thrown away by
+// window_unpartition, so they get no row in the compact buffers: window i owns cap_i = min(k, real_i) + 1 compact
+// rows [off_i, off_i + cap_i) = kept real tokens (sorted order), then -- only if a real token ever lost against a pad,
+// which needs a log-prob <= -1e6 -- explicit zero rows, then the representative token.  The remaining kept pads are
+// *virtual attention keys* (arows = -1, RoPE slot in aslots): cap_i + virtual_i = k + 1 keys, cap_i queries.
 __global__ __launch_bounds__(256) void window_topk_kernel(const float* __restrict__ scores, int V, int h, int w, int L, int k,
                                                           int32_t* __restrict__ order, int32_t* __restrict__ tok, float* __restrict__ wgt,
-                                                          int32_t* __restrict__ arows, int32_t* __restrict__ aslots, int32_t* __restrict__ acount) {
+                                                          int32_t* __restrict__ prow, int32_t* __restrict__ crow_tok,
+                                                          int32_t* __restrict__ rep_index, int32_t* __restrict__ rep_row,
+                                                          int32_t* __restrict__ arows, int32_t* __restrict__ aslots,
+                                                          int32_t* __restrict__ acount_q, int32_t* __restrict__ acount_k) {
     extern __shared__ char s_raw[];
     const int N = L * L;
     float* s_sc = reinterpret_cast<float*>(s_raw);              // [N] score by slot
     int32_t* s_tok = reinterpret_cast<int32_t*>(s_sc + N);       // [N] token row by slot
     int32_t* s_ord = s_tok + N;                                  // [N] slot by rank
     float* s_red = reinterpret_cast<float*>(s_ord + N);          // [4] wave partials
+    int32_t* s_ired = reinterpret_cast<int32_t*>(s_red + 4);     // [8] int partials
     const int nWh = (h + L - 1) / L, nWw = (w + L - 1) / L;
     const int win = blockIdx.x;
     const int v = win / (nWh * nWw), wr = (win / nWw) % nWh, wc = win % nWw;
@@ -191,6 +208,9 @@ __global__ __launch_bounds__(256) void window_topk_kernel(const float* __restric
         s_sc[j] = real ? scores[t] : PAD_SCORE;
         s_tok[j] = real ? t : -1;
     }
+    // compact-row offset of this window: sum of the (static) capacities of the windows before it
+    int offp = 0;
+    for (int i = threadIdx.x; i < win; i += blockDim.x) offp += min(k, window_real_count(i, h, w, L)) + 1;
     __syncthreads();
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
         const float sj = s_sc[j];
@@ -202,25 +222,56 @@ __global__ __launch_bounds__(256) void window_topk_kernel(const float* __restric
         s_ord[rank] = j;
     }
     __syncthreads();
-    // denominator of merge_tokens: sum of the fast (dropped) scores, pads included (toc3d_utils.py:68)
+    // denominator of merge_tokens: sum of the fast (dropped) scores, pads included (toc3d_utils.py:68);
+    // number of real tokens among the kept; window offset
     float part = 0.f;
     for (int p = k + threadIdx.x; p < N; p += blockDim.x) part += s_sc[s_ord[p]];
+    int nreal = 0;
+    for (int p = threadIdx.x; p < k; p += blockDim.x) nreal += s_tok[s_ord[p]] >= 0 ? 1 : 0;
     part = wave_sum(part);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = part;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nreal += __shfl_xor(nreal, o, 64); offp += __shfl_xor(offp, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = part; s_ired[threadIdx.x >> 6] = nreal; s_ired[4 + (threadIdx.x >> 6)] = offp; }
     __syncthreads();
     const float denom = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    const int kk = k < N ? k + 1 : k;
+    const int r_w = s_ired[0] + s_ired[1] + s_ired[2] + s_ired[3];
+    const int off = s_ired[4] + s_ired[5] + s_ired[6] + s_ired[7];
+    const int cap = min(k, window_real_count(win, h, w, L)) + 1;
+    const int e_w = cap - 1 - r_w;                               // explicit zero rows (0 unless a real token scored <= -1e6)
+    const int kk = k + 1;
     for (int p = threadIdx.x; p < N; p += blockDim.x) {
         const int slot = s_ord[p];
+        const int t = s_tok[slot];
         order[(int64_t)win * N + p] = slot;
-        tok[(int64_t)win * N + p] = s_tok[slot];
+        tok[(int64_t)win * N + p] = t;
         wgt[(int64_t)win * N + p] = p >= k ? s_sc[slot] / denom : 0.f;
+        int pr = -1;
+        if (p < k) {
+            int nr = 0;                                          // real tokens ranked before p
+            for (int q = 0; q < p; ++q) nr += s_tok[s_ord[q]] >= 0 ? 1 : 0;
+            int j;                                               // position in the window's key list
+            if (t >= 0) j = nr;
+            else { const int q = p - nr; j = q < e_w ? r_w + q : cap + (q - e_w); }
+            if (j < cap - 1) {                                   // explicit compact row
+                pr = off + j;
+                crow_tok[pr] = t;
+                rep_index[pr] = -1;
+            }
+            arows[(int64_t)win * kk + j] = pr;
+            aslots[(int64_t)win * kk + j] = slot;
+        }
+        prow[(int64_t)win * N + p] = pr;
     }
-    for (int j = threadIdx.x; j < kk; j += blockDim.x) {
-        arows[(int64_t)win * kk + j] = win * kk + j;
-        aslots[(int64_t)win * kk + j] = j < k ? s_ord[j] : k;     // representative token -> slot k (toc3d_eva_vit.py:434)
+    if (threadIdx.x == 0) {
+        const int rr = off + cap - 1;                            // representative token: last row of the window, RoPE slot k
+        crow_tok[rr] = -2;
+        rep_index[rr] = win;
+        rep_row[win] = rr;
+        arows[(int64_t)win * kk + cap - 1] = rr;
+        aslots[(int64_t)win * kk + cap - 1] = k;                 // toc3d_eva_vit.py:434
+        acount_q[win] = cap;
+        acount_k[win] = kk;
     }
-    if (threadIdx.x == 0) acount[win] = kk;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -231,15 +282,14 @@ __global__ __launch_bounds__(256) void window_topk_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int MAXV>
 __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __restrict__ x, int C, const int32_t* __restrict__ tok,
-                                                               const float* __restrict__ wgt, int nW, int N, int k,
+                                                               const float* __restrict__ wgt, const int32_t* __restrict__ crow_tok,
+                                                               const int32_t* __restrict__ rep_row, int nW, int N, int k, int Ms,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                float* __restrict__ shortcut, T* __restrict__ a_out, int64_t lda) {
     extern __shared__ __attribute__((aligned(16))) float s_part[];        // [16][C]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nvec = C >> 2;
-    const bool has_rep = k < N;
-    const int kk = has_rep ? k + 1 : k;
-    const int rep_blocks = has_rep ? nW : 0;
+    const int rep_blocks = nW;
     if ((int)blockIdx.x < rep_blocks) {
         const int win = blockIdx.x;
         f32x4 acc[MAXV];
@@ -295,7 +345,7 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
             const int vi = lane + 64 * i;
             v[i] = vi < nvec ? *reinterpret_cast<const f32x4*>(s_part + 4 * vi) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const int64_t orow = (int64_t)win * kk + k;
+        const int64_t orow = rep_row[win];
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int vi = lane + 64 * i;
@@ -306,11 +356,10 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
         wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
         return;
     }
-    const int64_t id = (int64_t)(blockIdx.x - rep_blocks) * 16 + wave;
-    if (id >= (int64_t)nW * k) return;
-    const int win = (int)(id / k), j = (int)(id % k);
-    const int src = tok[(int64_t)win * N + j];
-    const int64_t orow = (int64_t)win * kk + j;
+    const int64_t orow = (int64_t)(blockIdx.x - rep_blocks) * 16 + wave;
+    if (orow >= Ms) return;
+    const int src = crow_tok[orow];
+    if (src == -2) return;                               // representative row: written by its window's block above
     f32x4 v[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -327,7 +376,8 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
 }
 
 // scatter the slow rows back and add the representative token's branch outputs to the fast rows, in place.
-__global__ __launch_bounds__(256) void scatter_update_kernel(float* __restrict__ x, int C, const int32_t* __restrict__ tok, int nW, int N, int k,
+__global__ __launch_bounds__(256) void scatter_update_kernel(float* __restrict__ x, int C, const int32_t* __restrict__ tok,
+                                                             const int32_t* __restrict__ prow, int nW, int N, int k,
                                                              const float* __restrict__ slow_out, const float* __restrict__ r1,
                                                              const float* __restrict__ r2) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -336,11 +386,10 @@ __global__ __launch_bounds__(256) void scatter_update_kernel(float* __restrict__
     const int win = (int)(id / N), p = (int)(id % N);
     const int dst = tok[id];
     if (dst < 0) return;
-    const int kk = k < N ? k + 1 : k;
     const int nvec = C >> 2;
     float* xr = x + (int64_t)dst * C;
     if (p < k) {
-        const float* s = slow_out + ((int64_t)win * kk + p) * C;
+        const float* s = slow_out + (int64_t)prow[id] * C;
         for (int vi = lane; vi < nvec; vi += 64) *reinterpret_cast<f32x4*>(xr + 4 * vi) = *reinterpret_cast<const f32x4*>(s + 4 * vi);
     } else {
         const float* a = r1 + (int64_t)win * C;
@@ -419,53 +468,63 @@ int toc3d_rank_desc(const float* scores, int64_t B, int64_t n, int64_t* order, t
     return TOC3D_OK;
 }
 
+int64_t toc3d_window_topk_rows(int64_t V, int64_t h, int64_t w, int64_t L, int64_t k) {
+    if (V <= 0 || h <= 0 || w <= 0 || L <= 0 || k < 0) return -1;
+    const int64_t nWh = (h + L - 1) / L, nWw = (w + L - 1) / L;
+    int64_t rows = 0;
+    for (int64_t wr = 0; wr < nWh; ++wr)
+        for (int64_t wc = 0; wc < nWw; ++wc) {
+            const int64_t real = (L < h - wr * L ? L : h - wr * L) * (L < w - wc * L ? L : w - wc * L);
+            rows += (k < real ? k : real) + 1;
+        }
+    return rows * V;
+}
+
 int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int64_t L, int64_t k, int32_t* order,
-                      int32_t* tok, float* wgt, int32_t* arows, int32_t* aslots, int32_t* acount, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(scores && order && tok && wgt && arows && aslots && acount, "toc3d_window_topk: null buffer");
+                      int32_t* tok, float* wgt, int32_t* prow, int32_t* crow_tok, int32_t* rep_index, int32_t* rep_row,
+                      int32_t* arows, int32_t* aslots, int32_t* acount_q, int32_t* acount_k, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(scores && order && tok && wgt && prow && crow_tok && rep_index && rep_row && arows && aslots && acount_q && acount_k,
+                  "toc3d_window_topk: null buffer");
     TOC3D_REQUIRE(V > 0 && h > 0 && w > 0 && L > 0 && L <= 64, "toc3d_window_topk: bad dims");
     const int64_t N = L * L;
-    TOC3D_REQUIRE(k >= 0 && k <= N, "toc3d_window_topk: k=%lld outside [0, %lld]", (long long)k, (long long)N);
+    TOC3D_REQUIRE(k >= 0 && k < N, "toc3d_window_topk: k=%lld outside [0, %lld) (keep-all is the dense Block path)", (long long)k, (long long)N);
     const int nW = (int)(V * ((h + L - 1) / L) * ((w + L - 1) / L));
-    hipLaunchKernelGGL(window_topk_kernel, dim3(nW), dim3(256), (size_t)N * 12 + 16, as_stream(stream), scores, (int)V, (int)h, (int)w,
-                       (int)L, (int)k, order, tok, wgt, arows, aslots, acount);
+    hipLaunchKernelGGL(window_topk_kernel, dim3(nW), dim3(256), (size_t)N * 12 + 64, as_stream(stream), scores, (int)V, (int)h, (int)w,
+                       (int)L, (int)k, order, tok, wgt, prow, crow_tok, rep_index, rep_row, arows, aslots, acount_q, acount_k);
     TOC3D_LAUNCH_CHECK("toc3d_window_topk");
     return TOC3D_OK;
 }
 
-int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, int64_t nW, int64_t N,
-                          int64_t k, const float* gamma, const float* beta, float eps, float* shortcut, void* a_out,
-                          int64_t lda, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(x && tok && wgt && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln: null buffer");
+int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
+                          const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
+                          const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && tok && wgt && crow_tok && rep_row && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln: null buffer");
     TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
-    TOC3D_REQUIRE(k >= 0 && k <= N && lda >= C && lda % 4 == 0, "toc3d_gather_merge_ln: bad k / lda");
+    TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW, "toc3d_gather_merge_ln: bad k / lda / rows");
     if (nW <= 0) return TOC3D_OK;
-    const int rep_blocks = k < N ? (int)nW : 0;
-    const int row_blocks = (int)((nW * k + 15) / 16);
-    if (rep_blocks + row_blocks == 0) return TOC3D_OK;
-    dim3 grid((unsigned)(rep_blocks + row_blocks)), block(1024);
+    dim3 grid((unsigned)(nW + (rows + 15) / 16)), block(1024);
     const size_t lds = (size_t)16 * C * 4;
     hipStream_t s = as_stream(stream);
     if (dtype == TOC3D_BF16) {
         static bool set = false;
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_merge_ln_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); set = true; }
-        hipLaunchKernelGGL((gather_merge_ln_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, (int)nW, (int)N, (int)k, gamma, beta, eps, shortcut, (bf16_t*)a_out, lda);
+        hipLaunchKernelGGL((gather_merge_ln_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (bf16_t*)a_out, lda);
     } else if (dtype == TOC3D_F32) {
         static bool set = false;
         if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_merge_ln_kernel<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); set = true; }
-        hipLaunchKernelGGL((gather_merge_ln_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, (int)nW, (int)N, (int)k, gamma, beta, eps, shortcut, (float*)a_out, lda);
+        hipLaunchKernelGGL((gather_merge_ln_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (float*)a_out, lda);
     } else { toc3d_set_error("toc3d_gather_merge_ln: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln");
     return TOC3D_OK;
 }
 
-int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, int64_t nW, int64_t N, int64_t k, const float* slow_out,
-                         const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(x && tok && slow_out, "toc3d_scatter_update: null buffer");
-    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && k >= 0 && k <= N, "toc3d_scatter_update: bad dims");
-    TOC3D_REQUIRE(k == N || (rep_raw1 && rep_raw2), "toc3d_scatter_update: representative-token deltas missing");
+int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k,
+                         const float* slow_out, const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && tok && prow && slow_out && rep_raw1 && rep_raw2, "toc3d_scatter_update: null buffer");
+    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && k >= 0 && k < N, "toc3d_scatter_update: bad dims");
     if (nW <= 0 || N <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((nW * N + 3) / 4));
-    hipLaunchKernelGGL(scatter_update_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)C, tok, (int)nW, (int)N, (int)k, slow_out, rep_raw1, rep_raw2);
+    hipLaunchKernelGGL(scatter_update_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)C, tok, prow, (int)nW, (int)N, (int)k, slow_out, rep_raw1, rep_raw2);
     TOC3D_LAUNCH_CHECK("toc3d_scatter_update");
     return TOC3D_OK;
 }

@@ -20,8 +20,8 @@ _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
 # name -> argtypes, in header order.  'p' pointer, 'l' int64, 'i' int, 'f' float
 _SIGS = {
-    "toc3d_linear": "iiplplpplpllplllllp",
-    "toc3d_linear_ex": "iiiplplpplpllplllllp",
+    "toc3d_linear": "iiplplpplpllppllllp",
+    "toc3d_linear_ex": "iiiplplpplpllppllllp",
     "toc3d_pack_weight": "ipllpllp",
     "toc3d_pack_swiglu": "ippppllppllp",
     "toc3d_im2col_patches": "ippllllllp",
@@ -29,11 +29,11 @@ _SIGS = {
     "toc3d_layernorm_rows": "iplppppfplllp",
     "toc3d_layernorm_act": "iplppfplllp",
     "toc3d_window_map_dense": "llllppppp",
-    "toc3d_window_attention": "iplplppppllllpppfp",
+    "toc3d_window_attention": "iplplppppppllllpppfp",
     "toc3d_rank_desc": "pllpp",
-    "toc3d_window_topk": "plllllppppppp",
-    "toc3d_gather_merge_ln": "iplpplllppfpplp",
-    "toc3d_scatter_update": "plplllpppp",
+    "toc3d_window_topk": "plllllpppppppppppp",
+    "toc3d_gather_merge_ln": "iplppppllllppfpplp",
+    "toc3d_scatter_update": "plpplllpppp",
     "toc3d_pack_motion_weights": "p" * 24 + "p",
     "toc3d_motion_queries": "pllppppippllpp",
     "toc3d_collapse_query_scorer": "ppppplllfppp",
@@ -67,6 +67,8 @@ def load():
     lib.toc3d_abi_version.restype = _I
     lib.toc3d_last_error.restype = ctypes.c_char_p
     lib.toc3d_motion_weights_floats.restype = _I64
+    lib.toc3d_window_topk_rows.restype = _I64
+    lib.toc3d_window_topk_rows.argtypes = [_I64] * 5
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = _I

@@ -103,9 +103,9 @@ class CPFPN(nn.Module):
         else:
             a = ws["a"]
             lib.call("toc3d_pack_weight", dt, nhwc, M, Cin, a, M, Kl, s)           # f32 -> act conversion with K padding
-        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, 0, M, Co, Kl, 0, s)
+        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, None, M, Co, Kl, 0, s)
         lib.call("toc3d_im2col_3x3", dt, ws["lat"], ws["col"], Kf, V, h, w, Co, s)
-        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, ws["col"], Kf, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, 0, M, Co, Kf, 0, s)
+        lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, ws["col"], Kf, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, None, M, Co, Kf, 0, s)
         out0 = torch.empty(V, Co, h, w, dtype=torch.float32, device=dev)
         lib.call("toc3d_nhwc_to_nchw", ws["o0"], out0, V, h * w, Co, s)
         outs = [out0]
