@@ -83,7 +83,9 @@ def main():
     ap.add_argument("--config", default="toc3d_faster")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--hw", default="320x800")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--groups", type=int, default=2, help="concurrent view groups (independent views on separate HIP streams)")
+    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of launching eagerly (measured: no faster)")
+    ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
@@ -109,6 +111,7 @@ def main():
     model.load_state_dict(sd_cpu)
     model = model.to(dev).eval()
     model.alias_outputs = True
+    model.view_groups = args.groups
     neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision=args.precision))
     neck.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG))
     neck = neck.to(dev).eval()
@@ -144,7 +147,7 @@ def main():
         step()
     torch.cuda.synchronize()
     graph = None
-    if not args.no_graph and world == 1:
+    if args.graph and world == 1:
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -181,10 +184,22 @@ def main():
             e0.record()
             orig_call(name, *a)
             e1.record()
-            rec.append((name, a[1] if name == "toc3d_linear" else -1, e0, e1))
+            if name == "toc3d_linear_ex":
+                tag = f"[epi{a[1]} v{a[2]} M={a[15]} N={a[16]} K={a[17]}]"
+            elif name == "toc3d_linear":
+                tag = f"[epi{a[1]} M={a[14]} N={a[15]} K={a[16]}]"
+            elif name == "toc3d_window_attention":
+                tag = f"[stride={a[11]} nwin={a[12]} maxq={a[13]}]"
+            else:
+                tag = ""
+            rec.append((name, tag, e0, e1))
 
         n_inst = min(args.steps, 5)
         world_saved, world = world, 1                  # no collective in the instrumented pass
+        model.view_groups = 1                          # one stream: per-launch durations are not inflated by co-running kernels
+        for _ in range(2):
+            step()                                     # builds / autotunes the single-group plan outside the instrumented pass
+        torch.cuda.synchronize()
         try:
             lib.call = timed_call
             for _ in range(n_inst):
@@ -193,11 +208,17 @@ def main():
         finally:
             lib.call = orig_call
             world = world_saved
-        for name, epi, e0, e1 in rec:
-            key = name if epi < 0 else f"{name}[epi{epi}]"
-            d = breakdown.setdefault(key, [0, 0.0])
+            model.view_groups = args.groups
+        detail = {}
+        for name, tag, e0, e1 in rec:
+            t = e0.elapsed_time(e1)
+            d = breakdown.setdefault(name, [0, 0.0])
             d[0] += 1
-            d[1] += e0.elapsed_time(e1)
+            d[1] += t
+            if tag:
+                d = detail.setdefault(name + tag, [0, 0.0])
+                d[0] += 1
+                d[1] += t
         gemm_ms = sum(v[1] for k, v in breakdown.items() if k.startswith("toc3d_linear"))
         gemm_n = sum(v[0] for k, v in breakdown.items() if k.startswith("toc3d_linear"))
         alg, iss, n_launch = flop_model(cfg, V, h, w)
@@ -210,13 +231,16 @@ def main():
                 "unit": "TFLOP/s", "traffic": None,
                 "avg_launch_ms": avg_ms, "launches_per_step": gemm_n / n_inst,
                 "algorithmic_flop_per_step": alg + neck_flops, "issued_flop_per_step": iss + neck_flops,
-                "note": "HIP events around each launch in an eager instrumented pass of the same step run right after the timed region"}
+                "note": "HIP events around each launch in an eager, single-stream instrumented pass of the same step run right after the timed region"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         tot = sum(v[1] for v in breakdown.values())
         print("[bench] per-op GPU time per step (ms), event-timed eager pass:", file=sys.stderr)
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][1]):
             print(f"   {k:34s} {v[1] / n_inst:8.3f} ms  {v[0] // n_inst:4d} launches  {100 * v[1] / tot:5.1f}%", file=sys.stderr)
         print(f"   {'sum':34s} {tot / n_inst:8.3f} ms", file=sys.stderr)
+        print("[bench] per-shape detail (us per launch, launches per step):", file=sys.stderr)
+        for k, v in sorted(detail.items(), key=lambda kv: -kv[1][1]):
+            print(f"   {k:70s} {1e3 * v[1] / v[0]:8.1f} us x {v[0] // n_inst:3d}", file=sys.stderr)
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -231,6 +255,7 @@ def main():
             "config": {"workload": f"{args.config} EVA-02 ViT-L backbone + CPFPN neck, 6 views x 3x{H}x{W} per frame, 1 frame per rank per step, "
                                    f"random-init weights, prev_exists=True, injected Gumbel noise",
                        "frames_per_step": world, "launch": "hipGraph replay" if graph is not None else "eager",
+                       "view_groups": args.groups,
                        "baseline_note": "vs_baseline divides by the paper's 4.78 backbone-frames/s (fp32, GPU model unstated, BASELINE.md section 1)"},
             "whole_path_tflops": (alg / (ms * 1e-3)) / 1e12,
         }

@@ -135,11 +135,15 @@ int toc3d_window_map_dense(int64_t V, int64_t h, int64_t w, int64_t L, int32_t* 
  * projection of beta computed at pack time) with RoPE slot slots[i*stride+j]; they are keys only (their outputs are
  * dropped by window_unpartition).  out act [*, ldo]: out[row, head*64 + d].  Flash-style, keys streamed in tiles of 64
  * through LDS, online softmax in f32.  max_count = max_i count[i] (grid sizing only).
+ * rope_cos/rope_sin are the reference's buffers freqs_cos/freqs_sin [rope_side^2, 64]; the kernel relies on their axial
+ * structure (VisionRotaryEmbeddingFast, eva_utils.py:362-371: dims 0..31 depend on slot / rope_side, dims 32..63 on
+ * slot % rope_side, each frequency repeated for the pair (2i, 2i+1)) and keeps a [2, rope_side, 16] extract in LDS;
+ * the host module verifies that structure when it packs the buffers.
  */
 int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
                            const int32_t* slots, const int32_t* count, const int32_t* count_k, const int32_t* npad,
                            const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
-                           const float* rope_cos, const float* rope_sin, const float* v_bias, float scale,
+                           const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
                            toc3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -167,3 +167,40 @@ def test_state_dict_reload_repacks(golden_dir):
     with torch.no_grad():
         ref = O.forward_eva(sd2, cfg, inp["x"])["last_feat"]
     assert not torch.allclose(a, b) and rel_max(b, ref) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["toc3d_tiny", "eva_tiny"])
+def test_view_groups_on_separate_streams_are_bit_identical(name):
+    """Views are independent units: splitting them into concurrently running groups must not change a single bit."""
+    cfg, m = build(name, "bf16")
+    inp = synth.make_inputs(cfg, views_per_frame=2)
+    run = (lambda: run_toc3d(m, inp, True).img_feats["last_feat"].clone()) if synth.is_toc3d(cfg) else (lambda: m(inp["x"].to(DEV))["last_feat"].clone())
+    a = run()
+    m.view_groups = 2
+    b = run()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    if synth.is_toc3d(cfg):
+        o1 = run_toc3d(m, inp, True)
+        m.view_groups = 1
+        o2 = run_toc3d(m, inp, True)
+        for s in range(3):
+            assert torch.equal(o1.keep_idx[s], o2.keep_idx[s]) and torch.equal(o1.token_masks[s], o2.token_masks[s])
+
+
+def test_vitl_hires_1600x640_fp32_matches_oracle():
+    """BASELINE.json config 4 geometry (40x100 tokens: 21 + 10 windows per view), 1 view, against the oracle run on the host."""
+    cfg, m = build("toc3d_faster", "fp32")
+    sd = synth.make_state_dict(cfg)
+    inp = synth.make_inputs(cfg, views_per_frame=1, hw=(640, 1600))
+    with torch.no_grad():
+        ref = O.forward_toc3d(sd, cfg, inp["x"], inp["temp_queries"], inp["temp_ref_points"], inp["temp_vel"], inp["temp_timestamp"],
+                              inp["temp_ego_pose"], inp["ego_pose_inv"], True, inp["gumbel"])
+    out = run_toc3d(m, inp, True)
+    feat = out.img_feats["last_feat"]
+    assert tuple(feat.shape) == (1, 1024, 40, 100)
+    for s in range(3):
+        assert iou(out.keep_idx[s], ref["keep_idx"][s].numpy()) > 0.99
+    err = rel_max(feat, ref["last_feat"])
+    print(f"[vitl toc3d_faster 1600x640 fp32, 1 view] rel max err {err:.3e}")
+    assert err < 1e-3

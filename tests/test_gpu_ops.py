@@ -201,7 +201,7 @@ def test_window_attention_dense_with_virtual_pads(name, dt, tdt, L):
     assert int(count.sum()) == M and int((count + npad).min()) == N
     out = torch.zeros(M, C, dtype=tdt, device=DEV)
     lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots, count, None, npad, None, N, nW, int(count.max()), heads,
-             sd[pre + "rope.freqs_cos"].to(DEV), sd[pre + "rope.freqs_sin"].to(DEV), sd[pre + "v_bias"].to(DEV), 64 ** -0.5, S())
+             sd[pre + "rope.freqs_cos"].to(DEV), sd[pre + "rope.freqs_sin"].to(DEV), L, sd[pre + "v_bias"].to(DEV), 64 ** -0.5, S())
     err = relerr(out.float(), ref)
     assert err < (5e-5 if dt == lib.F32 else 3e-2), err
 
@@ -231,7 +231,7 @@ def test_window_attention_selected_slots(name, dt, tdt, n):
     count = torch.full((nW,), n, dtype=torch.int32, device=DEV)
     out = torch.zeros(M, C, dtype=tdt, device=DEV)
     lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots.int().to(DEV), count, None, None, None, n, nW, n, heads,
-             cosT.to(DEV), sinT.to(DEV), None, 64 ** -0.5, S())
+             cosT.to(DEV), sinT.to(DEV), 20, None, 64 ** -0.5, S())
     err = relerr(out.float(), ref)
     assert err < (5e-5 if dt == lib.F32 else 3e-2), err
 
@@ -381,14 +381,14 @@ def test_attention_virtual_pad_keys_equal_explicit_pad_rows(name, dt, tdt):
     rows = torch.arange(M, dtype=torch.int32).reshape(nW, n).to(DEV)
     cnt = torch.full((nW,), n, dtype=torch.int32, device=DEV)
     full = torch.zeros(M, C, dtype=tdt, device=DEV)
-    lib.call("toc3d_window_attention", dt, qkv, 3 * C, full, C, rows, slots.to(DEV), cnt, None, None, None, n, nW, n, heads, cosT, sinT, None, 64 ** -0.5, S())
+    lib.call("toc3d_window_attention", dt, qkv, 3 * C, full, C, rows, slots.to(DEV), cnt, None, None, None, n, nW, n, heads, cosT, sinT, 16, None, 64 ** -0.5, S())
     # virtual: only the real rows are queries; pads are keys taken from pad_qkv
     pad_qkv = qkv[n_real:n_real + 1].clone()
     rows_v = rows.clone()
     rows_v[:, n_real:] = -1
     cq = torch.full((nW,), n_real, dtype=torch.int32, device=DEV)
     virt = torch.zeros(M, C, dtype=tdt, device=DEV)
-    lib.call("toc3d_window_attention", dt, qkv, 3 * C, virt, C, rows_v, slots.to(DEV), cq, cnt, None, pad_qkv, n, nW, n_real, heads, cosT, sinT, None,
+    lib.call("toc3d_window_attention", dt, qkv, 3 * C, virt, C, rows_v, slots.to(DEV), cq, cnt, None, pad_qkv, n, nW, n_real, heads, cosT, sinT, 16, None,
              64 ** -0.5, S())
     fr = full.view(nW, n, C)[:, :n_real].float()
     vr = virt.view(nW, n, C)[:, :n_real].float()
@@ -506,11 +506,11 @@ def test_nhwc_to_nchw_and_im2col3x3(name, dt, tdt):
 @pytest.mark.parametrize("name,dt,tdt", DTYPES)
 def test_linear_variants_are_bit_identical(name, dt, tdt):
     """Every tile / pipeline variant of toc3d_linear_ex accumulates K in the same order: outputs must be bit-equal."""
-    M, N, K = 777, 640, 320
+    M, N, K = 777, 640, 512
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
     ref = None
-    for v in (list(range(1, 11)) + list(range(13, 22)) + ([11, 12] if dt == lib.BF16 else [])):
+    for v in (list(range(1, 11)) + list(range(13, 28)) + ([11, 12] if dt == lib.BF16 else [])):
         out = torch.zeros(M, N, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, None, M, N, K, 0, S())
         if ref is None:

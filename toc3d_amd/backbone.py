@@ -183,6 +183,8 @@ class _BackboneBase(nn.Module):
         self.autotune = True            # pick the GEMM tile variant per shape by measurement (first eager forward)
         self.alias_outputs = False      # True: returned tensors alias the reused workspace (benchmarks)
         self._side = None               # side stream: query-side scorer prep / image-level ranking overlap the blocks
+        self.view_groups = 1            # > 1: split the views into groups that run concurrently on separate streams
+        self._gstreams = []
 
     # -- state-dict hook: re-pack after new weights arrive ------------------------------------------
     def _load_from_state_dict(self, *a, **k):
@@ -246,9 +248,26 @@ class _BackboneBase(nn.Module):
             for n, mod in (("ln1", blk.norm1), ("ln2", blk.norm2), ("lnf", m.ffn_ln)):
                 p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
             p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
+            p["rope_side"] = self._check_axial_rope(p["cos"], p["sin"])
             blocks.append(p)
         torch.cuda.current_stream().synchronize()      # the f32 temporaries above must outlive the pack kernels
         return blocks
+
+    @staticmethod
+    def _check_axial_rope(cos, sin):
+        """The attention kernel keeps a [2, L, 16] extract of the RoPE buffers in LDS, which is exact iff the buffers have
+        VisionRotaryEmbeddingFast's axial structure (eva_utils.py:362-371).  Verified here, on the loaded buffers."""
+        L = int(math.isqrt(cos.shape[0]))
+        if L * L != cos.shape[0] or cos.shape[1] != 64:
+            raise NotImplementedError("RoPE buffers must be [L*L, 64]")
+        for t in (cos, sin):
+            g = t.view(L, L, 64)
+            ok = (torch.equal(g[:, :, :32], g[:, :1, :32].expand(L, L, 32)) and torch.equal(g[:, :, 32:], g[:1, :, 32:].expand(L, L, 32))
+                  and torch.equal(t[:, 0::2], t[:, 1::2]))
+            if not ok:
+                raise NotImplementedError("RoPE buffers do not have the axial (row | column, pair-repeated) structure of "
+                                          "VisionRotaryEmbeddingFast; the HIP attention kernel only supports that form")
+        return L
 
     def _pack_common(self):
         dev = self.patch_embed.proj.weight.device
@@ -306,7 +325,7 @@ class _BackboneBase(nn.Module):
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
-    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19), lib.F32: (1, 8, 9, 10, 13, 14, 16, 17)}
+    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27), lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26)}
 
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
         """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
@@ -376,9 +395,41 @@ class _BackboneBase(nn.Module):
         lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0)
         lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None,
-                 dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["v_bias"], 64 ** -0.5, s)
+                 dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], bp["v_bias"], 64 ** -0.5, s)
         self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, None, M, C, C, 0)
         self._mlp(bp, plan, M, x, None, None)
+
+    # -- view groups: independent views (SURVEY.md 8e) processed concurrently on separate HIP streams ----------
+    def _group_layout(self, V, B):
+        """[(view0, n_views, frame0, n_frames)] per group; falls back to one group when the split is not frame-aligned."""
+        G = max(1, int(self.view_groups))
+        vpf = V // B
+        if G > 1 and V % G == 0:
+            Vg = V // G
+            if Vg % vpf == 0:
+                return [(g * Vg, Vg, g * (Vg // vpf), Vg // vpf) for g in range(G)]
+            if vpf % Vg == 0:
+                return [(g * Vg, Vg, (g * Vg) // vpf, 1) for g in range(G)]
+        return [(0, V, 0, B)]
+
+    def _group_streams(self, n):
+        while len(self._gstreams) < n - 1:
+            self._gstreams.append(torch.cuda.Stream())
+        return [torch.cuda.current_stream()] + self._gstreams[: n - 1]
+
+    @staticmethod
+    def _fork(streams):
+        ev = torch.cuda.Event()
+        ev.record(streams[0])
+        for st in streams[1:]:
+            st.wait_event(ev)
+
+    @staticmethod
+    def _join(streams):
+        for st in streams[1:]:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            streams[0].wait_event(ev)
 
     def _check_input(self, x):
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
@@ -424,14 +475,38 @@ class EVA_ViT(_BackboneBase):
         x = self._check_input(x)
         if self._packed is None:
             self._packed = self._pack_common()
-        key = tuple(x.shape)
+        key = (tuple(x.shape), self.view_groups)
+        V = x.shape[0]
         if key not in self._plans:
-            self._plans[key] = self._base_plan(x.shape[0], x.shape[2], x.shape[3], x.device, 0)
-        plan, P = self._plans[key], self._packed
-        self._stem(plan, x, P)
+            layout = self._group_layout(V, V)
+            master = self._base_plan(V, x.shape[2], x.shape[3], x.device, 0) if len(layout) == 1 else None
+            groups = []
+            if master is None:
+                master = dict(V=V, h=x.shape[2] // self.patch_size, w=x.shape[3] // self.patch_size)
+                master["x"] = torch.empty(V * master["h"] * master["w"], self.embed_dim, dtype=torch.float32, device=x.device)
+                for (v0, nv, _, _) in layout:
+                    gp = self._base_plan(nv, x.shape[2], x.shape[3], x.device, 0)
+                    gp["x"] = master["x"][v0 * gp["T"]:(v0 + nv) * gp["T"]]
+                    gp["v0"], gp["nv"] = v0, nv
+                    groups.append(gp)
+            else:
+                master["v0"], master["nv"] = 0, V
+                groups = [master]
+            master["groups"] = groups
+            self._plans[key] = master
+        master, P = self._plans[key], self._packed
+        groups = master["groups"]
+        streams = self._group_streams(len(groups))
+        self._fork(streams)
+        for g, gp in enumerate(groups):
+            with torch.cuda.stream(streams[g]):
+                self._stem(gp, x[gp["v0"]:gp["v0"] + gp["nv"]], P)
         for i in range(self.depth):
-            self._dense_block(i, plan, P)
-        return {self._out_features[0]: self._feature_view(plan)}
+            for g, gp in enumerate(groups):
+                with torch.cuda.stream(streams[g]):
+                    self._dense_block(i, gp, P)
+        self._join(streams)
+        return {self._out_features[0]: self._feature_view(master)}
 
 
 class ToC3DEVAViT(_BackboneBase):
@@ -575,17 +650,31 @@ class ToC3DEVAViT(_BackboneBase):
                                     prow=torch.empty(nW, N, **i32), crow_tok=torch.empty(ms, **i32), rep_index=torch.empty(ms, **i32),
                                     rep_row=torch.empty(nW, **i32), arows=torch.empty(nW, k + 1, **i32),
                                     aslots=torch.empty(nW, k + 1, **i32), acount_q=torch.empty(nW, **i32), acount_k=torch.empty(nW, **i32))
-        Q = self.pruning_num_queries
         ns = len(self.pruning_loc)
-        plan["mq"] = torch.empty(ns, B, Q, QUERY_DIM, **f32)
-        plan["wc"] = torch.empty(ns, B, C, 2, **f32)
-        plan["bc"] = torch.empty(ns, B, 2, **f32)
         plan["pred"] = [torch.empty(M, 2, **f32) for _ in range(ns)]
-        plan["score"] = [torch.empty(M, **f32) for _ in range(ns)]
-        plan["mask"] = [torch.empty(M, **f32) for _ in range(ns)]
-        plan["order"] = [torch.empty(V, T, dtype=torch.int64, device=dev) for _ in range(ns)]
         plan["u1"] = plan["u2"] = None                    # first-frame scorer scratch, allocated on demand
         return plan
+
+    def _master_plan(self, V, H, W, B, dev):
+        """Shared outputs (x, masks, scores, image-level order, query-side buffers) + one work plan per view group."""
+        C, Q, ns = self.embed_dim, self.pruning_num_queries, len(self.pruning_loc)
+        h, w = H // self.patch_size, W // self.patch_size
+        T = h * w
+        f32 = dict(dtype=torch.float32, device=dev)
+        m = dict(V=V, h=h, w=w, T=T, M=V * T, x=torch.empty(V * T, C, **f32),
+                 score=[torch.empty(V * T, **f32) for _ in range(ns)], mask=[torch.empty(V * T, **f32) for _ in range(ns)],
+                 order=[torch.empty(V, T, dtype=torch.int64, device=dev) for _ in range(ns)],
+                 prep=dict(mq=torch.empty(ns, B, Q, QUERY_DIM, **f32), wc=torch.empty(ns, B, C, 2, **f32), bc=torch.empty(ns, B, 2, **f32), ev=None))
+        m["groups"] = []
+        for (v0, nv, f0, nf) in self._group_layout(V, B):
+            gp = self._plan(nv, H, W, nf, dev)
+            gp["v0"], gp["nv"], gp["frame0"], gp["prep"] = v0, nv, f0, m["prep"]
+            gp["x"] = m["x"][v0 * T:(v0 + nv) * T]
+            gp["score"] = [t[v0 * T:(v0 + nv) * T] for t in m["score"]]
+            gp["mask"] = [t[v0 * T:(v0 + nv) * T] for t in m["mask"]]
+            gp["order"] = [t[v0:v0 + nv] for t in m["order"]]
+            m["groups"].append(gp)
+        return m
 
     # -- scorer stage (toc3d_eva_vit.py:264-285) -------------------------------------------------------
     def _score_stage(self, st, plan, P, inputs, prev_exists, gumbel):
@@ -599,8 +688,10 @@ class ToC3DEVAViT(_BackboneBase):
         pred, score, mask = plan["pred"][st], plan["score"][st], plan["mask"][st]
         if prev_exists:
             if st == 0:
-                self._join_side(plan)          # query-side prep (all stages) ran on the side stream since forward() began
-            lib.call("toc3d_score_tokens", x, C, mask_prev, plan["wc"][st], plan["bc"][st], g, V, T, V // B, pred, score, mask, s)
+                torch.cuda.current_stream().wait_event(plan["prep"]["ev"])   # query-side prep (all stages) ran on the side stream
+            f0 = plan["frame0"]
+            lib.call("toc3d_score_tokens", x, C, mask_prev, plan["prep"]["wc"][st][f0:f0 + B], plan["prep"]["bc"][st][f0:f0 + B], g, V, T, V // B,
+                     pred, score, mask, s)
         else:
             # ScoreBasedTokenSelector.score (toc3d_utils.py:114-129); the reference also evaluates the motion-aware
             # queries here and discards them (:376-385) -- skipped, no observable effect
@@ -640,21 +731,27 @@ class ToC3DEVAViT(_BackboneBase):
             torch.cuda.current_stream().wait_event(ev)
             plan["side_pending"] = False
 
-    def _query_prep(self, plan, P, inputs):
-        """get_motion_aware_queries + the collapse of input_proj/einsum/aggregate for all stages (identical inputs,
-        per-stage weights; toc3d_utils.py:376-385), launched on the side stream at the start of forward()."""
+    def _query_prep(self, prep, P, inputs):
+        """get_motion_aware_queries + the collapse of input_proj/einsum/aggregate for all stages and frames (identical
+        inputs, per-stage weights; toc3d_utils.py:376-385), launched on the side stream at the start of forward()."""
         tq, rp, vel, ts, pose, inv = inputs
-        B, Q, C = plan["B"], tq.shape[1], self.embed_dim
+        B, Q, C = tq.shape[0], tq.shape[1], self.embed_dim
         ns = len(self.pruning_loc)
-        self._fork_side(plan)
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
         with torch.cuda.stream(self._side):
             s = lib.stream_ptr()
             lib.call("toc3d_motion_queries", P["motion_all"], ns, P["motion_stride"], tq, rp, vel, ts, 1 if ts.dtype == torch.float64 else 0,
-                     pose, inv, B, Q, plan["mq"], s)
+                     pose, inv, B, Q, prep["mq"], s)
             for st in range(ns):
                 q = P["scorers"][st]
-                lib.call("toc3d_collapse_query_scorer", plan["mq"][st], q["w_in"], q["b_in"], q["w_agg"], q["b_agg"], B, Q, C, float(q["scale"]),
-                         plan["wc"][st], plan["bc"][st], s)
+                lib.call("toc3d_collapse_query_scorer", prep["mq"][st], q["w_in"], q["b_in"], q["w_agg"], q["b_agg"], B, Q, C, float(q["scale"]),
+                         prep["wc"][st], prep["bc"][st], s)
+            prep["ev"] = torch.cuda.Event()
+            prep["ev"].record(self._side)
 
     def _accel_block(self, i, st, plan, P):
         """ToC3DEVAViTBlock.forward (toc3d_eva_vit.py:395-477)."""
@@ -668,7 +765,7 @@ class ToC3DEVAViT(_BackboneBase):
                  bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, s)
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, rows, 3 * C, C, 0)
         lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"],
-                 None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], None, 64 ** -0.5, s)
+                 None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], None, 64 ** -0.5, s)
         self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0, plan["rep1"], sel["rep_index"],
                      rows, C, C, 0)
         self._mlp(bp, plan, rows, slow, plan["rep2"], sel["rep_index"])
@@ -695,10 +792,11 @@ class ToC3DEVAViT(_BackboneBase):
             ts = ts.contiguous() if ts.dtype == torch.float64 else ts.float().contiguous()
             inputs = (f(temp_queries), f(temp_ref_points), f(temp_vel), ts, f(temp_ego_pose), f(ego_pose_inv))
         assert V % B == 0
-        key = (tuple(x.shape), B)
+        key = (tuple(x.shape), B, self.view_groups)
         if key not in self._plans:
-            self._plans[key] = self._plan(V, x.shape[2], x.shape[3], B, dev)
+            self._plans[key] = self._master_plan(V, x.shape[2], x.shape[3], B, dev)
         plan = self._plans[key]
+        groups = plan["groups"]
         T = plan["T"]
         ns = len(self.pruning_loc)
         if gumbel_noise is None:
@@ -708,19 +806,31 @@ class ToC3DEVAViT(_BackboneBase):
             gumbel = [g.to(dev).float().reshape(V * T, 2).contiguous() for g in gumbel_noise]
 
         if prev and ns:
-            self._query_prep(plan, P, inputs)
-        self._stem(plan, x, P)
+            self._query_prep(plan["prep"], P, inputs)
+        streams = self._group_streams(len(groups))
+        self._fork(streams)
+        for g, gp in enumerate(groups):
+            with torch.cuda.stream(streams[g]):
+                self._stem(gp, x[gp["v0"]:gp["v0"] + gp["nv"]], P)
         st = -1
         for i in range(self.depth):
             if i in self.pruning_loc:
                 st += 1
-                self._score_stage(st, plan, P, inputs, prev, gumbel)
-            if self._accelerated(i):
-                self._accel_block(i, st, plan, P)
-            else:
-                self._dense_block(i, plan, P)
-
-        self._join_side(plan)
+            for g, gp in enumerate(groups):
+                with torch.cuda.stream(streams[g]):
+                    if i in self.pruning_loc:
+                        r0, r1 = gp["v0"] * T, (gp["v0"] + gp["nv"]) * T
+                        self._score_stage(st, gp, P, inputs, prev, [gm[r0:r1] for gm in gumbel])
+                    if self._accelerated(i):
+                        self._accel_block(i, st, gp, P)
+                    else:
+                        self._dense_block(i, gp, P)
+        for g, gp in enumerate(groups):
+            with torch.cuda.stream(streams[g]):
+                self._join_side(gp)
+        self._join(streams)
+        if prev and ns and plan["prep"]["ev"] is not None:
+            torch.cuda.current_stream().wait_event(plan["prep"]["ev"])      # keeps the side stream joined (graph capture)
         h, w = plan["h"], plan["w"]
         cl = (lambda t: t) if self.alias_outputs else (lambda t: t.clone())
         masks = [cl(plan["mask"][s]).view(V, h, w, 1) for s in range(ns)]

@@ -28,6 +28,7 @@ struct AttnArgs {
     const void* pad_qkv;
     int64_t stride;
     int C;
+    int L;                                       // RoPE table side: tables are [L*L, 64]
     const float* cosT; const float* sinT; const float* v_bias;
     float scale;
 };
@@ -50,17 +51,56 @@ TOC3D_DEV void rope8(float (&x)[8], const float* __restrict__ c, const float* __
     }
 }
 
-template <typename T>
+// QM = 16-row MFMA tiles of queries per wave: a workgroup covers 64*QM query rows, so every K/V tile (and its RoPE
+// rotation) staged in LDS serves QM times more queries.
+TOC3D_DEV void frag_to_float(const Frag<bf16_t>& f, float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)f.v[i];
+}
+TOC3D_DEV void frag_to_float(const Frag<float>& f, float (&o)[8]) {
+    o[0] = f.lo[0]; o[1] = f.lo[1]; o[2] = f.lo[2]; o[3] = f.lo[3]; o[4] = f.hi[0]; o[5] = f.hi[1]; o[6] = f.hi[2]; o[7] = f.hi[3];
+}
+
+// one (key, 8-dim chunk) of a K/V tile in flight: raw K, raw V and the RoPE table rows, still in registers
+template <typename T> struct KVChunk {
+    Frag<T> k, v;
+};
+
+// RoPE of 8 consecutive head dims [dc*8, dc*8+8) with the compact axial tables held in LDS.
+// VisionRotaryEmbeddingFast (eva_utils.py:362-371): angle[slot][d] = row-part(slot / L) for d < 32, column-part(slot % L)
+// for d >= 32, each frequency repeated for the pair (2i, 2i+1) -> tab[part][coord][16 freqs] holds everything.
+// rc = (slot / L) << 16 | (slot % L).
+TOC3D_DEV void rope8_lds(float (&x)[8], const float* cosRC, const float* sinRC, int L, int rc, int dc) {
+    const int part = dc >> 2;
+    const int coord = part ? (rc & 0xffff) : (rc >> 16);
+    const int off = (part * L + coord) * 16 + (dc & 3) * 4;
+    const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosRC + off);
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinRC + off);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float xa = x[2 * t], xb = x[2 * t + 1];
+        x[2 * t] = xa * c4[t] - xb * s4[t];
+        x[2 * t + 1] = xb * c4[t] + xa * s4[t];
+    }
+}
+
+template <typename T, int QM>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     constexpr int LD = Pad<T>::ld;
+    constexpr int QB = 64 * QM;                  // query rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);          // [KT keys][LD]
     T* Vt = Ks + KT * LD;                        // [HD dims][LD]   (keys along the row)
-    T* Ps = Vt + HD * LD;                        // [4 waves][16 q][LD]
+    T* Ps = Vt + HD * LD;                        // [4 waves][16*QM q][LD]
+    int32_t* s_rows = reinterpret_cast<int32_t*>(Ps + 4 * 16 * QM * LD);   // [stride] key rows of this window
+    int32_t* s_slots = s_rows + a.stride;                                  // [stride] RoPE slots as (row << 16 | col)
+    float* s_cos = reinterpret_cast<float*>(s_slots + a.stride);           // [2][L][16] compact axial tables
+    float* s_sin = s_cos + 2 * a.L * 16;
+    const int L = a.L;
 
     const int qt = blockIdx.x, head = blockIdx.y, win = blockIdx.z;
     const int n = a.count[win];                  // queries: the window's compact rows
-    if (qt * 64 >= n) return;                    // uniform for the workgroup
+    if (qt * QB >= n) return;                    // uniform for the workgroup
     const int nkeys = a.count_k ? a.count_k[win] : n;   // keys: the same rows + virtual kept-pad keys (rows[j] < 0)
     const int32_t* rows = a.rows + (int64_t)win * a.stride;
     const int32_t* slots = a.slots + (int64_t)win * a.stride;
@@ -69,50 +109,83 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r16 = lane & 15, g = lane >> 4;
-    const bool wave_active = qt * 64 + wave * 16 < n;
+    const int q0 = qt * QB + wave * 16 * QM;     // first query row of this wave
+    const bool wave_active = q0 < n;
 
+    // the window's key list and the compact RoPE tables go to LDS once (5 KB instead of 512 B of table per key per tile)
+    for (int j = tid; j < nkeys; j += 256) {
+        const int sl = slots[j];
+        s_rows[j] = rows[j];
+        s_slots[j] = ((sl / L) << 16) | (sl % L);
+    }
+    for (int i = tid; i < L * 16; i += 256) {
+        const int c = i >> 4, f = i & 15;
+        s_cos[i] = a.cosT[(int64_t)(c * L) * HD + 2 * f];               // row part: slot (c, 0), dims 0..31
+        s_sin[i] = a.sinT[(int64_t)(c * L) * HD + 2 * f];
+        s_cos[L * 16 + i] = a.cosT[(int64_t)c * HD + 32 + 2 * f];       // column part: slot (0, c), dims 32..63
+        s_sin[L * 16 + i] = a.sinT[(int64_t)c * HD + 32 + 2 * f];
+    }
+    __syncthreads();
     // ---- Q fragments (A operand: row = r16, k = g*8 + j + 32*s), RoPE + scale applied in f32 ----
-    Frag<T> qf[2];
-    {
-        const int qi = qt * 64 + wave * 16 + r16;
+    Frag<T> qf[QM][2];
+#pragma unroll
+    for (int mi = 0; mi < QM; ++mi) {
+        const int qi = q0 + mi * 16 + r16;
         const bool ok = qi < n;
-        const int qrow = ok ? rows[qi] : 0, qslot = ok ? slots[qi] : 0;
+        const int qrow = ok ? s_rows[qi] : 0, qrc = ok ? s_slots[qi] : 0;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int d0 = s * 32 + g * 8;
             float x[8];
             load8(qkv + (int64_t)qrow * a.ldqkv + head * HD + d0, x);
-            rope8(x, a.cosT + (int64_t)qslot * HD + d0, a.sinT + (int64_t)qslot * HD + d0);
+            rope8_lds(x, s_cos, s_sin, L, qrc, d0 >> 3);
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = ok ? x[j] * a.scale : 0.f;
-            qf[s] = make_frag(x, T());
+            qf[mi][s] = make_frag(x, T());
         }
     }
-
-    f32x4 o[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m[4], l[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m[r] = NEG_BIG; l[r] = 0.f; }
-
-    T* Pw = Ps + wave * 16 * LD;
-    const int nkt = (nkeys + KT - 1) / KT;
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();                         // previous K/V tile fully consumed
+    // software pipeline: tile kt+1 is fetched into registers while tile kt is multiplied
+    KVChunk<T> pre[2];
+    auto fetch = [&](int kt) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int c = tid + it * 256;        // 512 (key, 8-dim chunk) pairs per tile
             const int key = c >> 3, dc = c & 7;
             const int kj = kt * KT + key;
             const bool ok = kj < nkeys;
-            const int row = ok ? rows[kj] : 0, slot = ok ? slots[kj] : 0;
+            const int row = ok ? s_rows[kj] : 0;
             // a kept padded slot is the row LN(0) = beta for every window: its q|k|v is a per-block constant
             const T* src = row >= 0 ? qkv + (int64_t)row * a.ldqkv : padq;
+            pre[it].k = read_frag(src + a.C + head * HD + dc * 8);
+            pre[it].v = read_frag(src + 2 * a.C + head * HD + dc * 8);
+        }
+    };
+    fetch(0);
+
+    f32x4 o[QM][4];
+    float m[QM][4], l[QM][4];
+#pragma unroll
+    for (int mi = 0; mi < QM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[mi][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m[mi][r] = NEG_BIG;
+            l[mi][r] = 0.f;
+        }
+
+    T* Pw = Ps + wave * 16 * QM * LD;
+    const int nkt = (nkeys + KT - 1) / KT;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                         // previous K/V tile fully consumed
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = tid + it * 256;
+            const int key = c >> 3, dc = c & 7;
+            const bool ok = kt * KT + key < nkeys;
             float kx[8], vx[8];
-            load8(src + a.C + head * HD + dc * 8, kx);
-            load8(src + 2 * a.C + head * HD + dc * 8, vx);
-            rope8(kx, a.cosT + (int64_t)slot * HD + dc * 8, a.sinT + (int64_t)slot * HD + dc * 8);
+            frag_to_float(pre[it].k, kx);
+            frag_to_float(pre[it].v, vx);
+            rope8_lds(kx, s_cos, s_sin, L, ok ? s_slots[kt * KT + key] : 0, dc);     // rotate_half pairs (eva_utils.py:318-322,379)
             if (!ok) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { kx[j] = 0.f; vx[j] = 0.f; }
@@ -122,61 +195,70 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             for (int j = 0; j < 8; ++j) Vt[(dc * 8 + j) * LD + key] = to_act<T>(vx[j]);
         }
         __syncthreads();
+        if (kt + 1 < nkt) fetch(kt + 1);         // in flight during the MFMA phase below
         if (!wave_active) continue;              // wave-uniform; barriers stay outside
 
-        // ---- S = Q K^T : 16 q x 64 keys ----
-        f32x4 sc[4];
+        // ---- S = Q K^T : 16*QM q x 64 keys (each K fragment feeds QM MFMAs) ----
+        f32x4 sc[QM][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mi = 0; mi < QM; ++mi) sc[mi][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag<T> kf = read_frag(Ks + (t * 16 + r16) * LD + s * 32 + g * 8);
-                mma_step(sc[t], qf[s], kf);
+#pragma unroll
+                for (int mi = 0; mi < QM; ++mi) mma_step(sc[mi][t], qf[mi][s], kf);
             }
         }
-        // lane holds S[q = g*4 + r][key = t*16 + r16]; mask keys past the window
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bool kok = kt * KT + t * 16 + r16 < nkeys;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[t][r] = kok ? sc[t][r] : NEG_BIG;
-        }
-        // ---- online softmax (per q row r; the row lives in the 16 lanes sharing g) ----
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float mx = fmaxf(fmaxf(sc[0][r], sc[1][r]), fmaxf(sc[2][r], sc[3][r]));
-            mx = row16_max(mx);
-            const float mn = fmaxf(m[r], mx);
-            const float alpha = __expf(m[r] - mn);
-            float ps = 0.f;
+        for (int mi = 0; mi < QM; ++mi) {
+            // lane holds S[q = g*4 + r][key = t*16 + r16]; mask keys past the window
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float p = __expf(sc[t][r] - mn);
-                sc[t][r] = p;
-                ps += p;
+                const bool kok = kt * KT + t * 16 + r16 < nkeys;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[mi][t][r] = kok ? sc[mi][t][r] : NEG_BIG;
             }
-            l[r] = l[r] * alpha + ps;            // per-lane partial; reduced over the 16 lanes at the end
-            m[r] = mn;
+            // ---- online softmax (per q row r; the row lives in the 16 lanes sharing g) ----
 #pragma unroll
-            for (int d = 0; d < 4; ++d) o[d][r] *= alpha;
+            for (int r = 0; r < 4; ++r) {
+                float mx = fmaxf(fmaxf(sc[mi][0][r], sc[mi][1][r]), fmaxf(sc[mi][2][r], sc[mi][3][r]));
+                mx = row16_max(mx);
+                const float mn = fmaxf(m[mi][r], mx);
+                const float alpha = __expf(m[mi][r] - mn);
+                float ps = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float p = __expf(sc[mi][t][r] - mn);
+                    sc[mi][t][r] = p;
+                    ps += p;
+                }
+                l[mi][r] = l[mi][r] * alpha + ps;   // per-lane partial; reduced over the 16 lanes at the end
+                m[mi][r] = mn;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o[mi][d][r] *= alpha;
+            }
+            // ---- P: C layout -> LDS -> A fragments (own wave only) ----
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pw[(mi * 16 + g * 4 + r) * LD + t * 16 + r16] = to_act<T>(sc[mi][t][r]);
         }
-        // ---- P: C layout -> LDS -> A fragments (own wave only) ----
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Pw[(g * 4 + r) * LD + t * 16 + r16] = to_act<T>(sc[t][r]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- O += P V : A = P[q][key], B = V[key][d] read from Vt[d][key] ----
+        // ---- O += P V : A = P[q][key], B = V[key][d] read from Vt[d][key] (each V fragment feeds QM MFMAs) ----
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const Frag<T> pf = read_frag(Pw + r16 * LD + s * 32 + g * 8);
+            Frag<T> pf[QM];
+#pragma unroll
+            for (int mi = 0; mi < QM; ++mi) pf[mi] = read_frag(Pw + (mi * 16 + r16) * LD + s * 32 + g * 8);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const Frag<T> vf = read_frag(Vt + (d * 16 + r16) * LD + s * 32 + g * 8);
-                mma_step(o[d], pf, vf);
+#pragma unroll
+                for (int mi = 0; mi < QM; ++mi) mma_step(o[mi][d], pf[mi], vf);
             }
         }
     }
@@ -185,35 +267,235 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     // ---- epilogue: fold in the virtual zero-padded keys, normalise, store ----
     const int np = a.npad ? a.npad[win] : 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float lr = row16_sum(l[r]);
-        float alpha = 1.f, padw = 0.f;
-        if (np > 0) {
-            const float mn = fmaxf(m[r], 0.f);
-            alpha = __expf(m[r] - mn);
-            padw = (float)np * __expf(-mn);
-            lr = lr * alpha + padw;
-        }
-        const float inv = 1.f / lr;
-        const int qi = qt * 64 + wave * 16 + g * 4 + r;
-        if (qi < n) {
-            const int64_t orow = rows[qi];
-            T* dst = reinterpret_cast<T*>(a.out) + orow * a.ldo + head * HD;
+    for (int mi = 0; mi < QM; ++mi)
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int dd = d * 16 + r16;
-                float v = o[d][r] * alpha;
-                if (np > 0) v += padw * a.v_bias[head * HD + dd];
-                dst[dd] = to_act<T>(v * inv);
+        for (int r = 0; r < 4; ++r) {
+            float lr = row16_sum(l[mi][r]);
+            float alpha = 1.f, padw = 0.f;
+            if (np > 0) {
+                const float mn = fmaxf(m[mi][r], 0.f);
+                alpha = __expf(m[mi][r] - mn);
+                padw = (float)np * __expf(-mn);
+                lr = lr * alpha + padw;
+            }
+            const float inv = 1.f / lr;
+            const int qi = q0 + mi * 16 + g * 4 + r;
+            if (qi < n) {
+                const int64_t orow = rows[qi];
+                T* dst = reinterpret_cast<T*>(a.out) + orow * a.ldo + head * HD;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int dd = d * 16 + r16;
+                    float v = o[mi][d][r] * alpha;
+                    if (np > 0) v += padw * a.v_bias[head * HD + dd];
+                    dst[dd] = to_act<T>(v * inv);
+                }
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Small windows (<= 208 keys: every accelerated block of the shipped configs): one workgroup per (window, head) keeps
+// the whole K (RoPE applied) and V^T of that head in LDS, so nothing is staged twice and the softmax is single-pass
+// (no running max / rescale).  Wave w walks the 16-query MFMA tiles w, w+4, ...
+// ---------------------------------------------------------------------------------------------------
+constexpr int SMALL_MAX_SUB = 13;                // 13 * 16 = 208 keys
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
+    constexpr int LD = Pad<T>::ld;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int head = blockIdx.x, win = blockIdx.y;
+    const int n = a.count[win];
+    const int nkeys = a.count_k ? a.count_k[win] : n;
+    const int nsub = (nkeys + 15) >> 4;          // 16-key MFMA tiles
+    const int NK32 = ((nkeys + 31) >> 5) << 5;   // keys padded to the 32-wide P.V step
+    const int LDP = NK32 + 16 / (int)sizeof(T);  // row stride of V^T and P (elements), keeps 16-byte alignment
+    T* Ks = reinterpret_cast<T*>(smem);          // [nsub*16][LD]
+    T* Vt = Ks + nsub * 16 * LD;                 // [HD][LDP]
+    T* Ps = Vt + HD * LDP;                       // [4 waves][16][LDP]
+    int32_t* s_rows = reinterpret_cast<int32_t*>(Ps + 4 * 16 * LDP);
+    int32_t* s_slots = s_rows + a.stride;
+    float* s_cos = reinterpret_cast<float*>(s_slots + a.stride);
+    float* s_sin = s_cos + 2 * a.L * 16;
+    const int L = a.L;
+    const int32_t* rows = a.rows + (int64_t)win * a.stride;
+    const int32_t* slots = a.slots + (int64_t)win * a.stride;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const T* padq = reinterpret_cast<const T*>(a.pad_qkv);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r16 = lane & 15, g = lane >> 4;
+
+    // ---- staging with every global load of the workgroup in flight at once (the kernel is latency-bound: its inputs
+    // were written by a GEMM on other XCDs, so nothing hits this XCD's L2) ----
+    constexpr int MAXC = (SMALL_MAX_SUB * 16 + 16) * 8 / 256;   // (key, 8-dim chunk) pairs per thread: 7
+    int crow[MAXC], cslot[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {                             // 1. index loads
+        const int key = (tid + i * 256) >> 3;
+        const bool ok = key < nkeys;
+        crow[i] = ok ? rows[key] : 0;
+        cslot[i] = ok ? slots[key] : 0;
+    }
+    Frag<T> kraw[MAXC], vraw[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {                             // 2. K / V rows (a kept pad = the per-block constant row)
+        const int c = tid + i * 256, dc = c & 7;
+        if (c < NK32 * 8) {
+            const T* src = crow[i] >= 0 ? qkv + (int64_t)crow[i] * a.ldqkv : padq;
+            kraw[i] = read_frag(src + a.C + head * HD + dc * 8);
+            vraw[i] = read_frag(src + 2 * a.C + head * HD + dc * 8);
+        }
+    }
+    for (int j = tid; j < nkeys; j += 256) {                     // 3. key list + compact RoPE tables -> LDS
+        const int sl = slots[j];
+        s_rows[j] = rows[j];
+        s_slots[j] = ((sl / L) << 16) | (sl % L);
+    }
+    for (int i = tid; i < L * 16; i += 256) {
+        const int c = i >> 4, f = i & 15;
+        s_cos[i] = a.cosT[(int64_t)(c * L) * HD + 2 * f];
+        s_sin[i] = a.sinT[(int64_t)(c * L) * HD + 2 * f];
+        s_cos[L * 16 + i] = a.cosT[(int64_t)c * HD + 32 + 2 * f];
+        s_sin[L * 16 + i] = a.sinT[(int64_t)c * HD + 32 + 2 * f];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {                             // 4. rotate K, transpose V into LDS; rows past nkeys are zero
+        const int c = tid + i * 256;
+        if (c < NK32 * 8) {
+            const int key = c >> 3, dc = c & 7;
+            float kx[8], vx[8];
+            frag_to_float(kraw[i], kx);
+            frag_to_float(vraw[i], vx);
+            rope8_lds(kx, s_cos, s_sin, L, ((cslot[i] / L) << 16) | (cslot[i] % L), dc);
+            if (key >= nkeys) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kx[j] = 0.f; vx[j] = 0.f; }
+            }
+            if (key < nsub * 16) store8(Ks + key * LD + dc * 8, kx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Vt[(dc * 8 + j) * LDP + key] = to_act<T>(vx[j]);
+        }
+    }
+    __syncthreads();
+
+    T* Pw = Ps + wave * 16 * LDP;
+    const int nmt = (n + 15) >> 4;
+    // raw Q rows of all tiles this wave owns (<= 4) are requested up front
+    constexpr int MAXT = (SMALL_MAX_SUB + 1 + 3) / 4;
+    Frag<T> qraw[MAXT][2];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const int qi = (wave + 4 * u) * 16 + r16;
+        const int qrow = qi < n ? s_rows[qi] : 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+            if (wave + 4 * u < nmt) qraw[u][s2] = read_frag(qkv + (int64_t)qrow * a.ldqkv + head * HD + s2 * 32 + g * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const int mt = wave + 4 * u;
+        if (mt >= nmt) break;
+        // Q fragment of this 16-row tile (RoPE + scale in f32)
+        Frag<T> qf[2];
+        {
+            const int qi = mt * 16 + r16;
+            const bool ok = qi < n;
+            const int qrc = ok ? s_slots[qi] : 0;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int d0 = s2 * 32 + g * 8;
+                float x[8];
+                frag_to_float(qraw[u][s2], x);
+                rope8_lds(x, s_cos, s_sin, L, qrc, d0 >> 3);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = ok ? x[j] * a.scale : 0.f;
+                qf[s2] = make_frag(x, T());
+            }
+        }
+        // S = Q K^T over all keys; lane holds S[q = g*4 + r][key = t*16 + r16]
+        f32x4 sc[SMALL_MAX_SUB];
+        float mx[4] = {NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};
+#pragma unroll
+        for (int t = 0; t < SMALL_MAX_SUB; ++t) {
+            sc[t] = f32x4{NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};
+            if (t < nsub) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) mma_step(acc, qf[s2], read_frag(Ks + (t * 16 + r16) * LD + s2 * 32 + g * 8));
+                const bool kok = t * 16 + r16 < nkeys;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[t][r] = kok ? acc[r] : NEG_BIG;
+                    mx[r] = fmaxf(mx[r], sc[t][r]);
+                }
+            }
+        }
+        float sum[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mx[r] = row16_max(mx[r]); sum[r] = 0.f; }
+        // P = exp(S - max) -> LDS (A-operand layout); columns past nsub*16 up to NK32 are zeroed
+#pragma unroll
+        for (int t = 0; t < SMALL_MAX_SUB + 1; ++t) {
+            if (t * 16 < NK32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = 0.f;
+                    if (t < SMALL_MAX_SUB && t < nsub) { pv = __expf(sc[t < SMALL_MAX_SUB ? t : 0][r] - mx[r]); sum[r] += pv; }
+                    Pw[(g * 4 + r) * LDP + t * 16 + r16] = to_act<T>(pv);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // O = P V
+        f32x4 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < NK32; ks += 32) {
+            const Frag<T> pf = read_frag(Pw + r16 * LDP + ks + g * 8);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) mma_step(o[d], pf, read_frag(Vt + (d * 16 + r16) * LDP + ks + g * 8));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = 1.f / row16_sum(sum[r]);
+            const int qi = mt * 16 + g * 4 + r;
+            if (qi < n) {
+                T* dst = reinterpret_cast<T*>(a.out) + (int64_t)s_rows[qi] * a.ldo + head * HD;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) dst[d * 16 + r16] = to_act<T>(o[d][r] * inv);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();          // P of this tile fully consumed before the next tile overwrites it
     }
 }
 
 template <typename T>
-void launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
-    const size_t lds = (size_t)(KT + HD + 4 * 16) * Pad<T>::ld * sizeof(T);
-    hipLaunchKernelGGL(attn_kernel<T>, grid, dim3(256), lds, s, a);
+size_t attn_small_lds(int64_t stride, int L) {
+    const int64_t nsub = (stride + 15) / 16, nk32 = (stride + 31) / 32 * 32, ldp = nk32 + 16 / (int)sizeof(T);
+    return (size_t)(nsub * 16 * Pad<T>::ld + (HD + 64) * ldp) * sizeof(T) + (size_t)stride * 8 + (size_t)L * 16 * 16;
+}
+
+template <typename T>
+void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
+    // 64-query workgroups: measured faster than 128-query ones on every window size of this model (more, fuller
+    // workgroups beat the halved K/V staging); the QM = 2 instantiation is kept for larger windows
+    // accelerated blocks (no analytic zero pads, <= 208 keys incl. virtual ones): whole-window-resident kernel
+    if (!a.npad && a.stride <= SMALL_MAX_SUB * 16) {
+        const size_t lds_s = attn_small_lds<T>(a.stride, a.L);
+        if (lds_s <= 80 * 1024) {                // keeps two workgroups per CU
+            static bool set = false;
+            if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }
+            hipLaunchKernelGGL((attn_small_kernel<T>), dim3((unsigned)num_heads, (unsigned)nwin), dim3(256), lds_s, s, a);
+            return;
+        }
+    }
+    const size_t lds = (size_t)(KT + HD + 4 * 16) * Pad<T>::ld * sizeof(T) + (size_t)a.stride * 8 + (size_t)a.L * 16 * 4 * 4;
+    dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)nwin);
+    hipLaunchKernelGGL((attn_kernel<T, 1>), grid, dim3(256), lds, s, a);
 }
 
 // window_partition as index maps (backbones/eva_utils.py:89-110): real tokens of each window in slot order.
@@ -244,23 +526,23 @@ extern "C" {
 int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
                            const int32_t* slots, const int32_t* count, const int32_t* count_k, const int32_t* npad,
                            const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
-                           const float* rope_cos, const float* rope_sin, const float* v_bias, float scale,
+                           const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
                            toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_window_attention: bad dtype %d", dtype);
     TOC3D_REQUIRE(qkv && out && rows && slots && count && rope_cos && rope_sin, "toc3d_window_attention: null buffer");
     TOC3D_REQUIRE(!npad || v_bias, "toc3d_window_attention: npad given without v_bias");
     TOC3D_REQUIRE(!count_k || pad_qkv, "toc3d_window_attention: count_k given without pad_qkv");
     TOC3D_REQUIRE(num_heads > 0 && nwin >= 0 && max_count >= 0 && stride >= max_count, "toc3d_window_attention: bad dims");
+    TOC3D_REQUIRE(rope_side > 0 && rope_side <= 256, "toc3d_window_attention: rope_side out of range");
     const int64_t C = num_heads * HD;
     TOC3D_REQUIRE(ldqkv >= 3 * C && ldo >= C, "toc3d_window_attention: leading dims too small for head_dim 64");
     const int esz = dtype == TOC3D_BF16 ? 2 : 4;
     TOC3D_REQUIRE((ldqkv * esz) % 16 == 0 && ((uintptr_t)qkv % 16) == 0, "toc3d_window_attention: qkv rows must be 16-byte aligned");
     TOC3D_REQUIRE(num_heads <= 65535 && nwin <= 65535, "toc3d_window_attention: grid too large");
     if (nwin == 0 || max_count == 0) return TOC3D_OK;
-    AttnArgs a{qkv, ldqkv, out, ldo, rows, slots, count, count_k, npad, pad_qkv, stride, (int)C, rope_cos, rope_sin, v_bias, scale};
-    dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)nwin);
-    if (dtype == TOC3D_BF16) launch_attn<bf16_t>(a, grid, as_stream(stream));
-    else launch_attn<float>(a, grid, as_stream(stream));
+    AttnArgs a{qkv, ldqkv, out, ldo, rows, slots, count, count_k, npad, pad_qkv, stride, (int)C, (int)rope_side, rope_cos, rope_sin, v_bias, scale};
+    if (dtype == TOC3D_BF16) launch_attn<bf16_t>(a, max_count, num_heads, nwin, as_stream(stream));
+    else launch_attn<float>(a, max_count, num_heads, nwin, as_stream(stream));
     TOC3D_LAUNCH_CHECK("toc3d_window_attention");
     return TOC3D_OK;
 }

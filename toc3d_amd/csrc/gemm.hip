@@ -37,9 +37,10 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // LDS swizzle: 16-byte chunk c of row r is stored at chunk position c ^ swz(r).  128-byte rows: swz = r & 7;
-// 64-byte rows (4 rows per 256-byte bank row): swz = (-(r >> 2)) & 3.  Both make every ds_read_b128 lane group
-// of the MFMA fragment reads hit 16 distinct 16-byte slots.
-template <int RB> TOC3D_DEV int swz(int r) { return RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3); }
+// 64-byte rows (4 rows per 256-byte bank row): swz = (-(r >> 2)) & 3; rows of 256 / 512 bytes (every row starts on
+// the same bank): swz = r & 15.  Each makes every ds_read_b128 lane group of the MFMA fragment reads hit 16
+// distinct 16-byte slots.
+template <int RB> TOC3D_DEV int swz(int r) { return RB >= 256 ? (r & 15) : (RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3)); }
 
 // stage one R-row x RB-byte operand tile with 16-byte global_load_lds: R*RB/16 chunks over 256 threads.
 template <typename T, int R, int RB, int NTHR>
@@ -65,11 +66,11 @@ TOC3D_DEV Frag<bf16_t> lds_frag(const char* tile, int r, int s, int g, bf16_t) {
     return f;
 }
 template <int RB>
-TOC3D_DEV Frag<float> lds_frag(const char* tile, int r, int /*s*/, int g, float) {
-    static_assert(RB == 128, "f32 tiles use 128-byte rows");
+TOC3D_DEV Frag<float> lds_frag(const char* tile, int r, int s, int g, float) {
+    static_assert(RB >= 128, "f32 tiles use rows of >= 128 bytes");
     Frag<float> f;
-    f.lo = *reinterpret_cast<const f32x4*>(tile + r * RB + (((2 * g) ^ (r & 7)) << 4));
-    f.hi = *reinterpret_cast<const f32x4*>(tile + r * RB + (((2 * g + 1) ^ (r & 7)) << 4));
+    f.lo = *reinterpret_cast<const f32x4*>(tile + r * RB + (((s * 8 + 2 * g) ^ swz<RB>(r)) << 4));
+    f.hi = *reinterpret_cast<const f32x4*>(tile + r * RB + (((s * 8 + 2 * g + 1) ^ swz<RB>(r)) << 4));
     return f;
 }
 
@@ -239,6 +240,7 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
+    if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
 }
@@ -274,6 +276,13 @@ int launch_epi(int variant, const GemmArgs& a, hipStream_t s) {
         case 19: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128, single buffer (48 KiB)
         case 20: launch_cfg<T, EPI, 128, 256, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, 128x256 tile, double buffered
         case 21: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves 256x256, 128x128... per-wave 64x128
+        // big K-tiles for latency-bound launches (about one tile per CU): fewer, fatter load rounds
+        case 22: launch_cfg<T, EPI, 128, 128, 1, 256, 2, 4, 1>(a, s); break;      // K-tile 128 bf16, 64 KiB
+        case 23: launch_cfg<T, EPI, 128, 128, 1, 512, 2, 4, 1>(a, s); break;      // K-tile 256 bf16, 128 KiB
+        case 24: launch_cfg<T, EPI, 64, 128, 1, 512, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 256, 96 KiB
+        case 25: launch_cfg<T, EPI, 128, 128, 2, 256, 2, 4, 1>(a, s); break;      // K-tile 128, double buffered, 128 KiB
+        case 26: launch_cfg<T, EPI, 64, 128, 1, 256, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 128, 48 KiB
+        case 27: launch_cfg<T, EPI, 64, 64, 1, 512, 2, 2, 1>(a, s); break;        // 64x64 tile, 4 waves, K-tile 256, 64 KiB
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;

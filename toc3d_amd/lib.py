@@ -29,7 +29,7 @@ _SIGS = {
     "toc3d_layernorm_rows": "iplppppfplllp",
     "toc3d_layernorm_act": "iplppfplllp",
     "toc3d_window_map_dense": "llllppppp",
-    "toc3d_window_attention": "iplplppppppllllpppfp",
+    "toc3d_window_attention": "iplplppppppllllpplpfp",
     "toc3d_rank_desc": "pllpp",
     "toc3d_window_topk": "plllllpppppppppppp",
     "toc3d_gather_merge_ln": "iplppppllllppfpplp",
