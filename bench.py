@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="concurrent view groups (independent views on separate HIP streams)")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of launching eagerly (measured: no faster)")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly")
+    ap.add_argument("--tune-cache", default=None, help="JSON file: load the GEMM variant table if present, save it after warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
@@ -142,10 +143,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- warm-up (also packs weights / builds plans), optional graph capture --------------------------
+    # ---- warm-up (also packs weights / builds plans / autotunes the GEMM tiles), optional graph capture -----
+    if args.tune_cache and os.path.exists(args.tune_cache):
+        model.load_tuning(args.tune_cache)
     for _ in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
+    if args.tune_cache and rank == 0:
+        model.save_tuning(args.tune_cache)
     graph = None
     if args.graph and world == 1:
         try:
@@ -233,6 +238,12 @@ def main():
                 "algorithmic_flop_per_step": alg + neck_flops, "issued_flop_per_step": iss + neck_flops,
                 "note": "HIP events around each launch in an eager, single-stream instrumented pass of the same step run right after the timed region"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # memory-side bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on
+        # gfx950 + WRITE_SIZE, see profiles/r01_gemm_hbm_traffic.json); only valid for the profiled workload
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+        if os.path.exists(tpath) and args.config == "toc3d_faster" and (H, W) == (320, 800) and args.precision == "bf16":
+            roof["traffic"] = json.load(open(tpath))["hbm_bytes_per_launch"]
+            roof["algorithmic_bytes_per_launch"] = None
         tot = sum(v[1] for v in breakdown.values())
         print("[bench] per-op GPU time per step (ms), event-timed eager pass:", file=sys.stderr)
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][1]):

@@ -204,3 +204,19 @@ def test_vitl_hires_1600x640_fp32_matches_oracle():
     err = rel_max(feat, ref["last_feat"])
     print(f"[vitl toc3d_faster 1600x640 fp32, 1 view] rel max err {err:.3e}")
     assert err < 1e-3
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_two_frames_batch_matches_oracle(groups):
+    """B = 2 frames (the scorer's queries are per frame, toc3d_utils.py:240 repeat_interleave): fp32 path vs the oracle."""
+    cfg, m = build("toc3d_tiny", "fp32")
+    m.view_groups = groups
+    sd = synth.make_state_dict(cfg)
+    inp = synth.make_inputs(cfg, n_frames=2, views_per_frame=2)
+    with torch.no_grad():
+        ref = O.forward_toc3d(sd, cfg, inp["x"], inp["temp_queries"], inp["temp_ref_points"], inp["temp_vel"], inp["temp_timestamp"],
+                              inp["temp_ego_pose"], inp["ego_pose_inv"], True, inp["gumbel"])
+    out = run_toc3d(m, inp, True)
+    assert rel_max(out.img_feats["last_feat"], ref["last_feat"]) < 1e-3
+    for s in range(3):          # order among near-equal scores may differ by float rounding; the kept *sets* must agree
+        assert iou(out.keep_idx[s], ref["keep_idx"][s].numpy()) > 0.995

@@ -325,7 +325,7 @@ class _BackboneBase(nn.Module):
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
-    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27), lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26)}
+    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 110, 114, 117, 126), lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 110, 126)}
 
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
         """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
@@ -357,6 +357,19 @@ class _BackboneBase(nn.Module):
                 var = best[1]
             self._tuned[key] = var
         lib.call("toc3d_linear_ex", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, s)
+
+    def save_tuning(self, path):
+        """Persist the autotuned (epilogue, M, N, K) -> variant table (JSON), e.g. to profile without tuning launches."""
+        import json
+        with open(path, "w") as f:
+            json.dump({"precision": self.precision, "table": [[list(k), v] for k, v in self._tuned.items()]}, f)
+
+    def load_tuning(self, path):
+        import json
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("precision") == self.precision:
+            self._tuned.update({tuple(k): int(v) for k, v in d["table"]})
 
     # -- launch sequences -----------------------------------------------------------------------------
     def _stem(self, plan, img, P):

@@ -31,6 +31,7 @@ struct GemmArgs {
     const float* res; int64_t ldr; int res_mod;
     float* rep_out; const int32_t* rep_index;
     int M, N, K, n_valid;
+    int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -99,8 +100,22 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
 
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tiles_m = (a.M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    int m0, n0;
+    if (a.order == 0) {
+        const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        m0 = (tile / tiles_n) * BM;
+        n0 = (tile % tiles_n) * BN;
+    } else {
+        // Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Each XCD owns a band of M-tile rows
+        // whose A panels (band * K bytes, ~1.5 MB) stay resident in its 4 MB L2, and walks the W panels one after the
+        // other (m fastest), so every W panel is fetched from memory once per XCD instead of once per A row-panel.
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int r0 = (xcd * tiles_m) >> 3, r1 = ((xcd + 1) * tiles_m) >> 3;
+        const int band = r1 - r0;
+        if (band <= 0 || l >= band * tiles_n) return;
+        m0 = (r0 + l % band) * BM;
+        n0 = (l / band) * BN;
+    }
 
     const T* A = reinterpret_cast<const T*>(a.A);
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -241,13 +256,15 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
+    const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
     hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
 }
 
 // tile / pipeline variants (toc3d_linear_ex `variant`); 0 = heuristic
 template <typename T, int EPI>
-int launch_epi(int variant, const GemmArgs& a, hipStream_t s) {
+int launch_epi(int variant, GemmArgs a, hipStream_t s) {
+    if (variant >= 100) { a.order = 1; variant -= 100; }      // variant + 100: same tile shape, per-XCD band order
     if (variant == 0) {
         // measured on MI355X (tools/gemm_sweep.py): occupancy beats ring depth on these shapes -- single-buffer tiles
         // (24-32 KiB LDS, >= 3 workgroups per CU); the narrower tile when there are few 128x128 tiles
@@ -376,7 +393,7 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
     }
     if (M == 0) return TOC3D_OK;
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
-               (int)M, (int)N, (int)K, (int)n_valid};
+               (int)M, (int)N, (int)K, (int)n_valid, 0};
     int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
