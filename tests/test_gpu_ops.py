@@ -510,7 +510,7 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
     ref = None
-    for v in (list(range(1, 11)) + list(range(13, 28)) + [110, 116, 126] + ([11, 12] if dt == lib.BF16 else [])):
+    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 110, 116, 126] + ([11, 12, 30, 31] if dt == lib.BF16 else [])):
         out = torch.zeros(M, N, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, None, M, N, K, 0, S())
         if ref is None:

@@ -325,7 +325,8 @@ class _BackboneBase(nn.Module):
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
-    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 110, 114, 117, 126), lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 110, 126)}
+    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 33, 110, 114, 117, 126),
+                 lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
         """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the

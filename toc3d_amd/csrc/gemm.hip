@@ -300,6 +300,13 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 25: launch_cfg<T, EPI, 128, 128, 2, 256, 2, 4, 1>(a, s); break;      // K-tile 128, double buffered, 128 KiB
         case 26: launch_cfg<T, EPI, 64, 128, 1, 256, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 128, 48 KiB
         case 27: launch_cfg<T, EPI, 64, 64, 1, 512, 2, 2, 1>(a, s); break;        // 64x64 tile, 4 waves, K-tile 256, 64 KiB
+        // deep LDS rings on 8 wavefronts: more bytes continuously in flight per CU (counted vmcnt, one barrier per K-tile)
+        case 28: launch_cfg<T, EPI, 128, 128, 3, 128, 2, 4, 1>(a, s); break;      // 96 KiB
+        case 29: launch_cfg<T, EPI, 128, 128, 4, 128, 2, 4, 1>(a, s); break;      // 128 KiB
+        case 30: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 4, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 64 KiB
+        case 31: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 6, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 96 KiB
+        case 32: launch_cfg<T, EPI, 256, 128, 3, 128, 4, 2, 1>(a, s); break;      // 256x128, 3-deep, 144 KiB
+        case 33: launch_cfg<T, EPI, 128, 64, 4, 128, 2, 4, 1>(a, s); break;       // 128x64, 4-deep, 96 KiB
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;

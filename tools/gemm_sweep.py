@@ -13,10 +13,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "fp32":
 S = lib.stream_ptr
 C, Hp = 1024, 2752
 shapes = []   # (name, epi, M, N, K)
-for M in (6000, 3744, 2808):
+for M in (6000, 3744):
     shapes += [("qkv", lib.EPI_BIAS, M, 3072, 1024), ("proj", lib.EPI_RESIDUAL, M, 1024, 1024),
                ("w12", lib.EPI_SWIGLU, M, 2 * Hp, 1024), ("w3", lib.EPI_RESIDUAL, M, 1024, Hp)]
-variants = [16, 116, 17, 117, 14, 114, 10, 110, 26, 126]
+variants = [16, 17, 28, 29, 30, 31, 32, 33]
 res = {}
 for name, epi, M, N, K in shapes:
     A = torch.randn(M, K, device=dev).to(tdt)
