@@ -184,6 +184,7 @@ class _BackboneBase(nn.Module):
         self.alias_outputs = False      # True: returned tensors alias the reused workspace (benchmarks)
         self._side = None               # side stream: query-side scorer prep / image-level ranking overlap the blocks
         self.view_groups = 1            # > 1: split the views into groups that run concurrently on separate streams
+        self.fold_ffn_ln = precision == "bf16"   # strict-parity path keeps the two-pass LayerNorm kernel
         self._gstreams = []
 
     # -- state-dict hook: re-pack after new weights arrive ------------------------------------------
@@ -245,6 +246,11 @@ class _BackboneBase(nn.Module):
                      self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
             p["w12"], p["b12"] = w12, b12
             p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
+            if self.fold_ffn_ln:
+                w3f = m.w3.weight.detach().float()
+                p["w3g"] = self._pack_linear(w3f * m.ffn_ln.weight.detach().float()[None, :])
+                p["c1"] = p["w3g"][:C, :Hd].float().sum(dim=1).contiguous()            # of the *rounded* weights: a constant row cancels exactly
+                p["c2"] = (w3f @ m.ffn_ln.bias.detach().float() + m.w3.bias.detach().float()).contiguous()
             for n, mod in (("ln1", blk.norm1), ("ln2", blk.norm2), ("lnf", m.ffn_ln)):
                 p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
             p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
@@ -319,6 +325,7 @@ class _BackboneBase(nn.Module):
                     att=torch.empty(R, C, dtype=tdt, device=dev),
                     hid=torch.zeros(R, Hp, dtype=tdt, device=dev),
                     hln=torch.zeros(R, Hp, dtype=tdt, device=dev),
+                    stats=torch.empty(R, (2 * Hp) // 128, 2, dtype=torch.float32, device=dev),
                     col=torch.zeros(M, _round_up(Kc, 64), dtype=tdt, device=dev),
                     Kc=Kc)
         plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
@@ -328,13 +335,18 @@ class _BackboneBase(nn.Module):
     _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 33, 110, 114, 117, 126),
                  lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
-    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
+    # tile variants whose N-tile is 128 wide (the SwiGLU row-statistics slots of the folded ffn_ln assume that width)
+    _BN128 = (1, 8, 10, 15, 16, 17, 22, 24, 26, 28, 29, 110, 117, 126)
+
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid,
+                stats=None, stats_slots=0, ln_c1=None, ln_n=0, ln_eps=0.0):
         """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
         real operands the first time the shape is seen (never during hipGraph capture: shapes are warmed up eagerly).
         All variants accumulate K in the same order, so the choice does not change results."""
-        key = (epi, M, N, K)
+        key = (epi, M, N, K, stats is not None)
         var = self._tuned.get(key)
         s = lib.stream_ptr()
+        tail = (stats, stats_slots, ln_c1, ln_n, float(ln_eps), s)
         if var is None:
             var = 0
             if self.autotune and not torch.cuda.is_current_stream_capturing():
@@ -343,21 +355,28 @@ class _BackboneBase(nn.Module):
                     o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
                 rep_s = torch.empty_like(rep_out) if rep_out is not None else None
                 best = None
-                for v in self._VARIANTS[self._dt]:
-                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, s)
-                    lib.call("toc3d_linear_ex", *args)
+                cands = self._VARIANTS[self._dt]
+                if epi == lib.EPI_SWIGLU and stats is not None:
+                    cands = [v for v in cands if v in self._BN128]
+                if epi == lib.EPI_SWIGLU:
+                    cands = [v for v in cands if v != 33]          # 16-column wave slabs cannot pair w1 / w2 columns
+                for v in cands:
+                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid) + tail
+                    lib.call("toc3d_linear_lnfold", *args)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(3):
-                        lib.call("toc3d_linear_ex", *args)
+                        lib.call("toc3d_linear_lnfold", *args)
                     e1.record()
                     e1.synchronize()
                     t = e0.elapsed_time(e1)
                     if best is None or t < best[0]:
                         best = (t, v)
                 var = best[1]
+            elif epi == lib.EPI_SWIGLU and stats is not None:
+                var = 16
             self._tuned[key] = var
-        lib.call("toc3d_linear_ex", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, s)
+        lib.call("toc3d_linear_lnfold", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *tail)
 
     def save_tuning(self, path):
         """Persist the autotuned (epilogue, M, N, K) -> variant table (JSON), e.g. to profile without tuning launches."""
@@ -394,6 +413,15 @@ class _BackboneBase(nn.Module):
         Hp = plan["hid"].shape[1]
         dt = self._dt
         lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
+        if self.fold_ffn_ln:
+            # ffn_ln folded into w3 (eva_vit.py:48-49): the SwiGLU epilogue leaves per-row (sum, sum^2) slots, w3 multiplies the
+            # un-normalised hidden by W3*gamma and applies rstd*(. - mean*c1) + c2 in its epilogue -- no pass over the hidden
+            slots = (2 * Hp) // 128
+            self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
+                         stats=plan["stats"], stats_slots=slots)
+            self._linear(lib.EPI_RESIDUAL, plan["hid"], Hp, bp["w3g"], bp["w3g"].shape[1], bp["c2"], res, C, res, C, 0,
+                         rep_out, rep_index, rows, C, Hp, 0, stats=plan["stats"], stats_slots=slots, ln_c1=bp["c1"], ln_n=Hd, ln_eps=self.LN_EPS)
+            return
         self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)
         lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
         self._linear(lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,
@@ -680,13 +708,21 @@ class ToC3DEVAViT(_BackboneBase):
                  order=[torch.empty(V, T, dtype=torch.int64, device=dev) for _ in range(ns)],
                  prep=dict(mq=torch.empty(ns, B, Q, QUERY_DIM, **f32), wc=torch.empty(ns, B, C, 2, **f32), bc=torch.empty(ns, B, 2, **f32), ev=None))
         m["groups"] = []
-        for (v0, nv, f0, nf) in self._group_layout(V, B):
+        layout = self._group_layout(V, B)
+        for (v0, nv, f0, nf) in layout:
             gp = self._plan(nv, H, W, nf, dev)
             gp["v0"], gp["nv"], gp["frame0"], gp["prep"] = v0, nv, f0, m["prep"]
-            gp["x"] = m["x"][v0 * T:(v0 + nv) * T]
-            gp["score"] = [t[v0 * T:(v0 + nv) * T] for t in m["score"]]
-            gp["mask"] = [t[v0 * T:(v0 + nv) * T] for t in m["mask"]]
-            gp["order"] = [t[v0:v0 + nv] for t in m["order"]]
+            gp["x"] = m["x"][v0 * T:(v0 + nv) * T]           # row slices of x are whole 128-byte lines (C*4 bytes per token)
+            if len(layout) == 1:
+                gp["score"], gp["mask"], gp["order"] = m["score"], m["mask"], m["order"]
+            else:
+                # Groups run on different streams, i.e. on different XCDs whose L2s are not coherent with each other: two
+                # groups must never write into the same 128-byte line.  A slice boundary at T floats (4000 B at 800x320)
+                # falls inside a line, so every group gets private, separately allocated score / mask / order buffers and
+                # forward() copies them into the contiguous outputs after the streams have joined.
+                gp["score"] = [torch.empty(nv * T, **f32) for _ in range(ns)]
+                gp["mask"] = [torch.empty(nv * T, **f32) for _ in range(ns)]
+                gp["order"] = [torch.empty(nv, T, dtype=torch.int64, device=dev) for _ in range(ns)]
             m["groups"].append(gp)
         return m
 
@@ -845,6 +881,12 @@ class ToC3DEVAViT(_BackboneBase):
         self._join(streams)
         if prev and ns and plan["prep"]["ev"] is not None:
             torch.cuda.current_stream().wait_event(plan["prep"]["ev"])      # keeps the side stream joined (graph capture)
+        if len(groups) > 1:
+            for gp in groups:                                                # private per-group buffers -> contiguous outputs
+                v0, nv = gp["v0"], gp["nv"]
+                for st_ in range(ns):
+                    plan["mask"][st_][v0 * T:(v0 + nv) * T].copy_(gp["mask"][st_])
+                    plan["order"][st_][v0:v0 + nv].copy_(gp["order"][st_])
         h, w = plan["h"], plan["w"]
         cl = (lambda t: t) if self.alias_outputs else (lambda t: t.clone())
         masks = [cl(plan["mask"][s]).view(V, h, w, 1) for s in range(ns)]

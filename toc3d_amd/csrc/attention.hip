@@ -93,8 +93,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     T* Vt = Ks + KT * LD;                        // [HD dims][LD]   (keys along the row)
     T* Ps = Vt + HD * LD;                        // [4 waves][16*QM q][LD]
     int32_t* s_rows = reinterpret_cast<int32_t*>(Ps + 4 * 16 * QM * LD);   // [stride] key rows of this window
-    int32_t* s_slots = s_rows + a.stride;                                  // [stride] RoPE slots as (row << 16 | col)
-    float* s_cos = reinterpret_cast<float*>(s_slots + a.stride);           // [2][L][16] compact axial tables
+    const int istride = (int)((a.stride + 3) & ~3);                        // keeps the tables behind the lists 16-byte aligned
+    int32_t* s_slots = s_rows + istride;                                   // [stride] RoPE slots as (row << 16 | col)
+    float* s_cos = reinterpret_cast<float*>(s_slots + istride);            // [2][L][16] compact axial tables
     float* s_sin = s_cos + 2 * a.L * 16;
     const int L = a.L;
 
@@ -315,8 +316,9 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     T* Vt = Ks + nsub * 16 * LD;                 // [HD][LDP]
     T* Ps = Vt + HD * LDP;                       // [4 waves][16][LDP]
     int32_t* s_rows = reinterpret_cast<int32_t*>(Ps + 4 * 16 * LDP);
-    int32_t* s_slots = s_rows + a.stride;
-    float* s_cos = reinterpret_cast<float*>(s_slots + a.stride);
+    const int istride = (int)((a.stride + 3) & ~3);
+    int32_t* s_slots = s_rows + istride;
+    float* s_cos = reinterpret_cast<float*>(s_slots + istride);
     float* s_sin = s_cos + 2 * a.L * 16;
     const int L = a.L;
     const int32_t* rows = a.rows + (int64_t)win * a.stride;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
 template <typename T>
 size_t attn_small_lds(int64_t stride, int L) {
     const int64_t nsub = (stride + 15) / 16, nk32 = (stride + 31) / 32 * 32, ldp = nk32 + 16 / (int)sizeof(T);
-    return (size_t)(nsub * 16 * Pad<T>::ld + (HD + 64) * ldp) * sizeof(T) + (size_t)stride * 8 + (size_t)L * 16 * 16;
+    return (size_t)(nsub * 16 * Pad<T>::ld + (HD + 64) * ldp) * sizeof(T) + (size_t)((stride + 3) & ~3) * 8 + (size_t)L * 16 * 16;
 }
 
 template <typename T>
@@ -493,7 +495,7 @@ void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_
             return;
         }
     }
-    const size_t lds = (size_t)(KT + HD + 4 * 16) * Pad<T>::ld * sizeof(T) + (size_t)a.stride * 8 + (size_t)a.L * 16 * 4 * 4;
+    const size_t lds = (size_t)(KT + HD + 4 * 16) * Pad<T>::ld * sizeof(T) + (size_t)((a.stride + 3) & ~3) * 8 + (size_t)a.L * 16 * 4 * 4;
     dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)nwin);
     hipLaunchKernelGGL((attn_kernel<T, 1>), grid, dim3(256), lds, s, a);
 }

@@ -32,6 +32,10 @@ struct GemmArgs {
     float* rep_out; const int32_t* rep_index;
     int M, N, K, n_valid;
     int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
+    // LayerNorm folded across two GEMMs (SwiGLU.ffn_ln, eva_vit.py:48-49):  w3(LN(h)) = rstd*(h.(W3*gamma)^T - mean*c1) + c2
+    float* stats;                                        // [M, stats_slots, 2] per-row (sum h, sum h^2) partials, one slot per N-tile
+    int stats_slots;
+    const float* ln_c1; int ln_n; float ln_eps;          // consumer side: c1[n] = sum_k (W3*gamma)[n,k]; statistics over ln_n columns
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -153,6 +157,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             __builtin_amdgcn_s_setprio(0);
         }
     };
+    float* s_ln = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [BM][2] mean, rstd (only with a.ln_c1)
+    if (EPI == TOC3D_EPI_RESIDUAL && a.ln_c1) {
+        for (int rl = tid; rl < BM; rl += NTHR) {
+            const int row = m0 + rl < a.M ? m0 + rl : a.M - 1;
+            const f32x2* st = reinterpret_cast<const f32x2*>(a.stats) + (int64_t)row * a.stats_slots;
+            float t1 = 0.f, t2 = 0.f;
+            for (int sl = 0; sl < a.stats_slots; ++sl) { const f32x2 v = st[sl]; t1 += v[0]; t2 += v[1]; }
+            const float mean = t1 / (float)a.ln_n;
+            const float var = fmaxf(t2 / (float)a.ln_n - mean * mean, 0.f);
+            s_ln[2 * rl] = mean;
+            s_ln[2 * rl + 1] = 1.0f / sqrtf(var + a.ln_eps);
+        }                                                      // visible after the first barrier of the K loop
+    }
     if (STAGES == 1) {
         // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
         for (int kt = 0; kt < nk; ++kt) {
@@ -181,8 +198,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     if (EPI == TOC3D_EPI_SWIGLU) {
         // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
         T* out = reinterpret_cast<T*>(a.out);
+        constexpr int NG = NT / 2 > 0 ? NT / 2 : 1;      // 16-unit groups per wave
+        float s1[MT][NG][4], s2[MT][NG][4];              // per-row, per-group partial (sum, sum of squares) of the hidden, as stored
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int jp = 0; jp < NG; ++jp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[i][jp][r] = 0.f; s2[i][jp][r] = 0.f; }
 #pragma unroll
             for (int jp = 0; jp < NT / 2; ++jp) {
                 const int pc = n0 + wn * TN + jp * 32 + r16;      // packed col of the w1 half
@@ -195,9 +218,39 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                         if (row < a.M) {
                             const float x1 = acc[i][2 * jp][r] + b1, x2 = acc[i][2 * jp + 1][r] + b2;
                             const float h = unit < a.n_valid ? silu(x1) * x2 : 0.f;
-                            out[(int64_t)row * a.ldo + unit] = to_act<T>(h);
+                            const T hs = to_act<T>(h);
+                            out[(int64_t)row * a.ldo + unit] = hs;
+                            const float hf = from_act(hs);
+                            s1[i][jp][r] = hf;
+                            s2[i][jp][r] = hf * hf;
                         }
                     }
+                }
+            }
+        }
+        if (a.stats) {
+            // deterministic row statistics for the LayerNorm folded into the next GEMM, one (sum, sum^2) slot per row per
+            // N-tile.  Canonical order, independent of the wave grid: 16 lanes of a 16-unit group (butterfly), groups in
+            // column order inside a wave, waves pairwise -- every 128-wide variant therefore produces the same bits.
+            f32x2* sred = reinterpret_cast<f32x2*>(smem);             // [WN][BM]
+            __syncthreads();                                           // every wave is done with the operand tiles
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t1 = row16_sum(s1[i][0][r]), t2 = row16_sum(s2[i][0][r]);
+#pragma unroll
+                    for (int jp = 1; jp < NG; ++jp) { t1 += row16_sum(s1[i][jp][r]); t2 += row16_sum(s2[i][jp][r]); }
+                    if (r16 == 0) sred[wn * BM + wm * TM + i * 16 + g * 4 + r] = f32x2{t1, t2};
+                }
+            __syncthreads();
+            for (int rl = tid; rl < BM; rl += NTHR) {
+                const int row = m0 + rl;
+                if (row < a.M) {
+                    f32x2 t = sred[rl];
+                    if (WN == 2) t += sred[BM + rl];
+                    if (WN == 4) t = (t + sred[BM + rl]) + (sred[2 * BM + rl] + sred[3 * BM + rl]);
+                    *reinterpret_cast<f32x2*>(a.stats + ((int64_t)row * a.stats_slots + n0 / BN) * 2) = t;
                 }
             }
         }
@@ -205,13 +258,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     }
     // rows first: the modular residual row and the representative-row test cost an integer division each,
     // so they are evaluated once per row (16 per lane), not once per element (64 per lane)
-    float bcol[NT];
+    float bcol[NT], c1col[NT];
     bool cok[NT];
+    const bool fold = EPI == TOC3D_EPI_RESIDUAL && a.ln_c1 != nullptr;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int col = n0 + wn * TN + j * 16 + r16;
         cok[j] = col < a.N;
         bcol[j] = (a.bias && cok[j]) ? a.bias[col] : 0.f;
+        c1col[j] = (fold && cok[j]) ? a.ln_c1[col] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -225,11 +280,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                 float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
                 float* reprow = nullptr;
                 if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
+                const int rl = wm * TM + i * 16 + g * 4 + r;
+                const float mean = fold ? s_ln[2 * rl] : 0.f, rstd = fold ? s_ln[2 * rl + 1] : 1.f;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     if (!cok[j]) continue;
                     const int col = n0 + wn * TN + j * 16 + r16;
-                    const float raw = acc[i][j][r] + bcol[j];
+                    const float raw = fold ? rstd * (acc[i][j][r] - mean * c1col[j]) + bcol[j] : acc[i][j][r] + bcol[j];
                     orow[col] = (resrow ? resrow[col] : 0.f) + raw;
                     if (reprow) reprow[col] = raw;
                 }
@@ -247,16 +304,21 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     }
 }
 
+thread_local bool g_slot_mismatch = false;             // SwiGLU statistics: the chosen tile width must match stats_slots
+thread_local bool g_bad_variant = false;               // variant cannot serve the requested epilogue
+
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = STAGES * (BM + BN) * RB;
+    constexpr int lds = STAGES * (BM + BN) * RB + (EPI == TOC3D_EPI_RESIDUAL ? BM * 8 : 0);
     static bool attr_set = false;      // > 64 KiB of dynamic LDS: raise the per-kernel limit once
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
+    if (EPI == TOC3D_EPI_SWIGLU && (BN / WN) % 32 != 0) { g_bad_variant = true; return; }   // a wave must own whole (w1, w2) 32-column groups
     if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
     const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
+    if (EPI == TOC3D_EPI_SWIGLU && a.stats && tn != a.stats_slots) { g_slot_mismatch = true; return; }
     const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
     hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
 }
@@ -307,6 +369,11 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 31: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 6, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 96 KiB
         case 32: launch_cfg<T, EPI, 256, 128, 3, 128, 4, 2, 1>(a, s); break;      // 256x128, 3-deep, 144 KiB
         case 33: launch_cfg<T, EPI, 128, 64, 4, 128, 2, 4, 1>(a, s); break;       // 128x64, 4-deep, 96 KiB
+        // 16 wavefronts per workgroup: 256-wide tiles (fewer L2->LDS bytes per FLOP) without giving up waves per CU
+        case 34: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 4, 1>(a, s); break;      // 256x128, 64x32 per wave, 48 KiB
+        case 35: launch_cfg<T, EPI, 256, 256, 1, 128, 4, 4, 1>(a, s); break;      // 256x256, 64x64 per wave, 64 KiB
+        case 36: launch_cfg<T, EPI, 128, 256, 1, 128, 4, 4, 1>(a, s); break;      // 128x256, 32x64 per wave, 48 KiB
+        case 37: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 4, 1>(a, s); break;      // 256x256 double buffered, 128 KiB
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;
@@ -375,10 +442,18 @@ __global__ void im2col_kernel(const float* __restrict__ img, T* __restrict__ out
 
 extern "C" {
 
-int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                    void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                    float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                    toc3d_stream_t stream) {
+int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                        void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                        float* row_stats, int64_t stats_slots, const float* ln_c1, int64_t ln_n, float ln_eps,
+                        toc3d_stream_t stream) {
+    if (row_stats) {
+        TOC3D_REQUIRE(stats_slots > 0, "toc3d_linear_lnfold: stats_slots must be positive");
+        TOC3D_REQUIRE(epilogue == TOC3D_EPI_SWIGLU || (epilogue == TOC3D_EPI_RESIDUAL && ln_c1 && ln_n > 0),
+                      "toc3d_linear_lnfold: row_stats is produced by SWIGLU and consumed by RESIDUAL (+ ln_c1, ln_n)");
+    } else {
+        TOC3D_REQUIRE(!ln_c1, "toc3d_linear_lnfold: ln_c1 without row_stats");
+    }
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && K > 0, "toc3d_linear: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -400,11 +475,23 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
     }
     if (M == 0) return TOC3D_OK;
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
-               (int)M, (int)N, (int)K, (int)n_valid, 0};
+               (int)M, (int)N, (int)K, (int)n_valid, 0, row_stats, (int)stats_slots, ln_c1, (int)ln_n, ln_eps};
+    g_slot_mismatch = false;
+    g_bad_variant = false;
     int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
+    if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab < 32)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
+    if (g_slot_mismatch) { toc3d_set_error("toc3d_linear_lnfold: variant %d has %s N-tiles than stats_slots=%lld", variant, "a different number of", (long long)stats_slots); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
     return TOC3D_OK;
+}
+
+int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                    void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                    float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                    toc3d_stream_t stream) {
+    return toc3d_linear_lnfold(dtype, epilogue, variant, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index,
+                               M, N, K, n_valid, nullptr, 0, nullptr, 0, 0.f, stream);
 }
 
 int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
