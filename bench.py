@@ -189,7 +189,7 @@ def main():
             e0.record()
             orig_call(name, *a)
             e1.record()
-            if name == "toc3d_linear_ex":
+            if name in ("toc3d_linear_ex", "toc3d_linear_lnfold"):
                 tag = f"[epi{a[1]} v{a[2]} M={a[15]} N={a[16]} K={a[17]}]"
             elif name == "toc3d_linear":
                 tag = f"[epi{a[1]} M={a[14]} N={a[15]} K={a[16]}]"
@@ -250,8 +250,11 @@ def main():
             print(f"   {k:34s} {v[1] / n_inst:8.3f} ms  {v[0] // n_inst:4d} launches  {100 * v[1] / tot:5.1f}%", file=sys.stderr)
         print(f"   {'sum':34s} {tot / n_inst:8.3f} ms", file=sys.stderr)
         print("[bench] per-shape detail (us per launch, launches per step):", file=sys.stderr)
+        import re
         for k, v in sorted(detail.items(), key=lambda kv: -kv[1][1]):
-            print(f"   {k:70s} {1e3 * v[1] / v[0]:8.1f} us x {v[0] // n_inst:3d}", file=sys.stderr)
+            mnk = re.search(r"M=(\d+) N=(\d+) K=(\d+)", k)
+            tf = f"  {2.0 * int(mnk[1]) * int(mnk[2]) * int(mnk[3]) / (v[1] / v[0] * 1e-3) / 1e12:6.0f} TF issued" if mnk else ""
+            print(f"   {k:70s} {1e3 * v[1] / v[0]:8.1f} us x {v[0] // n_inst:3d}  = {v[1] / n_inst:6.3f} ms{tf}", file=sys.stderr)
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps

@@ -111,6 +111,18 @@ int toc3d_pack_swiglu(int dtype, const float* w1, const float* w2, const float* 
 int toc3d_im2col_patches(int dtype, const float* img, void* out, int64_t ldo, int64_t V, int64_t Cin, int64_t H, int64_t W,
                          int64_t patch, toc3d_stream_t stream);
 
+/* Camera images as uint8.  img uint8 HWC [V, H, W, 3] (BGR as loaded,
+ * mmdet3d/datasets/pipelines/loading.py:47-50); mean3 / std3 are HOST float[3] (img_norm_cfg, configs/ToC3D/ToC3D_faster.py:13-14).
+ * toc3d_normalize_images = NormalizeMultiviewImage (datasets/pipelines/transform_3d.py:87-100, mmcv.imnormalize:
+ *   channel flip if to_rgb, then fl32(fl32(x - mean) * fl32(1/std))) + PadMultiViewImage (transform_3d.py:38-50: zeros bottom /
+ *   right up to [Hp, Wp]) + the HWC->CHW transpose of DefaultFormatBundle (mmdet3d/datasets/pipelines/formating.py:42-47)
+ *   -> out f32 NCHW [V, 3, Hp, Wp], i.e. the tensor ToC3DEVAViT.forward receives.
+ * toc3d_im2col_patches_u8 = the same fused into toc3d_im2col_patches: rows [V*(Hp/p)*(Wp/p), ldo], identical values. */
+int toc3d_normalize_images(const uint8_t* img, int64_t V, int64_t H, int64_t W, const float* mean3, const float* std3, int to_rgb,
+                           float* out, int64_t Hp, int64_t Wp, toc3d_stream_t stream);
+int toc3d_im2col_patches_u8(int dtype, const uint8_t* img, int64_t V, int64_t H, int64_t W, const float* mean3, const float* std3,
+                            int to_rgb, void* out, int64_t ldo, int64_t Hp, int64_t Wp, int64_t patch, toc3d_stream_t stream);
+
 /* get_abs_pos (backbones/eva_utils.py:229-258): pos f32 [S*S, C] (cls row already dropped) -> out f32 [h*w, C],
  * bicubic, align_corners=False, A = -0.75 (torch F.interpolate semantics).  Copy if S == h == w. */
 int toc3d_abs_pos_bicubic(const float* pos, int64_t S, int64_t C, float* out, int64_t h, int64_t w, toc3d_stream_t stream);

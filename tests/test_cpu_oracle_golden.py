@@ -109,3 +109,21 @@ def test_state_dict_spec_matches_reference(golden_dir):
         assert mine == spec[name]
     n = sum(int(np.prod(v)) for k, v in spec["toc3d_faster"].items() if "freqs_" not in k and not k.endswith("pc_range"))
     assert abs(n - 311.06e6) < 0.05e6          # 311.06 M parameters
+
+
+def test_image_oracle_normalise_pad_format():
+    """oracle/image_oracle.py (parity unpinned: mmcv / OpenCV absent) against the published formula in float64, and the
+    pipeline's layout rules: padded pixels are exactly zero, channel flip happens before mean/std are applied."""
+    from oracle import image_oracle as I
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (2, 30, 50, 3), dtype=np.uint8)
+    mean, std = [103.530, 116.280, 123.675], [57.375, 57.120, 58.395]          # projects/configs/ToC3D/ToC3D_faster.py:13-14
+    for to_rgb in (False, True):
+        out = I.prepare_images(img, mean, std, to_rgb, 32)
+        assert out.shape == (2, 3, 32, 64) and out.dtype == np.float32
+        src = img[..., ::-1] if to_rgb else img
+        ref = (src.astype(np.float64) - np.float32(mean).astype(np.float64)) / np.float32(std).astype(np.float64)
+        assert np.abs(out[:, :, :30, :50] - ref.transpose(0, 3, 1, 2)).max() < 4e-7 * 4.5       # <= 2 ulp of the largest value
+        assert (out[:, :, 30:, :] == 0).all() and (out[:, :, :, 50:] == 0).all()
+    # integer-valued float32 input (what LoadMultiViewImageFromFiles(to_float32=True) hands over) gives the same bits
+    assert np.array_equal(I.imnormalize(img[0].astype(np.float32), mean, std, False), I.imnormalize(img[0], mean, std, False))

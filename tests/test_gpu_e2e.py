@@ -210,6 +210,33 @@ def test_repeated_forwards_are_bit_identical(name, groups, instances, vpf):
                 assert torch.equal(cur[1][s], ref[1][s]) and torch.equal(cur[2][s], ref[2][s])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("hw", [(320, 800), (300, 790)])
+def test_uint8_images_give_the_same_bits_as_host_normalised_float(precision, hw):
+    """raw uint8 HWC camera images + img_norm_cfg == the reference's host pipeline
+    (NormalizeMultiviewImage -> PadMultiViewImage -> CHW float32, restated in oracle/image_oracle.py) fed as float32."""
+    from oracle import image_oracle as I
+    norm = dict(mean=[103.530, 116.280, 123.675], std=[57.375, 57.120, 58.395], to_rgb=False)
+    cfg = configs.get("toc3d_tiny")
+    m = toc3d_amd.build_backbone(dict(cfg, precision=precision, img_norm_cfg=norm))
+    m.load_state_dict(synth.make_state_dict(cfg), strict=True)
+    m = m.to(DEV).eval()
+    inp = synth.make_inputs(cfg, views_per_frame=2)
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (2, hw[0], hw[1], 3), dtype=np.uint8)
+    xf = torch.from_numpy(I.prepare_images(img, norm["mean"], norm["std"], norm["to_rgb"], 32))
+    a = run_toc3d(m, dict(inp, x=xf), True)
+    fa, ka = a.img_feats["last_feat"].clone(), [k.clone() for k in a.keep_idx]
+    b = run_toc3d(m, dict(inp, x=torch.from_numpy(img)), True)
+    assert fa.shape == b.img_feats["last_feat"].shape == (2, cfg["embed_dim"], 320 // 16, 800 // 16)
+    assert torch.equal(fa, b.img_feats["last_feat"])
+    for s in range(3):
+        assert torch.equal(ka[s], b.keep_idx[s])
+    plain = toc3d_amd.build_backbone(dict(cfg, precision=precision)).to(DEV).eval()
+    with pytest.raises(ValueError, match="img_norm_cfg"):
+        plain(torch.from_numpy(img).to(DEV))
+
+
 def test_vitl_hires_1600x640_fp32_matches_oracle():
     """BASELINE.json config 4 geometry (40x100 tokens: 21 + 10 windows per view), 1 view, against the oracle run on the host."""
     cfg, m = build("toc3d_faster", "fp32")

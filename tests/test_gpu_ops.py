@@ -702,3 +702,44 @@ def test_linear_is_bit_stable_under_load(name, dt, tdt):
     for r in runs[1:]:
         for got, ref, what in zip(r, runs[0], ("bias", "swiglu hidden", "swiglu statistics", "folded residual", "gelu")):
             assert torch.equal(got.view(torch.uint8), ref.view(torch.uint8)), f"{what} epilogue differs between launches"
+
+
+# ---------------------------------------------------------------------------------------------------
+# uint8 camera images
+IMG_NORM = dict(mean=[103.530, 116.280, 123.675], std=[57.375, 57.120, 58.395])       # projects/configs/ToC3D/ToC3D_faster.py:13-14
+
+
+@pytest.mark.parametrize("to_rgb", [False, True])
+@pytest.mark.parametrize("V,H,W", [(2, 320, 800), (1, 300, 790), (3, 33, 47)])
+def test_normalize_images_matches_oracle_bit_exact(to_rgb, V, H, W):
+    """NormalizeMultiviewImage + PadMultiViewImage + HWC->CHW (transform_3d.py:87-100,38-50) on the device."""
+    from oracle import image_oracle as I
+    from toc3d_amd.preprocess import prepare_images
+    rng = np.random.default_rng(V * 1000 + H)
+    img = rng.integers(0, 256, (V, H, W, 3), dtype=np.uint8)
+    ref = I.prepare_images(img, IMG_NORM["mean"], IMG_NORM["std"], to_rgb, 32)
+    out = prepare_images(torch.from_numpy(img).to(DEV), IMG_NORM["mean"], IMG_NORM["std"], to_rgb, 32)
+    assert tuple(out.shape) == ref.shape
+    assert torch.equal(out.cpu(), torch.from_numpy(ref))
+    with pytest.raises(RuntimeError, match="CUDA/HIP"):
+        prepare_images(torch.from_numpy(img), IMG_NORM["mean"], IMG_NORM["std"], to_rgb, 32)
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+@pytest.mark.parametrize("H,W", [(320, 800), (300, 790)])
+def test_im2col_u8_equals_im2col_of_normalized_images(name, dt, tdt, H, W):
+    """The fused uint8 im2col writes exactly what toc3d_im2col_patches writes for the normalised, padded float image."""
+    from toc3d_amd.preprocess import prepare_images
+    V, p = 2, 16
+    rng = np.random.default_rng(5)
+    img = torch.from_numpy(rng.integers(0, 256, (V, H, W, 3), dtype=np.uint8)).to(DEV)
+    x = prepare_images(img, IMG_NORM["mean"], IMG_NORM["std"], False, 32)
+    Hp, Wp = x.shape[2], x.shape[3]
+    M, Kp = V * (Hp // p) * (Wp // p), 768
+    a = torch.zeros(M, Kp, dtype=tdt, device=DEV)
+    b = torch.zeros(M, Kp, dtype=tdt, device=DEV)
+    lib.call("toc3d_im2col_patches", dt, x, a, Kp, V, 3, Hp, Wp, p, S())
+    lib.call("toc3d_im2col_patches_u8", dt, img, V, H, W, torch.tensor(IMG_NORM["mean"]), torch.tensor(IMG_NORM["std"]), 0, b, Kp, Hp, Wp, p, S())
+    assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+    with pytest.raises(RuntimeError, match="multiple of the patch"):
+        lib.call("toc3d_im2col_patches_u8", dt, img, V, H, W, torch.tensor(IMG_NORM["mean"]), torch.tensor(IMG_NORM["std"]), 0, b, Kp, Hp + 1, Wp, p, S())

@@ -5,8 +5,9 @@ reference's type names, like ``projects/mmdet3d_plugin`` does on import (``tools
 """
 from .backbone import EVA_ViT, ToC3DEVAViT, ToC3DViTReturnType
 from .neck import CPFPN
+from .preprocess import prepare_images
 from .registry import BACKBONES, NECKS, build_backbone, build_neck, register_all
 
 register_all()
 
-__all__ = ["ToC3DEVAViT", "EVA_ViT", "CPFPN", "ToC3DViTReturnType", "BACKBONES", "NECKS", "build_backbone", "build_neck"]
+__all__ = ["ToC3DEVAViT", "EVA_ViT", "CPFPN", "ToC3DViTReturnType", "BACKBONES", "NECKS", "build_backbone", "build_neck", "prepare_images"]

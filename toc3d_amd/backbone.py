@@ -150,8 +150,19 @@ class _BackboneBase(nn.Module):
 
     def _setup_common(self, img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias,
                       use_abs_pos, pt_hw_seq_len, window_size, global_window_size, global_attn_indexes,
-                      pretrain_img_size, pretrain_use_cls_token, out_feature, precision):
+                      pretrain_img_size, pretrain_use_cls_token, out_feature, precision, img_norm_cfg=None, pad_size_divisor=32):
         assert precision in ("bf16", "fp32"), precision
+        # uint8 boundary: with img_norm_cfg (the config's dict(mean, std, to_rgb), ToC3D_faster.py:13-14)
+        # forward() also accepts raw uint8 HWC camera images and applies NormalizeMultiviewImage + PadMultiViewImage
+        # (datasets/pipelines/transform_3d.py:87-100,38-50) inside the patch-embedding im2col
+        self.img_norm_cfg = None
+        if img_norm_cfg is not None:
+            self.img_norm_cfg = dict(mean=torch.tensor(list(img_norm_cfg["mean"]), dtype=torch.float32),
+                                     std=torch.tensor(list(img_norm_cfg["std"]), dtype=torch.float32),
+                                     to_rgb=bool(img_norm_cfg.get("to_rgb", True)))
+            assert self.img_norm_cfg["mean"].numel() == 3 and self.img_norm_cfg["std"].numel() == 3
+        self.pad_size_divisor = int(pad_size_divisor)
+        assert self.pad_size_divisor % patch_size == 0, "PadMultiViewImage divisor must be a multiple of the patch size"
         if embed_dim // num_heads != 64 or embed_dim % num_heads:
             raise NotImplementedError("the HIP attention kernel is built for head_dim 64 (EVA-02 L/B/tiny test config)")
         if embed_dim % 64 or embed_dim > 1024:
@@ -396,13 +407,18 @@ class _BackboneBase(nn.Module):
         """PatchEmbed + abs-pos add (toc3d_eva_vit.py:243-247) -> residual stream x f32 [V*T, C]."""
         s = lib.stream_ptr()
         C, V = self.embed_dim, plan["V"]
-        H, W = img.shape[2], img.shape[3]
+        H, W = plan["h"] * self.patch_size, plan["w"] * self.patch_size
         Kp = plan["col"].shape[1]
         hw = (plan["h"], plan["w"])
         if hw not in P["pos"]:
             P["pos"][hw] = self._pos_for(hw[0], hw[1], img.device)
         pos = P["pos"][hw]
-        lib.call("toc3d_im2col_patches", self._dt, img, plan["col"], Kp, V, self.in_chans, H, W, self.patch_size, s)
+        if img.dtype == torch.uint8:
+            n = self.img_norm_cfg
+            lib.call("toc3d_im2col_patches_u8", self._dt, img, V, img.shape[1], img.shape[2], n["mean"], n["std"], int(n["to_rgb"]),
+                     plan["col"], Kp, H, W, self.patch_size, s)
+        else:
+            lib.call("toc3d_im2col_patches", self._dt, img, plan["col"], Kp, V, self.in_chans, H, W, self.patch_size, s)
         self._linear(lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
                      plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, None, plan["M"], C, Kp, 0)
 
@@ -474,12 +490,21 @@ class _BackboneBase(nn.Module):
             streams[0].wait_event(ev)
 
     def _check_input(self, x):
+        """-> (tensor, H, W): f32 NCHW (B*Nv, 3, H, W) as the reference's detector passes it (petr3d.py:139-141), or uint8 HWC
+        (B*Nv, H0, W0, 3) raw camera images when the backbone was built with ``img_norm_cfg``; H, W are the padded sizes."""
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise RuntimeError("toc3d_amd: input must be a CUDA/HIP tensor -- the HIP extension is the only compute path "
                                "(no CPU fallback)")
+        if x.dtype == torch.uint8:
+            if self.img_norm_cfg is None:
+                raise ValueError("uint8 images need the backbone to be built with img_norm_cfg=dict(mean=..., std=..., to_rgb=...)")
+            if x.dim() != 4 or x.shape[3] != 3 or self.in_chans != 3:
+                raise ValueError(f"expected uint8 HWC images (B*Nv, H, W, 3), got {tuple(x.shape)}")
+            d = self.pad_size_divisor
+            return x.contiguous(), -(-x.shape[1] // d) * d, -(-x.shape[2] // d) * d
         if x.dim() != 4 or x.shape[1] != self.in_chans or x.shape[2] % self.patch_size or x.shape[3] % self.patch_size:
             raise ValueError(f"expected (B*Nv, {self.in_chans}, H, W) with H, W multiples of {self.patch_size}, got {tuple(x.shape)}")
-        return x.float().contiguous()
+        return x.float().contiguous(), x.shape[2], x.shape[3]
 
     def _feature_view(self, plan):
         x = plan["x"] if self.alias_outputs else plan["x"].clone()
@@ -504,7 +529,7 @@ class EVA_ViT(_BackboneBase):
                                       "are dead code for the shipped configs and not built")
         self._setup_common(img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, use_abs_pos,
                            pt_hw_seq_len, window_size, global_window_size, global_attn_indexes, pretrain_img_size,
-                           pretrain_use_cls_token, out_feature, precision)
+                           pretrain_use_cls_token, out_feature, precision, unused.get("img_norm_cfg"), unused.get("pad_size_divisor", 32))
         self.blocks = nn.ModuleList([
             _Block(embed_dim, mlp_ratio, qkv_bias, partial(nn.LayerNorm, eps=1e-6),
                    self.rope_glb if i in self.global_attn_indexes else self.rope_win) for i in range(depth)])
@@ -514,20 +539,20 @@ class EVA_ViT(_BackboneBase):
 
     @torch.no_grad()
     def forward(self, x, *args, **kwargs):
-        x = self._check_input(x)
+        x, H, W = self._check_input(x)
         if self._packed is None:
             self._packed = self._pack_common()
-        key = (tuple(x.shape), self.view_groups)
+        key = (tuple(x.shape), x.dtype, self.view_groups)
         V = x.shape[0]
         if key not in self._plans:
             layout = self._group_layout(V, V)
-            master = self._base_plan(V, x.shape[2], x.shape[3], x.device, 0) if len(layout) == 1 else None
+            master = self._base_plan(V, H, W, x.device, 0) if len(layout) == 1 else None
             groups = []
             if master is None:
-                master = dict(V=V, h=x.shape[2] // self.patch_size, w=x.shape[3] // self.patch_size)
+                master = dict(V=V, h=H // self.patch_size, w=W // self.patch_size)
                 master["x"] = torch.empty(V * master["h"] * master["w"], self.embed_dim, dtype=torch.float32, device=x.device)
                 for (v0, nv, _, _) in layout:
-                    gp = self._base_plan(nv, x.shape[2], x.shape[3], x.device, 0)
+                    gp = self._base_plan(nv, H, W, x.device, 0)
                     gp["x"] = master["x"][v0 * gp["T"]:(v0 + nv) * gp["T"]]
                     gp["v0"], gp["nv"] = v0, nv
                     groups.append(gp)
@@ -577,7 +602,7 @@ class ToC3DEVAViT(_BackboneBase):
                                       "(toc3d_eva_vit.py:463); use EVA_ViT for the dense baseline")
         self._setup_common(img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, use_abs_pos,
                            pt_hw_seq_len, window_size, global_window_size, global_attn_indexes, pretrain_img_size,
-                           pretrain_use_cls_token, out_feature, precision)
+                           pretrain_use_cls_token, out_feature, precision, unused.get("img_norm_cfg"), unused.get("pad_size_divisor", 32))
         self.pruning_loc = pruning_loc
         self.pruning_num_queries = pruning_num_queries
         self.pruning_attn_scale = pruning_attn_scale
@@ -824,7 +849,7 @@ class ToC3DEVAViT(_BackboneBase):
     @torch.no_grad()
     def forward(self, x, temp_queries=None, prev_exists=None, temp_ref_points=None, temp_vel=None, temp_timestamp=None,
                 temp_ego_pose=None, ego_pose_inv=None, *args, gumbel_noise=None, **kwargs):
-        x = self._check_input(x)
+        x, H, W = self._check_input(x)
         if self._packed is None:
             self._packed = self._pack()
         P = self._packed
@@ -842,9 +867,9 @@ class ToC3DEVAViT(_BackboneBase):
             ts = ts.contiguous() if ts.dtype == torch.float64 else ts.float().contiguous()
             inputs = (f(temp_queries), f(temp_ref_points), f(temp_vel), ts, f(temp_ego_pose), f(ego_pose_inv))
         assert V % B == 0
-        key = (tuple(x.shape), B, self.view_groups)
+        key = (tuple(x.shape), x.dtype, B, self.view_groups)
         if key not in self._plans:
-            self._plans[key] = self._master_plan(V, x.shape[2], x.shape[3], B, dev)
+            self._plans[key] = self._master_plan(V, H, W, B, dev)
         plan = self._plans[key]
         groups = plan["groups"]
         T = plan["T"]

@@ -438,9 +438,97 @@ __global__ void im2col_kernel(const float* __restrict__ img, T* __restrict__ out
     }
 }
 
+// ---- uint8 camera images: NormalizeMultiviewImage + PadMultiViewImage + HWC->CHW, standalone or fused
+// into the patch-embedding im2col.  Arithmetic exactly as mmcv.imnormalize on a CV_32F image (oracle/image_oracle.py):
+// fl32(fl32(x - mean) * stdinv), channel flip first when to_rgb, padded pixels exactly 0.
+struct ImgNorm { float mean[3]; float stdinv[3]; int to_rgb; };
+
+TOC3D_DEV float norm_px(unsigned v, int c, const ImgNorm& n) {
+    const float d = __fsub_rn((float)v, n.mean[c]);
+    return __fmul_rn(d, n.stdinv[c]);
+}
+
+__global__ void normalize_images_kernel(const uint8_t* __restrict__ img, int V, int H, int W, ImgNorm n, float* __restrict__ out, int Hp, int Wp) {
+    const int64_t total = (int64_t)V * Hp * (Wp / 4);                    // 4 consecutive px (all 3 channels) per thread
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x0 = (int)(i % (Wp / 4)) * 4, y = (int)((i / (Wp / 4)) % Hp), v = (int)(i / ((int64_t)(Wp / 4) * Hp));
+        float o[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = y < H && x0 + q < W;
+            const uint8_t* px = img + (((int64_t)v * H + y) * W + x0 + q) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c][q] = in ? norm_px(px[n.to_rgb ? 2 - c : c], c, n) : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f32x4*>(out + (((int64_t)v * 3 + c) * Hp + y) * Wp + x0) = f32x4{o[c][0], o[c][1], o[c][2], o[c][3]};
+    }
+}
+
+template <typename T>
+__global__ void im2col_u8_kernel(const uint8_t* __restrict__ img, int V, int H, int W, ImgNorm n, T* __restrict__ out, int64_t ldo, int Hp, int Wp, int p) {
+    const int h = Hp / p, w = Wp / p;
+    const int q4 = p / 4;                                                // 4-px groups per patch row
+    const int64_t total = (int64_t)V * h * w * p * q4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % q4) * 4, py = (int)((i / q4) % p);
+        const int64_t m = i / ((int64_t)q4 * p);
+        const int pc = (int)(m % w), pr = (int)((m / w) % h), v = (int)(m / ((int64_t)w * h));
+        const int y = pr * p + py, x0 = pc * p + px;
+        T* dst = out + m * ldo + py * p + px;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = y < H && x0 + q < W;
+            const uint8_t* src = img + (((int64_t)v * H + y) * W + x0 + q) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[c * p * p + q] = to_act<T>(in ? norm_px(src[n.to_rgb ? 2 - c : c], c, n) : 0.f);
+        }
+    }
+}
+
+ImgNorm make_norm(const float* mean3, const float* std3, int to_rgb) {
+    ImgNorm n;
+    for (int c = 0; c < 3; ++c) { n.mean[c] = mean3[c]; n.stdinv[c] = (float)(1.0 / (double)std3[c]); }
+    n.to_rgb = to_rgb;
+    return n;
+}
+
 }  // namespace
 
 extern "C" {
+
+int toc3d_normalize_images(const uint8_t* img, int64_t V, int64_t H, int64_t W, const float* mean3, const float* std3, int to_rgb,
+                           float* out, int64_t Hp, int64_t Wp, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(img && out && mean3 && std3, "toc3d_normalize_images: null buffer");
+    TOC3D_REQUIRE(V > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W && Wp % 4 == 0, "toc3d_normalize_images: bad dims (Wp must be a multiple of 4)");
+    TOC3D_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "toc3d_normalize_images: zero std");
+    const int64_t total = V * Hp * (Wp / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(normalize_images_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, make_norm(mean3, std3, to_rgb),
+                       out, (int)Hp, (int)Wp);
+    TOC3D_LAUNCH_CHECK("toc3d_normalize_images");
+    return TOC3D_OK;
+}
+
+int toc3d_im2col_patches_u8(int dtype, const uint8_t* img, int64_t V, int64_t H, int64_t W, const float* mean3, const float* std3, int to_rgb,
+                            void* out, int64_t ldo, int64_t Hp, int64_t Wp, int64_t patch, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(img && out && mean3 && std3, "toc3d_im2col_patches_u8: null buffer");
+    TOC3D_REQUIRE(V > 0 && H > 0 && W > 0 && patch > 0 && patch % 4 == 0 && Hp >= H && Wp >= W && Hp % patch == 0 && Wp % patch == 0,
+                  "toc3d_im2col_patches_u8: bad dims (padded size must be a multiple of the patch, patch a multiple of 4)");
+    TOC3D_REQUIRE(ldo >= 3 * patch * patch, "toc3d_im2col_patches_u8: ldo < 3*patch*patch");
+    TOC3D_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "toc3d_im2col_patches_u8: zero std");
+    const int64_t total = V * (Hp / patch) * (Wp / patch) * patch * (patch / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const ImgNorm n = make_norm(mean3, std3, to_rgb);
+    if (dtype == TOC3D_BF16)
+        hipLaunchKernelGGL(im2col_u8_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, n, (bf16_t*)out, ldo, (int)Hp, (int)Wp, (int)patch);
+    else if (dtype == TOC3D_F32)
+        hipLaunchKernelGGL(im2col_u8_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, n, (float*)out, ldo, (int)Hp, (int)Wp, (int)patch);
+    else { toc3d_set_error("toc3d_im2col_patches_u8: bad dtype"); return TOC3D_ERR_ARG; }
+    TOC3D_LAUNCH_CHECK("toc3d_im2col_patches_u8");
+    return TOC3D_OK;
+}
 
 int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                         void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
