@@ -237,6 +237,33 @@ def test_uint8_images_give_the_same_bits_as_host_normalised_float(precision, hw)
         plain(torch.from_numpy(img).to(DEV))
 
 
+@pytest.mark.parametrize("name", ["toc3d_tiny", "eva_tiny"])
+def test_packed_weight_cache_and_checkpoint_converter(name, tmp_path):
+    """a reference-style .pth (keys img_backbone.*, tools/test.py:207) -> packed file -> a model that
+    never sees the state dict; bit-identical features, also at a resolution the writer never ran (abs-pos re-derived)."""
+    from toc3d_amd.packed_io import convert_checkpoint
+    cfg = configs.get(name)
+    sd = synth.make_state_dict(cfg)
+    ckpt = {"meta": {}, "state_dict": {"img_backbone." + k: v for k, v in sd.items()} | {"pts_bbox_head.x": torch.zeros(1)}}
+    torch.save(ckpt, tmp_path / "det.pth")
+    packed = str(tmp_path / "det.backbone.bf16.safetensors")
+    a = convert_checkpoint(str(tmp_path / "det.pth"), dict(cfg, precision="bf16"), packed)
+    inp = synth.make_inputs(cfg, views_per_frame=2)
+    inp2 = synth.make_inputs(cfg, views_per_frame=1, hw=(256, 512))
+    run = (lambda m, i: run_toc3d(m, i, True).img_feats["last_feat"].clone()) if synth.is_toc3d(cfg) else (lambda m, i: m(i["x"].to(DEV))["last_feat"].clone())
+    ref = run(a, inp)
+    torch.manual_seed(123)
+    b = toc3d_amd.build_backbone(dict(cfg, precision="bf16")).to(DEV).eval()        # random weights, never loaded
+    b.load_packed(packed)
+    assert torch.equal(run(b, inp), ref)
+    assert torch.equal(run(b, inp2), run(a, inp2))
+    c = toc3d_amd.build_backbone(dict(cfg, precision="fp32")).to(DEV).eval()
+    with pytest.raises(ValueError, match="different model"):
+        c.load_packed(packed)
+    with pytest.raises(KeyError):
+        convert_checkpoint(str(tmp_path / "det.pth"), dict(cfg, precision="bf16"), packed, prefix="backbone.")
+
+
 def test_vitl_hires_1600x640_fp32_matches_oracle():
     """BASELINE.json config 4 geometry (40x100 tokens: 21 + 10 windows per view), 1 view, against the oracle run on the host."""
     cfg, m = build("toc3d_faster", "fp32")

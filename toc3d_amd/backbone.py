@@ -298,13 +298,15 @@ class _BackboneBase(nn.Module):
         P["b_patch"] = self._f32(self.patch_embed.proj.bias)
         P["blocks"] = self._pack_blocks(dev)
         P["pos"] = {}                                   # (h, w) -> bicubic-resized abs-pos, built on first use
+        if self.pos_embed is not None:                  # source grid (cls row dropped, eva_utils.py:240-243)
+            P["pos_embed"] = self._f32(self.pos_embed[0, 1:] if self.pretrain_use_cls_token else self.pos_embed[0]).clone()
         return P
 
     def _pos_for(self, h, w, dev):
         C = self.embed_dim
-        if self.pos_embed is None:
+        pe = self._packed.get("pos_embed") if self._packed is not None else None
+        if pe is None:
             return None
-        pe = self._f32(self.pos_embed[0, 1:] if self.pretrain_use_cls_token else self.pos_embed[0])
         S = int(math.isqrt(pe.shape[0]))
         assert S * S == pe.shape[0]
         out = torch.empty(h * w, C, dtype=torch.float32, device=dev)
@@ -388,6 +390,16 @@ class _BackboneBase(nn.Module):
                 var = 16
             self._tuned[key] = var
         lib.call("toc3d_linear_lnfold", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *tail)
+
+    def save_packed(self, path):
+        """Write the packed device weights (what the kernels consume) to a safetensors file; see ``packed_io``."""
+        from .packed_io import save_packed
+        save_packed(self, path)
+
+    def load_packed(self, path):
+        """Restore weights from ``save_packed`` (module already on the GPU); replaces load_state_dict + packing."""
+        from .packed_io import load_packed
+        load_packed(self, path)
 
     def save_tuning(self, path):
         """Persist the autotuned (epilogue, M, N, K) -> variant table (JSON), e.g. to profile without tuning launches."""
