@@ -100,6 +100,19 @@ TOC3D_DEV float row16_sum(float v) {
     return v;
 }
 
+// the 4 lane groups g = lane >> 4 that share lane & 15 (one row of a transposed MFMA C tile)
+TOC3D_DEV float g4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// 4 consecutive elements as one 8-byte (bf16) / 16-byte (f32) store
+TOC3D_DEV void store4(bf16_t* p, const bf16_t (&v)[4]) {
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<bf16x4_t*>(p) = bf16x4_t{v[0], v[1], v[2], v[3]};
+}
+TOC3D_DEV void store4(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md T1): blocks that land on one XCD
 // (bid % 8) get a contiguous chunk of work ids so neighbouring tiles share that XCD's L2.
 TOC3D_DEV int xcd_remap(int bid, int nwg) {

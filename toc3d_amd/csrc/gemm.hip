@@ -32,6 +32,7 @@ struct GemmArgs {
     float* rep_out; const int32_t* rep_index;
     int M, N, K, n_valid;
     int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
+    int vec;                                             // epilogue may use 4-element vector accesses (alignment checked on the host)
     // LayerNorm folded across two GEMMs (SwiGLU.ffn_ln, eva_vit.py:48-49):  w3(LN(h)) = rstd*(h.(W3*gamma)^T - mean*c1) + c2
     float* stats;                                        // [M, stats_slots, 2] per-row (sum h, sum h^2) partials, one slot per N-tile
     int stats_slots;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) mma_step(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < NT; ++j) mma_step(acc[i][j], fb[j], fa[i]);   // swapped: C^T tile layout, see the epilogue
             __builtin_amdgcn_s_setprio(0);
         }
     };
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             float t1 = 0.f, t2 = 0.f;
             for (int sl = 0; sl < a.stats_slots; ++sl) { const f32x2 v = st[sl]; t1 += v[0]; t2 += v[1]; }
             const float mean = t1 / (float)a.ln_n;
-            const float var = fmaxf(t2 / (float)a.ln_n - mean * mean, 0.f);
+            const float var = fmaxf(__fmaf_rn(-mean, mean, t2 / (float)a.ln_n), 0.f);
             s_ln[2 * rl] = mean;
             s_ln[2 * rl + 1] = 1.0f / sqrtf(var + a.ln_eps);
         }                                                      // visible after the first barrier of the K loop
@@ -194,55 +195,57 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    // ---- epilogue: lane holds C[row = .. + g*4 + r][col = .. + r16] ----
+    // ---- epilogue.  The MFMA is issued with the operands swapped (W fragment as A, activation fragment as B), so a lane
+    // holds C[row = .. + r16][4 consecutive cols = .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of
+    // 2- / 4-byte scattered ones.  a.vec (host-checked alignment / leading dims) enables the vector path. ----
     if (EPI == TOC3D_EPI_SWIGLU) {
         // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
         T* out = reinterpret_cast<T*>(a.out);
         constexpr int NG = NT / 2 > 0 ? NT / 2 : 1;      // 16-unit groups per wave
-        float s1[MT][NG][4], s2[MT][NG][4];              // per-row, per-group partial (sum, sum of squares) of the hidden, as stored
+        float s1[MT][NG], s2[MT][NG];                    // per-row, per-group partial (sum, sum of squares) of the hidden, as stored
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            const int row = m0 + wm * TM + i * 16 + r16;
 #pragma unroll
-            for (int jp = 0; jp < NG; ++jp)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s1[i][jp][r] = 0.f; s2[i][jp][r] = 0.f; }
+            for (int jp = 0; jp < NG; ++jp) { s1[i][jp] = 0.f; s2[i][jp] = 0.f; }
 #pragma unroll
             for (int jp = 0; jp < NT / 2; ++jp) {
-                const int pc = n0 + wn * TN + jp * 32 + r16;      // packed col of the w1 half
-                const int unit = (pc >> 5) * 16 + r16;
-                if (pc < a.N) {
-                    const float b1 = a.bias[pc], b2 = a.bias[pc + 16];
+                const int pc = n0 + wn * TN + jp * 32 + g * 4;    // packed col of the w1 half, first of 4
+                const int unit0 = (pc >> 5) * 16 + g * 4;
+                if (pc < a.N && row < a.M) {
+                    T hs[4];
+                    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = m0 + wm * TM + i * 16 + g * 4 + r;
-                        if (row < a.M) {
-                            const float x1 = acc[i][2 * jp][r] + b1, x2 = acc[i][2 * jp + 1][r] + b2;
-                            const float h = unit < a.n_valid ? silu(x1) * x2 : 0.f;
-                            const T hs = to_act<T>(h);
-                            out[(int64_t)row * a.ldo + unit] = hs;
-                            const float hf = from_act(hs);
-                            s1[i][jp][r] = hf;
-                            s2[i][jp][r] = hf * hf;
-                        }
+                        const float x1 = acc[i][2 * jp][r] + a.bias[pc + r], x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
+                        const float h = unit0 + r < a.n_valid ? silu(x1) * x2 : 0.f;
+                        hs[r] = to_act<T>(h);
+                        const float hf = from_act(hs[r]);
+                        t1 += hf;
+                        t2 = __fmaf_rn(hf, hf, t2);
                     }
+                    s1[i][jp] = t1;
+                    s2[i][jp] = t2;
+                    T* dst = out + (int64_t)row * a.ldo + unit0;
+                    if (a.vec) store4(dst, hs);
+                    else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
                 }
             }
         }
         if (a.stats) {
             // deterministic row statistics for the LayerNorm folded into the next GEMM, one (sum, sum^2) slot per row per
-            // N-tile.  Canonical order, independent of the wave grid: 16 lanes of a 16-unit group (butterfly), groups in
-            // column order inside a wave, waves pairwise -- every 128-wide variant therefore produces the same bits.
+            // N-tile.  Canonical order, independent of the wave grid: the 4 units of a lane in order, the 4 lane groups of a
+            // 16-unit group (butterfly), groups in column order inside a wave, waves pairwise -- every 128-wide variant
+            // therefore produces the same bits.
             f32x2* sred = reinterpret_cast<f32x2*>(smem);             // [WN][BM]
             __syncthreads();                                           // every wave is done with the operand tiles
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
+                float t1 = g4_sum(s1[i][0]), t2 = g4_sum(s2[i][0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t1 = row16_sum(s1[i][0][r]), t2 = row16_sum(s2[i][0][r]);
-#pragma unroll
-                    for (int jp = 1; jp < NG; ++jp) { t1 += row16_sum(s1[i][jp][r]); t2 += row16_sum(s2[i][jp][r]); }
-                    if (r16 == 0) sred[wn * BM + wm * TM + i * 16 + g * 4 + r] = f32x2{t1, t2};
-                }
+                for (int jp = 1; jp < NG; ++jp) { t1 += g4_sum(s1[i][jp]); t2 += g4_sum(s2[i][jp]); }
+                if (g == 0) sred[wn * BM + wm * TM + i * 16 + r16] = f32x2{t1, t2};
+            }
             __syncthreads();
             for (int rl = tid; rl < BM; rl += NTHR) {
                 const int row = m0 + rl;
@@ -256,49 +259,65 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         }
         return;
     }
-    // rows first: the modular residual row and the representative-row test cost an integer division each,
-    // so they are evaluated once per row (16 per lane), not once per element (64 per lane)
-    float bcol[NT], c1col[NT];
-    bool cok[NT];
     const bool fold = EPI == TOC3D_EPI_RESIDUAL && a.ln_c1 != nullptr;
+    float bcol[NT][4], c1col[NT][4];
+    int nok[NT];                                         // valid columns among the lane's 4 (0..4)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wn * TN + j * 16 + r16;
-        cok[j] = col < a.N;
-        bcol[j] = (a.bias && cok[j]) ? a.bias[col] : 0.f;
-        c1col[j] = (fold && cok[j]) ? a.ln_c1[col] : 0.f;
+        const int col = n0 + wn * TN + j * 16 + g * 4;
+        nok[j] = a.N - col < 0 ? 0 : (a.N - col > 4 ? 4 : a.N - col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
+            c1col[j][r] = (fold && r < nok[j]) ? a.ln_c1[col + r] : 0.f;
+        }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        const int row = m0 + wm * TM + i * 16 + r16;
+        if (row >= a.M) continue;
+        if (EPI == TOC3D_EPI_RESIDUAL) {
+            // the modular residual row and the representative-row test cost an integer division / a load each: once per row
+            const int rr = a.res_mod > 0 ? row % a.res_mod : row;
+            const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
+            float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
+            float* reprow = nullptr;
+            if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
+            const int rl = wm * TM + i * 16 + r16;
+            const float mean = fold ? s_ln[2 * rl] : 0.f, rstd = fold ? s_ln[2 * rl + 1] : 1.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * TM + i * 16 + g * 4 + r;
-            if (row >= a.M) continue;
-            if (EPI == TOC3D_EPI_RESIDUAL) {
-                const int rr = a.res_mod > 0 ? row % a.res_mod : row;
-                const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
-                float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
-                float* reprow = nullptr;
-                if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
-                const int rl = wm * TM + i * 16 + g * 4 + r;
-                const float mean = fold ? s_ln[2 * rl] : 0.f, rstd = fold ? s_ln[2 * rl + 1] : 1.f;
+            for (int j = 0; j < NT; ++j) {
+                if (nok[j] == 0) continue;
+                const int col = n0 + wn * TN + j * 16 + g * 4;
+                float raw[4];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (!cok[j]) continue;
-                    const int col = n0 + wn * TN + j * 16 + r16;
-                    const float raw = fold ? rstd * (acc[i][j][r] - mean * c1col[j]) + bcol[j] : acc[i][j][r] + bcol[j];
-                    orow[col] = (resrow ? resrow[col] : 0.f) + raw;
-                    if (reprow) reprow[col] = raw;
+                for (int r = 0; r < 4; ++r)      // explicit FMAs: the rounding must not depend on how a tile variant's code gets contracted
+                    raw[r] = fold ? __fmaf_rn(rstd, __fmaf_rn(-mean, c1col[j][r], acc[i][j][r]), bcol[j][r]) : acc[i][j][r] + bcol[j][r];
+                if (a.vec && nok[j] == 4) {
+                    f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{rv[0] + raw[0], rv[1] + raw[1], rv[2] + raw[2], rv[3] + raw[3]};
+                    if (reprow) *reinterpret_cast<f32x4*>(reprow + col) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+                } else {
+                    for (int r = 0; r < nok[j]; ++r) {
+                        orow[col + r] = (resrow ? resrow[col + r] : 0.f) + raw[r];
+                        if (reprow) reprow[col + r] = raw[r];
+                    }
                 }
-            } else {
-                T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
+            }
+        } else {
+            T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (!cok[j]) continue;
-                    const int col = n0 + wn * TN + j * 16 + r16;
-                    const float raw = acc[i][j][r] + bcol[j];
-                    orow[col] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
+            for (int j = 0; j < NT; ++j) {
+                if (nok[j] == 0) continue;
+                const int col = n0 + wn * TN + j * 16 + g * 4;
+                T o4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float raw = acc[i][j][r] + bcol[j][r];
+                    o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
                 }
+                if (a.vec && nok[j] == 4) store4(orow + col, o4);
+                else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
             }
         }
     }
@@ -562,8 +581,12 @@ int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int
         TOC3D_REQUIRE(!rep_index || rep_out, "toc3d_linear: rep_index set without rep_out");
     }
     if (M == 0) return TOC3D_OK;
+    // 4-wide epilogue accesses: every row start and column group must be 16-byte aligned in its own element size
+    const int64_t osz = epilogue == TOC3D_EPI_RESIDUAL ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
+    const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * osz) == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
+                     (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0));
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
-               (int)M, (int)N, (int)K, (int)n_valid, 0, row_stats, (int)stats_slots, ln_c1, (int)ln_n, ln_eps};
+               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, row_stats, (int)stats_slots, ln_c1, (int)ln_n, ln_eps};
     g_slot_mismatch = false;
     g_bad_variant = false;
     int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
