@@ -393,6 +393,12 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 35: launch_cfg<T, EPI, 256, 256, 1, 128, 4, 4, 1>(a, s); break;      // 256x256, 64x64 per wave, 64 KiB
         case 36: launch_cfg<T, EPI, 128, 256, 1, 128, 4, 4, 1>(a, s); break;      // 128x256, 32x64 per wave, 48 KiB
         case 37: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 4, 1>(a, s); break;      // 256x256 double buffered, 128 KiB
+        // K-tile 32 rings on 8 wavefronts at the LDS footprint of the single-buffer tile: prefetch inside the workgroup without losing occupancy
+        case 38: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 32 KiB
+        case 39: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 48 KiB
+        case 40: launch_cfg<T, EPI, 128, 256, 1, 128, 2, 4, 1>(a, s); break;      // 128x256, 64x64 per wave, 48 KiB
+        case 41: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 256, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 128x256, K-tile 32 x 2, 48 KiB
+        case 42: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 256, 128, 2, 64, 4, 2, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 256x128, K-tile 32 x 2, 48 KiB
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;

@@ -16,7 +16,7 @@ shapes = []   # (name, epi, M, N, K)
 for M in (6000, 3744):
     shapes += [("qkv", lib.EPI_BIAS, M, 3072, 1024), ("proj", lib.EPI_RESIDUAL, M, 1024, 1024),
                ("w12", lib.EPI_SWIGLU, M, 2 * Hp, 1024), ("w3", lib.EPI_RESIDUAL, M, 1024, Hp)]
-variants = [16, 17, 33, 34, 35, 36, 37, 134, 135]
+variants = [int(v) for v in os.environ.get('VARIANTS', '16,17,19,38,39,40,41,42').split(',')]
 res = {}
 for name, epi, M, N, K in shapes:
     A = torch.randn(M, K, device=dev).to(tdt)
