@@ -277,6 +277,30 @@ int toc3d_nhwc_to_nchw(const float* x, float* out, int64_t V, int64_t T, int64_t
 int toc3d_im2col_3x3(int dtype, const float* x, void* out, int64_t ldo, int64_t V, int64_t h, int64_t w, int64_t C,
                      toc3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Temporal memory bank: the head-side producer of the scorer inputs temp_queries / temp_ref_points /
+ * temp_vel / temp_timestamp / temp_ego_pose (detectors/petr3d.py:115-134).  State = five caller-owned device buffers of
+ * `capacity` = memory_len + topk slots per sample: emb f32 [B, cap, D], ref f32 [B, cap, 3], ts f64 [B, cap], pose f32
+ * [B, cap, 4, 4], vel f32 [B, cap, 2].
+ * toc3d_memory_pre_update: StreamPETRHead.pre_update_memory (dense_heads/streampetr_head.py:322-346) in place on slots
+ *   [0, memory_len): += timestamp, ego_pose_inv @ pose, transform_reference_points, memory_refresh by prev_exists [B],
+ *   then the pseudo reference points / identity poses of the first num_propagated slots.  fresh != 0: the bank is all zeros
+ *   (reset_memory, :315-320, then :326-331) and only the last step applies.
+ * toc3d_memory_scores: sigmoid(cls).topk(1).values (:361) -> score f32 [rows]; rank it with toc3d_rank_desc.
+ * toc3d_memory_post_update: post_update_memory (:355-377): slots [0, topk) = the top-k queries (order from toc3d_rank_desc,
+ *   lowest index first on ties) of the last decoder layer (bbox_preds [B, Q, ld_bbox]: ref = cols 0..2, velocity = last 2;
+ *   outs_dec [B, Q, D]; rec_ego_pose [B, Q, 4, 4]), slots [topk, cap) = in-bank slots [0, memory_len); then ego_pose
+ *   transform of the reference points and poses and -= timestamp.  In / out banks must be different buffers. */
+int toc3d_memory_pre_update(float* emb, float* ref, double* ts, float* pose, float* vel, const float* prev_exists, const double* timestamp,
+                            const float* ego_pose_inv, const float* pseudo_reference_points, const float* pc_range, int64_t B, int64_t capacity,
+                            int64_t memory_len, int64_t num_propagated, int64_t embed_dims, int fresh, toc3d_stream_t stream);
+int toc3d_memory_scores(const float* cls_scores, int64_t rows, int64_t num_classes, float* score, toc3d_stream_t stream);
+int toc3d_memory_post_update(const float* emb_in, const float* ref_in, const double* ts_in, const float* pose_in, const float* vel_in,
+                             float* emb_out, float* ref_out, double* ts_out, float* pose_out, float* vel_out, const int64_t* order,
+                             const float* rec_ego_pose, const float* bbox_preds, int64_t ld_bbox, const float* outs_dec, const float* ego_pose,
+                             const double* timestamp, int64_t B, int64_t Q, int64_t capacity, int64_t memory_len, int64_t topk, int64_t embed_dims,
+                             toc3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,3 +221,72 @@ def build_reference_cpfpn(cfg: dict):
     ref = load_reference()
     kw = {k: v for k, v in cfg.items() if k != "type"}
     return ref.cp_fpn.CPFPN(**kw).eval()
+
+
+# ---------------------------------------------------------------------------------------------------
+# StreamPETRHead temporal memory: only the three memory methods are exercised; everything
+# the module imports at top level is stubbed (dense_heads/streampetr_head.py:12-31).
+_HEAD = {}
+
+
+def load_reference_head():
+    """Returns the reference ``StreamPETRHead`` class (methods used unbound on a plain object holding the memory state)."""
+    if _HEAD:
+        return _HEAD["cls"]
+    load_reference()
+    heads = _Registry()
+    sys.modules["mmcv.cnn"].Linear = nn.Linear
+    sys.modules["mmcv.cnn"].bias_init_with_prob = lambda p: 0.0
+    sys.modules["mmcv.runner"].force_fp32 = lambda *a, **k: (lambda f: f)
+    core = sys.modules["mmdet.core"]
+    core.build_assigner = core.build_sampler = core.multi_apply = core.reduce_mean = None
+    sys.modules["mmdet.models.utils"].build_transformer = None
+    sys.modules["mmdet.models.utils"].NormedLinear = nn.Linear
+    sys.modules["mmdet.models"].HEADS = heads
+
+    class AnchorFreeHead(nn.Module):
+        pass
+
+    _mod("mmdet.models.dense_heads")
+    _mod("mmdet.models.dense_heads.anchor_free_head", AnchorFreeHead=AnchorFreeHead)
+    _mod("mmdet3d.core")
+    _mod("mmdet3d.core.bbox")
+    _mod("mmdet3d.core.bbox.coders", build_bbox_coder=None)
+    sys.modules["mmdet3d.models"].build_loss = lambda cfg: None
+    for name, path in [("projects.mmdet3d_plugin.core", "projects/mmdet3d_plugin/core"),
+                       ("projects.mmdet3d_plugin.core.bbox", "projects/mmdet3d_plugin/core/bbox"),
+                       ("projects.mmdet3d_plugin.models.dense_heads", "projects/mmdet3d_plugin/models/dense_heads")]:
+        _mod(name).__path__ = [f"{REF}/{path}"]
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        mod = importlib.import_module("projects.mmdet3d_plugin.models.dense_heads.streampetr_head")
+    _HEAD["cls"] = mod.StreamPETRHead
+    return _HEAD["cls"]
+
+
+class ReferenceMemory:
+    """Plain holder for the attributes ``StreamPETRHead.{reset,pre_update,post_update}_memory`` touch
+    (dense_heads/streampetr_head.py:315-377), driven through the reference's own (unbound) methods."""
+
+    def __init__(self, memory_len, topk_proposals, num_propagated, embed_dims, pc_range, pseudo_reference_points):
+        self.memory_len, self.topk_proposals, self.num_propagated, self.embed_dims = memory_len, topk_proposals, num_propagated, embed_dims
+        self.pc_range = torch.tensor(pc_range, dtype=torch.float32)
+        self.pseudo_reference_points = types.SimpleNamespace(weight=pseudo_reference_points)
+        self.training = False
+        self._cls = load_reference_head()
+        self._cls.reset_memory(self)
+
+    def pre_update_memory(self, data):
+        self._cls.pre_update_memory(self, data)
+
+    def post_update_memory(self, data, rec_ego_pose, all_cls_scores, all_bbox_preds, outs_dec):
+        orig = torch.topk
+
+        def stable_topk(input, k, dim=-1, largest=True, sorted=True):       # tie rule pinned like torch.sort elsewhere
+            v, i = torch.sort(input, dim=dim, descending=largest, stable=True)
+            return v.narrow(dim, 0, k), i.narrow(dim, 0, k)
+
+        torch.topk = stable_topk
+        try:
+            self._cls.post_update_memory(self, data, rec_ego_pose, all_cls_scores, all_bbox_preds, outs_dec, None)
+        finally:
+            torch.topk = orig

@@ -127,3 +127,25 @@ def test_image_oracle_normalise_pad_format():
         assert (out[:, :, 30:, :] == 0).all() and (out[:, :, :, 50:] == 0).all()
     # integer-valued float32 input (what LoadMultiViewImageFromFiles(to_float32=True) hands over) gives the same bits
     assert np.array_equal(I.imnormalize(img[0].astype(np.float32), mean, std, False), I.imnormalize(img[0], mean, std, False))
+
+
+def test_memory_bank_oracle_matches_reference_golden(golden_dir):
+    """oracle/memory_oracle.py against tests/golden/memory_bank.npz, written by the reference's own
+    StreamPETRHead.pre/post_update_memory (oracle/gen_golden_memory.py): bit-exact over a 4-frame sequence incl. a scene change."""
+    from oracle.memory_oracle import MemoryBank
+    from oracle.gen_golden_memory import CFG, B, NQ, NCLS, FRAMES
+    g = np.load(os.path.join(golden_dir, "memory_bank.npz"))
+    inp = synth.memory_inputs(CFG, B, NQ, NCLS, FRAMES, seed=0)
+    m = MemoryBank(pseudo_reference_points=inp["pseudo"], **CFG)
+    for f in range(FRAMES):
+        fr = inp["frames"][f]
+        m.pre_update_memory(fr["data"])
+        for k, v in m.state().items():
+            ref = torch.from_numpy(g[f"f{f}_pre_{k}"])
+            assert v.dtype == ref.dtype and torch.equal(v, ref), (f, "pre", k)
+        q = m.backbone_queries(8, mid_frame=f > 0)
+        assert q["temp_queries"].shape[1] == 8 and (f > 0 or float(q["temp_queries"].abs().sum()) == 0.0)
+        m.post_update_memory(fr["data"], fr["rec_ego_pose"], fr["cls"], fr["bbox"], fr["dec"])
+        for k, v in m.state().items():
+            ref = torch.from_numpy(g[f"f{f}_post_{k}"])
+            assert v.dtype == ref.dtype and torch.equal(v, ref), (f, "post", k)

@@ -296,3 +296,76 @@ def test_two_frames_batch_matches_oracle(groups):
     assert rel_max(out.img_feats["last_feat"], ref["last_feat"]) < 1e-3
     for s in range(3):          # order among near-equal scores may differ by float rounding; the kept *sets* must agree
         assert iou(out.keep_idx[s], ref["keep_idx"][s].numpy()) > 0.995
+
+
+# ---------------------------------------------------------------------------------------------------
+# temporal memory bank
+def _run_memory(mem, oracle, inp, frames, tol=2e-6):
+    d = lambda t: t.to(DEV)
+    for f in range(frames):
+        fr = inp["frames"][f]
+        data = {k: d(v) for k, v in fr["data"].items()}
+        mem.pre_update_memory(data)
+        oracle.pre_update_memory(fr["data"])
+        for phase in ("pre", "post"):
+            if phase == "post":
+                mem.post_update_memory(data, d(fr["rec_ego_pose"]), d(fr["cls"])[None], d(fr["bbox"])[None], d(fr["dec"])[None])
+                oracle.post_update_memory(fr["data"], fr["rec_ego_pose"], fr["cls"], fr["bbox"], fr["dec"])
+            ref = oracle.state()
+            got = dict(embedding=mem.memory_embedding, reference_point=mem.memory_reference_point, timestamp=mem.memory_timestamp,
+                       egopose=mem.memory_egopose, velo=mem.memory_velo)
+            for k in ref:
+                r, g = ref[k].double(), got[k].double().cpu()
+                assert r.shape == g.shape, (f, phase, k, r.shape, g.shape)
+                if k in ("embedding", "velo", "timestamp"):              # copies, masks and f64 sums: exact
+                    assert torch.equal(g, r), (f, phase, k)
+                else:                                                    # 4x4 products: torch's CPU bmm may fuse multiply-adds
+                    assert (g - r).abs().max() <= tol * max(1.0, float(r.abs().max())), (f, phase, k, float((g - r).abs().max()))
+
+
+def test_memory_bank_matches_reference_golden_sequence(golden_dir):
+    """toc3d_amd.TemporalMemory over the 4-frame golden sequence written by the reference's own head methods."""
+    from oracle.memory_oracle import MemoryBank
+    from oracle.gen_golden_memory import CFG, B, NQ, NCLS, FRAMES
+    inp = synth.memory_inputs(CFG, B, NQ, NCLS, FRAMES, seed=0)
+    mem = toc3d_amd.TemporalMemory(pseudo_reference_points=inp["pseudo"], **CFG)
+    g = np.load(os.path.join(golden_dir, "memory_bank.npz"))
+    d = lambda t: t.to(DEV)
+    for f in range(FRAMES):
+        fr = inp["frames"][f]
+        data = {k: d(v) for k, v in fr["data"].items()}
+        mem.pre_update_memory(data)
+        mem.post_update_memory(data, d(fr["rec_ego_pose"]), d(fr["cls"])[None], d(fr["bbox"])[None], d(fr["dec"])[None])
+        for k, got in (("embedding", mem.memory_embedding), ("velo", mem.memory_velo), ("timestamp", mem.memory_timestamp),
+                       ("reference_point", mem.memory_reference_point), ("egopose", mem.memory_egopose)):
+            ref = torch.from_numpy(g[f"f{f}_post_{k}"]).double()
+            got = got.double().cpu()
+            if k in ("embedding", "velo", "timestamp"):
+                assert torch.equal(got, ref), (f, k)
+            else:
+                assert (got - ref).abs().max() <= 2e-6 * max(1.0, float(ref.abs().max())), (f, k)
+    _run_memory(toc3d_amd.TemporalMemory(pseudo_reference_points=inp["pseudo"], **CFG), MemoryBank(pseudo_reference_points=inp["pseudo"], **CFG), inp, FRAMES)
+
+
+def test_memory_bank_full_size_feeds_the_backbone():
+    """Shipped sizes (memory_len 512, top-k 128, 128 propagated, 256-d, 900 + 128 queries, projects/configs/ToC3D/ToC3D_faster.py) against the
+    oracle for 3 frames, then the bank's first 64 slots drive a ToC3D forward exactly like tensors sliced from the oracle's bank."""
+    from oracle.memory_oracle import MemoryBank
+    cfgm = dict(memory_len=512, topk_proposals=128, num_propagated=128, embed_dims=256, pc_range=[-51.2, -51.2, -5.0, 51.2, 51.2, 3.0])
+    inp = synth.memory_inputs(cfgm, 1, 900, 10, 3, seed=1)
+    mem = toc3d_amd.TemporalMemory(pseudo_reference_points=inp["pseudo"], **cfgm)
+    ora = MemoryBank(pseudo_reference_points=inp["pseudo"], **cfgm)
+    _run_memory(mem, ora, inp, 3)
+    with pytest.raises(RuntimeError, match="CUDA/HIP"):
+        mem.pre_update_memory(inp["frames"][0]["data"])
+    cfg, m = build("toc3d_tiny", "fp32")
+    binp = synth.make_inputs(cfg, views_per_frame=2)
+    q = mem.backbone_queries(cfg["pruning_num_queries"], prev_exists=True)
+    oq = ora.backbone_queries(cfg["pruning_num_queries"], True)
+    x, inv = binp["x"].to(DEV), binp["ego_pose_inv"].to(DEV)
+    a = m(x, ego_pose_inv=inv, gumbel_noise=binp["gumbel"], **q)
+    fa, ka = a.img_feats["last_feat"].clone(), [k.clone() for k in a.keep_idx]
+    b = m(x, ego_pose_inv=inv, gumbel_noise=binp["gumbel"], prev_exists=True, **{k: v.to(DEV) for k, v in oq.items()})
+    assert float((fa - b.img_feats["last_feat"]).abs().max()) < 1e-3 * float(fa.abs().max())
+    for s in range(3):
+        assert iou(ka[s], b.keep_idx[s].cpu()) > 0.99

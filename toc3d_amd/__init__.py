@@ -6,8 +6,9 @@ reference's type names, like ``projects/mmdet3d_plugin`` does on import (``tools
 from .backbone import EVA_ViT, ToC3DEVAViT, ToC3DViTReturnType
 from .neck import CPFPN
 from .preprocess import prepare_images
+from .memory import TemporalMemory
 from .registry import BACKBONES, NECKS, build_backbone, build_neck, register_all
 
 register_all()
 
-__all__ = ["ToC3DEVAViT", "EVA_ViT", "CPFPN", "ToC3DViTReturnType", "BACKBONES", "NECKS", "build_backbone", "build_neck", "prepare_images"]
+__all__ = ["ToC3DEVAViT", "EVA_ViT", "CPFPN", "ToC3DViTReturnType", "BACKBONES", "NECKS", "build_backbone", "build_neck", "prepare_images", "TemporalMemory"]

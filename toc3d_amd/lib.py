@@ -45,6 +45,9 @@ _SIGS = {
     "toc3d_score_head": "ipllppplpppp",
     "toc3d_nhwc_to_nchw": "pplllp",
     "toc3d_im2col_3x3": "ipplllllp",
+    "toc3d_memory_pre_update": "pppppppppplllllip",
+    "toc3d_memory_scores": "pllpp",
+    "toc3d_memory_post_update": "ppppppppppppplpppllllllp",
 }
 _CT = {"p": _P, "l": _I64, "i": _I, "f": _F}
 

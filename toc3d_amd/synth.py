@@ -243,3 +243,26 @@ def make_inputs(cfg, n_frames: int = 1, views_per_frame: int = 6, hw=(320, 800),
         gum.append(torch.from_numpy(-np.log(e)))
     out["gumbel"] = gum
     return {k: ([t.to(device) for t in v] if isinstance(v, list) else v.to(device)) for k, v in out.items()}
+
+
+def memory_inputs(cfg: dict, B: int, num_query: int, num_classes: int, frames: int, seed: int = 0):
+    """Seeded inputs for the temporal memory bank: per frame the ``data`` dict of the head
+    (prev_exists, f64 epoch timestamps, ego pose and its inverse) and the last decoder layer's outputs."""
+    import numpy as np
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    out = {"pseudo": torch.rand(cfg["num_propagated"], 3, generator=g), "frames": []}
+    Q = num_query + cfg["num_propagated"]
+    for f in range(frames):
+        prev = torch.ones(B) if f > 0 else torch.zeros(B)
+        if f == 3 and B > 1:
+            prev[1] = 0.0                                        # scene change for one sample of the batch
+        ang = 0.02 * r(B)
+        pose = torch.eye(4).repeat(B, 1, 1)
+        pose[:, 0, 0], pose[:, 0, 1], pose[:, 1, 0], pose[:, 1, 1] = torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang)
+        pose[:, :3, 3] = r(B, 3) * torch.tensor([2.0, 0.5, 0.05])
+        data = dict(prev_exists=prev, timestamp=torch.tensor([1.5e9 + 0.5 * f + 7.0 * b for b in range(B)], dtype=torch.float64),
+                    ego_pose=pose, ego_pose_inv=torch.linalg.inv(pose))
+        out["frames"].append(dict(data=data, rec_ego_pose=torch.eye(4).repeat(B, Q, 1, 1), cls=r(B, Q, num_classes) * 2.0,
+                                  bbox=r(B, Q, 10) * 5.0, dec=r(B, Q, cfg["embed_dims"])))
+    return out
