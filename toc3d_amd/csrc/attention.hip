@@ -84,6 +84,12 @@ TOC3D_DEV void rope8_lds(float (&x)[8], const float* cosRC, const float* sinRC, 
     }
 }
 
+// V^T row of head dim d.  A (key, 8-dim chunk) thread writes dims dc*8 + j; in natural order the 8 chunks of a wavefront
+// instruction land 8 rows apart = on 2 bank groups (measured: SQ_LDS_BANK_CONFLICT 55 % of the LDS-active cycles).  With
+// row(d) = (d & 3)*16 + (d >> 2) they land 2 rows apart = 8 distinct bank groups, and the P.V accumulator of MFMA column
+// block d', lane column r16 is head dim r16*4 + d': each lane owns 4 consecutive output dims (one 8 / 16-byte store).
+TOC3D_DEV int vt_row(int d) { return (d & 3) * 16 + (d >> 2); }
+
 template <typename T, int QM>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     constexpr int LD = Pad<T>::ld;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             }
             store8(Ks + key * LD + dc * 8, kx);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Vt[(dc * 8 + j) * LD + key] = to_act<T>(vx[j]);
+            for (int j = 0; j < 8; ++j) Vt[vt_row(dc * 8 + j) * LD + key] = to_act<T>(vx[j]);
         }
         __syncthreads();
         if (kt + 1 < nkt) fetch(kt + 1);         // in flight during the MFMA phase below
@@ -283,14 +289,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             const int qi = q0 + mi * 16 + g * 4 + r;
             if (qi < n) {
                 const int64_t orow = rows[qi];
-                T* dst = reinterpret_cast<T*>(a.out) + orow * a.ldo + head * HD;
+                T* dst = reinterpret_cast<T*>(a.out) + orow * a.ldo + head * HD + r16 * 4;
+                T o4[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int dd = d * 16 + r16;
+                for (int d = 0; d < 4; ++d) {                   // V^T row d*16 + r16 holds head dim r16*4 + d (vt_row)
                     float v = o[mi][d][r] * alpha;
-                    if (np > 0) v += padw * a.v_bias[head * HD + dd];
-                    dst[dd] = to_act<T>(v * inv);
+                    if (np > 0) v += padw * a.v_bias[head * HD + r16 * 4 + d];
+                    o4[d] = to_act<T>(v * inv);
                 }
+                store4(dst, o4);
             }
         }
 }
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int SMALL_MAX_SUB = 13;                // 13 * 16 = 208 keys
 
-template <typename T>
+template <typename T, bool CHUNK>
 __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     constexpr int LD = Pad<T>::ld;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -314,8 +321,10 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     const int LDP = NK32 + 16 / (int)sizeof(T);  // row stride of V^T and P (elements), keeps 16-byte alignment
     T* Ks = reinterpret_cast<T*>(smem);          // [nsub*16][LD]
     T* Vt = Ks + nsub * 16 * LD;                 // [HD][LDP]
-    T* Ps = Vt + HD * LDP;                       // [4 waves][16][LDP]
-    int32_t* s_rows = reinterpret_cast<int32_t*>(Ps + 4 * 16 * LDP);
+    constexpr int PLD = 32 + 16 / (int)sizeof(T); // P chunk tile row stride (elements)
+    const int PS = CHUNK ? PLD : LDP;            // P row stride: one 32-key chunk at a time, or the whole key range
+    T* Ps = Vt + HD * LDP;                       // [4 waves][16][PS]
+    int32_t* s_rows = reinterpret_cast<int32_t*>(Ps + 4 * 16 * PS);
     const int istride = (int)((a.stride + 3) & ~3);
     int32_t* s_slots = s_rows + istride;
     float* s_cos = reinterpret_cast<float*>(s_slots + istride);
@@ -377,12 +386,12 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
             }
             if (key < nsub * 16) store8(Ks + key * LD + dc * 8, kx);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Vt[(dc * 8 + j) * LDP + key] = to_act<T>(vx[j]);
+            for (int j = 0; j < 8; ++j) Vt[vt_row(dc * 8 + j) * LDP + key] = to_act<T>(vx[j]);
         }
     }
     __syncthreads();
 
-    T* Pw = Ps + wave * 16 * LDP;
+    T* Pw = Ps + wave * 16 * PS;
     const int nmt = (n + 15) >> 4;
     // raw Q rows of all tiles this wave owns (<= 4) are requested up front
     constexpr int MAXT = (SMALL_MAX_SUB + 1 + 3) / 4;
@@ -437,38 +446,66 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
         float sum[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { mx[r] = row16_max(mx[r]); sum[r] = 0.f; }
-        // P = exp(S - max) -> LDS (A-operand layout); columns past nsub*16 up to NK32 are zeroed
-#pragma unroll
-        for (int t = 0; t < SMALL_MAX_SUB + 1; ++t) {
-            if (t * 16 < NK32) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv = 0.f;
-                    if (t < SMALL_MAX_SUB && t < nsub) { pv = __expf(sc[t < SMALL_MAX_SUB ? t : 0][r] - mx[r]); sum[r] += pv; }
-                    Pw[(g * 4 + r) * LDP + t * 16 + r16] = to_act<T>(pv);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // O = P V
+        // O = P V.  P = exp(S - max) goes through wave-private LDS (C layout -> A-operand layout).  CHUNK: one [16][32] tile at
+        // a time, so the P buffer costs 5 KB instead of 21 KB per workgroup (3 workgroups / CU up to 144 keys) -- for launches
+        // with more workgroups than 2 per CU; otherwise the whole P row block at once (shorter dependent chain per wave).
         f32x4 o[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < NK32; ks += 32) {
-            const Frag<T> pf = read_frag(Pw + r16 * LDP + ks + g * 8);
+        if constexpr (CHUNK) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d) mma_step(o[d], pf, read_frag(Vt + (d * 16 + r16) * LDP + ks + g * 8));
+            for (int c = 0; c < (SMALL_MAX_SUB + 1) / 2; ++c) {
+                if (c * 32 < NK32) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 2 * c + tt;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float pv = 0.f;
+                            if (t < SMALL_MAX_SUB && t < nsub) { pv = __expf(sc[t < SMALL_MAX_SUB ? t : 0][r] - mx[r]); sum[r] += pv; }
+                            Pw[(g * 4 + r) * PLD + tt * 16 + r16] = to_act<T>(pv);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const Frag<T> pf = read_frag(Pw + r16 * PLD + g * 8);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) mma_step(o[d], pf, read_frag(Vt + (d * 16 + r16) * LDP + c * 32 + g * 8));
+                    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order: the next chunk's writes follow this read)
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < SMALL_MAX_SUB + 1; ++t) {      // columns past nsub*16 up to NK32 are zeroed
+                if (t * 16 < NK32) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = 0.f;
+                        if (t < SMALL_MAX_SUB && t < nsub) { pv = __expf(sc[t < SMALL_MAX_SUB ? t : 0][r] - mx[r]); sum[r] += pv; }
+                        Pw[(g * 4 + r) * LDP + t * 16 + r16] = to_act<T>(pv);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int ks = 0; ks < NK32; ks += 32) {
+                const Frag<T> pf = read_frag(Pw + r16 * LDP + ks + g * 8);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) mma_step(o[d], pf, read_frag(Vt + (d * 16 + r16) * LDP + ks + g * 8));
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float inv = 1.f / row16_sum(sum[r]);
             const int qi = mt * 16 + g * 4 + r;
             if (qi < n) {
-                T* dst = reinterpret_cast<T*>(a.out) + (int64_t)s_rows[qi] * a.ldo + head * HD;
+                T* dst = reinterpret_cast<T*>(a.out) + (int64_t)s_rows[qi] * a.ldo + head * HD + r16 * 4;
+                T o4[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) dst[d * 16 + r16] = to_act<T>(o[d][r] * inv);
+                for (int d = 0; d < 4; ++d) o4[d] = to_act<T>(o[d][r] * inv);     // V^T row d*16 + r16 holds head dim r16*4 + d
+                store4(dst, o4);
             }
         }
         __builtin_amdgcn_wave_barrier();          // P of this tile fully consumed before the next tile overwrites it
@@ -476,25 +513,32 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
 }
 
 template <typename T>
-size_t attn_small_lds(int64_t stride, int L) {
+size_t attn_small_lds(int64_t stride, int L, bool chunk) {
     const int64_t nsub = (stride + 15) / 16, nk32 = (stride + 31) / 32 * 32, ldp = nk32 + 16 / (int)sizeof(T);
-    return (size_t)(nsub * 16 * Pad<T>::ld + (HD + 64) * ldp) * sizeof(T) + (size_t)((stride + 3) & ~3) * 8 + (size_t)L * 16 * 16;
+    const int64_t ps = chunk ? 32 + 16 / (int)sizeof(T) : ldp;
+    return (size_t)(nsub * 16 * Pad<T>::ld + HD * ldp + 64 * ps) * sizeof(T) + (size_t)((stride + 3) & ~3) * 8 + (size_t)L * 16 * 16;
+}
+
+template <typename T, bool CHUNK>
+void launch_small(const AttnArgs& a, size_t lds, int64_t num_heads, int64_t nwin, hipStream_t s) {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_kernel<T, CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }
+    hipLaunchKernelGGL((attn_small_kernel<T, CHUNK>), dim3((unsigned)num_heads, (unsigned)nwin), dim3(256), lds, s, a);
 }
 
 template <typename T>
 void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
-    // 64-query workgroups: measured faster than 128-query ones on every window size of this model (more, fuller
-    // workgroups beat the halved K/V staging); the QM = 2 instantiation is kept for larger windows
-    // accelerated blocks (no analytic zero pads, <= 208 keys incl. virtual ones): whole-window-resident kernel
+    // accelerated blocks (no analytic zero pads, <= 208 keys incl. virtual ones): whole-window-resident kernel, one workgroup
+    // per (window, head), when its LDS footprint lets at least two of them share a CU.  With more workgroups than two per
+    // CU the chunked-P form (smaller footprint -> a third workgroup per CU) wins; with fewer, the plain form (measured).
     if (!a.npad && a.stride <= SMALL_MAX_SUB * 16) {
-        const size_t lds_s = attn_small_lds<T>(a.stride, a.L);
-        if (lds_s <= 80 * 1024) {                // keeps two workgroups per CU
-            static bool set = false;
-            if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }
-            hipLaunchKernelGGL((attn_small_kernel<T>), dim3((unsigned)num_heads, (unsigned)nwin), dim3(256), lds_s, s, a);
-            return;
-        }
+        const size_t full = attn_small_lds<T>(a.stride, a.L, false), chunk = attn_small_lds<T>(a.stride, a.L, true);
+        const bool crowded = nwin * num_heads > 2 * 256;
+        if (crowded && chunk <= 53 * 1024 && full > 53 * 1024) { launch_small<T, true>(a, chunk, num_heads, nwin, s); return; }
+        if (full <= 80 * 1024) { launch_small<T, false>(a, full, num_heads, nwin, s); return; }
     }
+    // dense / large windows: flash-style kernel, 64-query workgroups (measured faster than 128-query ones on every window
+    // size of this model: more, fuller workgroups beat the halved K/V staging)
     const size_t lds = (size_t)(KT + HD + 4 * 16) * Pad<T>::ld * sizeof(T) + (size_t)((a.stride + 3) & ~3) * 8 + (size_t)a.L * 16 * 4 * 4;
     dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)nwin);
     hipLaunchKernelGGL((attn_kernel<T, 1>), grid, dim3(256), lds, s, a);
@@ -540,6 +584,7 @@ int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out,
     TOC3D_REQUIRE(ldqkv >= 3 * C && ldo >= C, "toc3d_window_attention: leading dims too small for head_dim 64");
     const int esz = dtype == TOC3D_BF16 ? 2 : 4;
     TOC3D_REQUIRE((ldqkv * esz) % 16 == 0 && ((uintptr_t)qkv % 16) == 0, "toc3d_window_attention: qkv rows must be 16-byte aligned");
+    TOC3D_REQUIRE(ldo % 4 == 0 && ((uintptr_t)out % 16) == 0, "toc3d_window_attention: out must be 16-byte aligned with ldo a multiple of 4");
     TOC3D_REQUIRE(num_heads <= 65535 && nwin <= 65535, "toc3d_window_attention: grid too large");
     if (nwin == 0 || max_count == 0) return TOC3D_OK;
     AttnArgs a{qkv, ldqkv, out, ldo, rows, slots, count, count_k, npad, pad_qkv, stride, (int)C, (int)rope_side, rope_cos, rope_sin, v_bias, scale};
