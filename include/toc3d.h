@@ -99,20 +99,6 @@ int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int
                         float* row_stats, int64_t stats_slots, const float* ln_c1, int64_t ln_n, float ln_eps,
                         toc3d_stream_t stream);
 
-/* toc3d_linear_chain: toc3d_linear_ex with LayerNorms folded across GEMM boundaries, so that Block.norm1 / norm2
- * (backbones/eva_vit.py:249,263) and SwiGLU.ffn_ln (eva_vit.py:48) need no pass of their own over the activations:
- *   producer side -- stats_out f32 [M, stats_out_slots, 2]: per row and per 128-wide N-tile the (sum, sum of squares) of the
- *     values AS STORED in the activation dtype: the hidden for EPI_SWIGLU, the new residual rows for EPI_RESIDUAL, which then
- *     also writes them to act_out [M, ld_act] (the next GEMM's A operand).  Needs a variant with 128-wide N-tiles.
- *   consumer side -- ln_c1 f32 [N] = rowsum of the packed W*gamma, bias = W beta + b, stats_in / stats_in_slots / ln_n / ln_eps:
- *     any epilogue first maps the accumulator to rstd*(acc - mean*c1[n]) + bias[n] with (mean, rstd) from the row's slots.
- * The reduction order is fixed, so every tile variant returns the same bits. */
-int toc3d_linear_chain(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                       void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                       float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                       const float* stats_in, int64_t stats_in_slots, const float* ln_c1, int64_t ln_n, float ln_eps,
-                       float* stats_out, int64_t stats_out_slots, void* act_out, int64_t ld_act, toc3d_stream_t stream);
-
 /* f32 [N, K] state-dict weight -> act [Np, Kp], zero padded (Np multiple of 128, Kp multiple of 64). */
 int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out, int64_t Np, int64_t Kp, toc3d_stream_t stream);
 /* mlp.w1 / mlp.w2 (eva_vit.py:35-36) -> interleaved [2*Hp, Kp] + bias [2*Hp]; packed row 32b+i = w1 row 16b+i,

@@ -743,63 +743,3 @@ def test_im2col_u8_equals_im2col_of_normalized_images(name, dt, tdt, H, W):
     assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
     with pytest.raises(RuntimeError, match="multiple of the patch"):
         lib.call("toc3d_im2col_patches_u8", dt, img, V, H, W, torch.tensor(IMG_NORM["mean"]), torch.tensor(IMG_NORM["std"]), 0, b, Kp, Hp + 1, Wp, p, S())
-
-
-@pytest.mark.parametrize("name,dt,tdt", DTYPES)
-@pytest.mark.parametrize("M,C,Hd", [(300, 128, 341), (1000, 1024, 2730)])
-def test_layernorm_chain_across_gemms(name, dt, tdt, M, C, Hd):
-    """Block.norm1 / norm2 (eva_vit.py:249,263) folded across GEMM boundaries (toc3d_linear_chain): the residual epilogue
-    leaves the activation copy + row statistics, the next GEMM (bias epilogue = q|k|v, SwiGLU epilogue = w1|w2) applies the
-    LayerNorm in its epilogue.  Against the exact composition in float64 on the values as stored; bit-identical across variants."""
-    K0 = 256
-    A0, W0, b0 = rnd(M, K0, seed=1), rnd(C, K0, seed=2, scale=K0 ** -0.5), rnd(C, seed=3)
-    res = rnd(M, C, seed=4) * 3.0 + 0.7                                       # non-zero mean rows on purpose
-    gam, bet = 1 + 0.2 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
-    Wq, bq = rnd(3 * C, C, seed=7, scale=C ** -0.5), rnd(3 * C, seed=8)
-    w1, w2 = rnd(Hd, C, seed=9, scale=C ** -0.5), rnd(Hd, C, seed=10, scale=C ** -0.5)
-    b1, b2 = rnd(Hd, seed=11) * 0.3, rnd(Hd, seed=12) * 0.3
-    a0_d, w0_d = as_act(A0, tdt), pack(W0, dt, tdt)
-    slots = C // 128
-    # consumers' packed weights: W * gamma, c1 = rowsum of the packed (rounded) weights, c2 = W beta + b
-    wq_g = pack(Wq * gam[None, :], dt, tdt)
-    c1q = wq_g[:3 * C, :C].float().sum(1).contiguous()
-    c2q = (Wq @ bet + bq).to(DEV)
-    Hp = ru(Hd, 64)
-    w12 = torch.empty(2 * Hp, C, dtype=tdt, device=DEV)
-    c2_12 = torch.empty(2 * Hp, device=DEV)
-    lib.call("toc3d_pack_swiglu", dt, (w1 * gam[None, :]).to(DEV), (w2 * gam[None, :]).to(DEV), (w1 @ bet + b1).to(DEV), (w2 @ bet + b2).to(DEV),
-             Hd, C, w12, c2_12, Hp, C, S())
-    c1_12 = w12.float().sum(1).contiguous()
-    first = None
-    for vp, vq, v12 in ((16, 16, 16), (8, 14, 8), (17, 13, 1), (126, 110, 117), (1, 26, 15)):
-        x = res.to(DEV).clone()
-        act = torch.full((M, C), float("nan"), dtype=tdt, device=DEV)
-        st = torch.full((M, slots, 2), float("nan"), device=DEV)
-        lib.call("toc3d_linear_chain", dt, lib.EPI_RESIDUAL, vp, a0_d, K0, w0_d, K0, b0.to(DEV), x, C, x, C, 0, None, None, M, C, K0, 0,
-                 None, 0, None, 0, 0.0, st, slots, act, C, S())
-        xr = res.double() + A0.to(tdt).double() @ W0.to(tdt).double().T + b0.double()
-        assert relerr(x, xr) < (2e-5 if dt == lib.F32 else 6e-3)
-        assert torch.equal(act.float(), x.to(tdt).float()), "activation copy must be the rounded residual row"
-        xs = act.double().cpu()                                              # values as stored: what the statistics describe
-        s_ref = torch.stack([xs.view(M, slots, 128).sum(2), (xs * xs).view(M, slots, 128).sum(2)], dim=2)
-        assert relerr(st, s_ref) < 1e-5
-        qkv = torch.zeros(M, 3 * C, dtype=tdt, device=DEV)
-        lib.call("toc3d_linear_chain", dt, lib.EPI_BIAS, vq, act, C, wq_g, C, c2q, qkv, 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
-                 st, slots, c1q, C, 1e-6, None, 0, None, 0, S())
-        ln = torch.nn.functional.layer_norm(xs, (C,), gam.double(), bet.double(), 1e-6)
-        q_ref = ln @ Wq.double().T + bq.double()
-        assert relerr(qkv.float(), q_ref) < (3e-5 if dt == lib.F32 else 1.2e-2), (vq, relerr(qkv.float(), q_ref))
-        hid = torch.zeros(M, Hp, dtype=tdt, device=DEV)
-        hst = torch.zeros(M, 2 * Hp // 128, 2, device=DEV)
-        lib.call("toc3d_linear_chain", dt, lib.EPI_SWIGLU, v12, act, C, w12, C, c2_12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
-                 st, slots, c1_12, C, 1e-6, hst, 2 * Hp // 128, None, 0, S())
-        h_ref = torch.nn.functional.silu(ln @ w1.double().T + b1.double()) * (ln @ w2.double().T + b2.double())
-        assert relerr(hid[:, :Hd].float(), h_ref) < (3e-5 if dt == lib.F32 else 1.5e-2), (v12, relerr(hid[:, :Hd].float(), h_ref))
-        cur = (x.clone(), act.clone(), st.clone(), qkv.clone(), hid.clone(), hst.clone())
-        if first is None:
-            first = cur
-        for got, ref, what in zip(cur, first, ("residual", "activation copy", "row statistics", "q|k|v", "hidden", "hidden statistics")):
-            assert torch.equal(got.view(torch.uint8), ref.view(torch.uint8)), f"{what}: variants {(vp, vq, v12)} differ from the first set"
-    with pytest.raises(RuntimeError, match="128-wide"):                       # 64-wide tiles cannot fill 128-wide statistic slots
-        lib.call("toc3d_linear_chain", dt, lib.EPI_RESIDUAL, 14, a0_d, K0, w0_d, K0, b0.to(DEV), x, C, x, C, 0, None, None, M, C, K0, 0,
-                 None, 0, None, 0, 0.0, st, slots, act, C, S())

@@ -19,7 +19,6 @@ Extra forward kwarg: ``gumbel_noise`` (list of 3 tensors (B*Nv, T, 2)) to make t
 from __future__ import annotations
 
 import math
-import os
 from functools import partial
 from typing import Dict, List, Optional
 
@@ -197,9 +196,6 @@ class _BackboneBase(nn.Module):
         self._side = None               # side stream: query-side scorer prep / image-level ranking overlap the blocks
         self.view_groups = 1            # > 1: split the views into groups that run concurrently on separate streams
         self.fold_ffn_ln = precision == "bf16"   # strict-parity path keeps the two-pass LayerNorm kernel
-        # norm1 / norm2 folded into the q|k|v and w1|w2 GEMMs (toc3d_linear_chain): the producing residual epilogue leaves the
-        # activation copy + row statistics, so no LayerNorm pass runs between GEMMs.  bf16 path only, needs 128-wide statistic slots.
-        self.fold_norms = precision == "bf16" and embed_dim % 128 == 0 and os.environ.get("TOC3D_FOLD_NORMS", "1") != "0"
         self._gstreams = []
 
     # -- state-dict hook: re-pack after new weights arrive ------------------------------------------
@@ -261,22 +257,6 @@ class _BackboneBase(nn.Module):
                      self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
             p["w12"], p["b12"] = w12, b12
             p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
-            if self.fold_norms:
-                g1, be1 = blk.norm1.weight.detach().float(), blk.norm1.bias.detach().float()
-                g2, be2 = blk.norm2.weight.detach().float(), blk.norm2.bias.detach().float()
-                wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach().float()
-                p["wqkvg"] = self._pack_linear(wq * g1[None, :])
-                p["c1q"] = p["wqkvg"][:3 * C, :C].float().sum(dim=1).contiguous()         # of the *rounded* weights (see c1 below)
-                p["c2q"] = (wq @ be1 + p["bqkv"]).contiguous()
-                w1f, w2f = m.w1.weight.detach().float(), m.w2.weight.detach().float()
-                w12g = torch.empty(2 * Hp, C, dtype=self._tdt, device=dev)
-                c2_12 = torch.empty(2 * Hp, dtype=torch.float32, device=dev)
-                lib.call("toc3d_pack_swiglu", self._dt, (w1f * g2[None, :]).contiguous(), (w2f * g2[None, :]).contiguous(),
-                         (w1f @ be2 + m.w1.bias.detach().float()).contiguous(), (w2f @ be2 + m.w2.bias.detach().float()).contiguous(),
-                         Hd, C, w12g, c2_12, Hp, C, lib.stream_ptr())
-                torch.cuda.current_stream().synchronize()                                   # the f32 temporaries above
-                p["w12g"], p["c2_12"] = w12g, c2_12
-                p["c1_12"] = w12g.float().sum(dim=1).contiguous()
             if self.fold_ffn_ln:
                 w3f = m.w3.weight.detach().float()
                 p["w3g"] = self._pack_linear(w3f * m.ffn_ln.weight.detach().float()[None, :])
@@ -359,8 +339,6 @@ class _BackboneBase(nn.Module):
                     hid=torch.zeros(R, Hp, dtype=tdt, device=dev),
                     hln=torch.zeros(R, Hp, dtype=tdt, device=dev),
                     stats=torch.empty(R, (2 * Hp) // 128, 2, dtype=torch.float32, device=dev),
-                    xstats=torch.empty(R, max(1, C // 128), 2, dtype=torch.float32, device=dev),   # folded norm1 / norm2: row statistics of the
-                    xa_valid=False,                                                                 # residual rows; plan["a"] = their activation copy
                     col=torch.zeros(M, _round_up(Kc, 64), dtype=tdt, device=dev),
                     Kc=Kc)
         plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
@@ -374,18 +352,15 @@ class _BackboneBase(nn.Module):
     # tile variants whose N-tile is 128 wide (the SwiGLU row-statistics slots of the folded ffn_ln assume that width)
     _BN128 = (1, 8, 10, 15, 16, 17, 22, 24, 26, 28, 29, 110, 117, 126)
 
-    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fin=None, fout=None):
-        """toc3d_linear_chain with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid,
+                stats=None, stats_slots=0, ln_c1=None, ln_n=0, ln_eps=0.0):
+        """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
         real operands the first time the shape is seen (never during hipGraph capture: shapes are warmed up eagerly).
-        All variants accumulate K in the same order, so the choice does not change results.
-        fin  = (stats_in, slots, c1, ln_n, eps): LayerNorm folded in front of this GEMM (consumer side);
-        fout = (stats_out, slots, act_out, ld_act): row statistics (+ activation copy, residual epilogue) for the next one."""
-        key = (epi, M, N, K, fin is not None, fout is not None)
+        All variants accumulate K in the same order, so the choice does not change results."""
+        key = (epi, M, N, K, stats is not None)
         var = self._tuned.get(key)
         s = lib.stream_ptr()
-        si, sis, c1, ln_n, eps = fin if fin is not None else (None, 0, None, 0, 0.0)
-        so, sos, ao, lda_o = fout if fout is not None else (None, 0, None, 0)
-        tail = (si, sis, c1, ln_n, float(eps), so, sos, ao, lda_o, s)
+        tail = (stats, stats_slots, ln_c1, ln_n, float(ln_eps), s)
         if var is None:
             var = 0
             if self.autotune and not torch.cuda.is_current_stream_capturing():
@@ -393,12 +368,9 @@ class _BackboneBase(nn.Module):
                 if epi == lib.EPI_RESIDUAL:                 # in-place residual add: tune into scratch
                     o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
                 rep_s = torch.empty_like(rep_out) if rep_out is not None else None
-                ttail = tail
-                if fout is not None:                        # statistics / activation copy feed later launches: tune into scratch too
-                    ttail = (si, sis, c1, ln_n, float(eps), torch.empty_like(so), sos, torch.empty_like(ao) if ao is not None else None, lda_o, s)
                 best = None
                 cands = self._VARIANTS[self._dt]
-                if so is not None:
+                if epi == lib.EPI_SWIGLU and stats is not None:
                     cands = [v for v in cands if v in self._BN128]
                 if epi == lib.EPI_SWIGLU:
                     cands = [v for v in cands if v != 33]          # 16-column wave slabs cannot pair w1 / w2 columns
@@ -408,14 +380,14 @@ class _BackboneBase(nn.Module):
                 if _BackboneBase._flush is None or _BackboneBase._flush.device != out.device:
                     _BackboneBase._flush = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=out.device)
                 for v in cands:
-                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid) + ttail
-                    lib.call("toc3d_linear_chain", *args)
+                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid) + tail
+                    lib.call("toc3d_linear_lnfold", *args)
                     ts = []
                     for _ in range(3):
                         _BackboneBase._flush.zero_()
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        lib.call("toc3d_linear_chain", *args)
+                        lib.call("toc3d_linear_lnfold", *args)
                         e1.record()
                         e1.synchronize()
                         ts.append(e0.elapsed_time(e1))
@@ -423,10 +395,10 @@ class _BackboneBase(nn.Module):
                     if best is None or t < best[0]:
                         best = (t, v)
                 var = best[1]
-            elif so is not None:
+            elif epi == lib.EPI_SWIGLU and stats is not None:
                 var = 16
             self._tuned[key] = var
-        lib.call("toc3d_linear_chain", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *tail)
+        lib.call("toc3d_linear_lnfold", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *tail)
 
     def save_packed(self, path):
         """Write the packed device weights (what the kernels consume) to a safetensors file; see ``packed_io``."""
@@ -468,62 +440,43 @@ class _BackboneBase(nn.Module):
                      plan["col"], Kp, H, W, self.patch_size, s)
         else:
             lib.call("toc3d_im2col_patches", self._dt, img, plan["col"], Kp, V, self.in_chans, H, W, self.patch_size, s)
-        fout = (plan["xstats"], C // 128, plan["a"], C) if self.fold_norms else None      # block 0's norm1 is folded into its q|k|v GEMM
         self._linear(lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
-                     plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, None, plan["M"], C, Kp, 0, fout=fout)
-        plan["xa_valid"] = fout is not None
+                     plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, None, plan["M"], C, Kp, 0)
 
-    def _mlp(self, bp, plan, rows, res, rep_out, rep_index, produce_next=False):
-        """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C].
-        With fold_norms the caller's proj GEMM already left plan["a"] = activation copy of res and plan["xstats"]; produce_next:
-        the w3 epilogue leaves the same pair for the next block's norm1."""
+    def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
+        """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
         s = lib.stream_ptr()
         C, Hd = self.embed_dim, self.hidden_dim
         Hp = plan["hid"].shape[1]
         dt = self._dt
-        xs = C // 128
-        if self.fold_norms and plan["xa_valid"]:
-            w12, b12, fin12 = bp["w12g"], bp["c2_12"], (plan["xstats"], xs, bp["c1_12"], C, self.LN_EPS)
-        else:
-            lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
-            w12, b12, fin12 = bp["w12"], bp["b12"], None
-        fout3 = (plan["xstats"], xs, plan["a"], C) if (self.fold_norms and produce_next) else None
+        lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
         if self.fold_ffn_ln:
             # ffn_ln folded into w3 (eva_vit.py:48-49): the SwiGLU epilogue leaves per-row (sum, sum^2) slots, w3 multiplies the
             # un-normalised hidden by W3*gamma and applies rstd*(. - mean*c1) + c2 in its epilogue -- no pass over the hidden
             slots = (2 * Hp) // 128
-            self._linear(lib.EPI_SWIGLU, plan["a"], C, w12, C, b12, plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                         fin=fin12, fout=(plan["stats"], slots, None, 0))
+            self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
+                         stats=plan["stats"], stats_slots=slots)
             self._linear(lib.EPI_RESIDUAL, plan["hid"], Hp, bp["w3g"], bp["w3g"].shape[1], bp["c2"], res, C, res, C, 0,
-                         rep_out, rep_index, rows, C, Hp, 0, fin=(plan["stats"], slots, bp["c1"], Hd, self.LN_EPS), fout=fout3)
-        else:
-            self._linear(lib.EPI_SWIGLU, plan["a"], C, w12, C, b12, plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd, fin=fin12)
-            lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
-            self._linear(lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,
-                         rep_out, rep_index, rows, C, Hp, 0, fout=fout3)
-        plan["xa_valid"] = fout3 is not None
+                         rep_out, rep_index, rows, C, Hp, 0, stats=plan["stats"], stats_slots=slots, ln_c1=bp["c1"], ln_n=Hd, ln_eps=self.LN_EPS)
+            return
+        self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)
+        lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
+        self._linear(lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,
+                     rep_out, rep_index, rows, C, Hp, 0)
 
-    def _dense_block(self, i, plan, P, next_dense=False):
-        """Block.forward (eva_vit.py:247-268): LN -> window attention (pads folded analytically) -> +res; MLP -> +res.
-        next_dense: the following block is dense too, so this block's w3 epilogue prepares its folded norm1."""
+    def _dense_block(self, i, plan, P):
+        """Block.forward (eva_vit.py:247-268): LN -> window attention (pads folded analytically) -> +res; MLP -> +res."""
         s = lib.stream_ptr()
         bp = P["blocks"][i]
         C, M, dt = self.embed_dim, plan["M"], self._dt
         x = plan["x"]
         dm = plan["dense"][self._block_side(i)]
-        xs = C // 128
-        if self.fold_norms and plan["xa_valid"]:          # norm1 folded into q|k|v: plan["a"] / plan["xstats"] come from the previous GEMM
-            self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkvg"], C, bp["c2q"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
-                         fin=(plan["xstats"], xs, bp["c1q"], C, self.LN_EPS))
-        else:
-            lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
-            self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0)
+        lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
+        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0)
         lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None,
                  dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], bp["v_bias"], 64 ** -0.5, s)
-        fout = (plan["xstats"], xs, plan["a"], C) if self.fold_norms else None
-        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, None, M, C, C, 0, fout=fout)
-        plan["xa_valid"] = fout is not None
-        self._mlp(bp, plan, M, x, None, None, produce_next=next_dense)
+        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, None, M, C, C, 0)
+        self._mlp(bp, plan, M, x, None, None)
 
     # -- view groups: independent views (SURVEY.md 8e) processed concurrently on separate HIP streams ----------
     def _group_layout(self, V, B):
@@ -639,7 +592,7 @@ class EVA_ViT(_BackboneBase):
         for i in range(self.depth):
             for g, gp in enumerate(groups):
                 with torch.cuda.stream(streams[g]):
-                    self._dense_block(i, gp, P, next_dense=i + 1 < self.depth)
+                    self._dense_block(i, gp, P)
         self._join(streams)
         return {self._out_features[0]: self._feature_view(master)}
 
@@ -822,7 +775,6 @@ class ToC3DEVAViT(_BackboneBase):
     # -- scorer stage (toc3d_eva_vit.py:264-285) -------------------------------------------------------
     def _score_stage(self, st, plan, P, inputs, prev_exists, gumbel):
         s = lib.stream_ptr()
-        plan["xa_valid"] = False                                      # the first-frame scorer reuses plan["a"] as scratch
         q = P["scorers"][st]
         C, dt = self.embed_dim, self._dt
         V, T, M, B = plan["V"], plan["T"], plan["M"], plan["B"]
@@ -910,11 +862,9 @@ class ToC3DEVAViT(_BackboneBase):
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, rows, 3 * C, C, 0)
         lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"],
                  None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], None, 64 ** -0.5, s)
-        fout = (plan["xstats"], C // 128, plan["a"], C) if self.fold_norms else None       # norm2 folded into w1|w2
         self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0, plan["rep1"], sel["rep_index"],
-                     rows, C, C, 0, fout=fout)
-        plan["xa_valid"] = fout is not None
-        self._mlp(bp, plan, rows, slow, plan["rep2"], sel["rep_index"])        # leaves xa_valid False: the next block gathers / normalises itself
+                     rows, C, C, 0)
+        self._mlp(bp, plan, rows, slow, plan["rep2"], sel["rep_index"])
         lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"], s)
 
     @torch.no_grad()
@@ -970,8 +920,7 @@ class ToC3DEVAViT(_BackboneBase):
                     if self._accelerated(i):
                         self._accel_block(i, st, gp, P)
                     else:
-                        nd = i + 1 < self.depth and not self._accelerated(i + 1) and (i + 1) not in self.pruning_loc
-                        self._dense_block(i, gp, P, next_dense=nd)
+                        self._dense_block(i, gp, P)
         for g, gp in enumerate(groups):
             with torch.cuda.stream(streams[g]):
                 self._join_side(gp)

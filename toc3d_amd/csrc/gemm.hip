@@ -33,14 +33,10 @@ struct GemmArgs {
     int M, N, K, n_valid;
     int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
     int vec;                                             // epilogue may use 4-element vector accesses (alignment checked on the host)
-    // LayerNorm folded across two GEMMs:  W(LN(h)) = rstd*(h.(W*gamma)^T - mean*c1) + c2  with the row statistics of h produced by
-    // the epilogue of the GEMM that wrote h (SwiGLU.ffn_ln, eva_vit.py:48-49; Block.norm1 / norm2, eva_vit.py:249,263).
-    const float* stats_in;                               // consumer: [M, stats_in_slots, 2] per-row (sum h, sum h^2) partials
-    int stats_in_slots;
-    const float* ln_c1; int ln_n; float ln_eps;          // consumer: c1[n] = sum_k (W*gamma)[n,k]; statistics over ln_n columns
-    float* stats_out;                                    // producer: one (sum, sum^2) slot per row per N-tile of the values as stored
-    int stats_out_slots;
-    void* act_out; int64_t ld_act;                       // residual epilogue: activation-dtype copy of the new residual rows (the next GEMM's A)
+    // LayerNorm folded across two GEMMs (SwiGLU.ffn_ln, eva_vit.py:48-49):  w3(LN(h)) = rstd*(h.(W3*gamma)^T - mean*c1) + c2
+    float* stats;                                        // [M, stats_slots, 2] per-row (sum h, sum h^2) partials, one slot per N-tile
+    int stats_slots;
+    const float* ln_c1; int ln_n; float ln_eps;          // consumer side: c1[n] = sum_k (W3*gamma)[n,k]; statistics over ln_n columns
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -162,19 +158,18 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             __builtin_amdgcn_s_setprio(0);
         }
     };
-    // folded LayerNorm (consumer side): each of the first BM threads fetches one row's statistics now (the loads overlap the
-    // K loop) and publishes (mean, rstd) through the operand-tile LDS once the loop is done -- no LDS of its own
-    static_assert(BM <= NTHR, "one statistics row per thread");
-    float* s_ln = reinterpret_cast<float*>(smem);                         // [BM][2] mean, rstd, valid in the epilogue only
-    float my_mean = 0.f, my_rstd = 1.f;
-    if (a.ln_c1 && tid < BM) {
-        const int row = m0 + tid < a.M ? m0 + tid : a.M - 1;
-        const f32x2* st = reinterpret_cast<const f32x2*>(a.stats_in) + (int64_t)row * a.stats_in_slots;
-        float t1 = 0.f, t2 = 0.f;
-        for (int sl = 0; sl < a.stats_in_slots; ++sl) { const f32x2 v = st[sl]; t1 += v[0]; t2 += v[1]; }
-        my_mean = t1 / (float)a.ln_n;
-        const float var = fmaxf(__fmaf_rn(-my_mean, my_mean, t2 / (float)a.ln_n), 0.f);
-        my_rstd = 1.0f / sqrtf(var + a.ln_eps);
+    float* s_ln = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [BM][2] mean, rstd (only with a.ln_c1)
+    if (EPI == TOC3D_EPI_RESIDUAL && a.ln_c1) {
+        for (int rl = tid; rl < BM; rl += NTHR) {
+            const int row = m0 + rl < a.M ? m0 + rl : a.M - 1;
+            const f32x2* st = reinterpret_cast<const f32x2*>(a.stats) + (int64_t)row * a.stats_slots;
+            float t1 = 0.f, t2 = 0.f;
+            for (int sl = 0; sl < a.stats_slots; ++sl) { const f32x2 v = st[sl]; t1 += v[0]; t2 += v[1]; }
+            const float mean = t1 / (float)a.ln_n;
+            const float var = fmaxf(__fmaf_rn(-mean, mean, t2 / (float)a.ln_n), 0.f);
+            s_ln[2 * rl] = mean;
+            s_ln[2 * rl + 1] = 1.0f / sqrtf(var + a.ln_eps);
+        }                                                      // visible after the first barrier of the K loop
     }
     if (STAGES == 1) {
         // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
@@ -200,11 +195,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    if (a.ln_c1) {
-        __syncthreads();                                                  // every wave is done with the operand tiles
-        if (tid < BM) { s_ln[2 * tid] = my_mean; s_ln[2 * tid + 1] = my_rstd; }
-        __syncthreads();
-    }
     // ---- epilogue.  The MFMA is issued with the operands swapped (W fragment as A, activation fragment as B), so a lane
     // holds C[row = .. + r16][4 consecutive cols = .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of
     // 2- / 4-byte scattered ones.  a.vec (host-checked alignment / leading dims) enables the vector path. ----
@@ -225,18 +215,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                 if (pc < a.N && row < a.M) {
                     T hs[4];
                     float t1 = 0.f, t2 = 0.f;
-                    const int rl = wm * TM + i * 16 + r16;
-                    const float mean = a.ln_c1 ? s_ln[2 * rl] : 0.f, rstd = a.ln_c1 ? s_ln[2 * rl + 1] : 1.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x1, x2;
-                        if (a.ln_c1) {                      // norm2 folded into w1|w2 (explicit FMAs: identical bits for every tile variant)
-                            x1 = __fmaf_rn(rstd, __fmaf_rn(-mean, a.ln_c1[pc + r], acc[i][2 * jp][r]), a.bias[pc + r]);
-                            x2 = __fmaf_rn(rstd, __fmaf_rn(-mean, a.ln_c1[pc + 16 + r], acc[i][2 * jp + 1][r]), a.bias[pc + 16 + r]);
-                        } else {
-                            x1 = acc[i][2 * jp][r] + a.bias[pc + r];
-                            x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
-                        }
+                        const float x1 = acc[i][2 * jp][r] + a.bias[pc + r], x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
                         const float h = unit0 + r < a.n_valid ? silu(x1) * x2 : 0.f;
                         hs[r] = to_act<T>(h);
                         const float hf = from_act(hs[r]);
@@ -251,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                 }
             }
         }
-        if (a.stats_out) {
+        if (a.stats) {
             // deterministic row statistics for the LayerNorm folded into the next GEMM, one (sum, sum^2) slot per row per
             // N-tile.  Canonical order, independent of the wave grid: the 4 units of a lane in order, the 4 lane groups of a
             // 16-unit group (butterfly), groups in column order inside a wave, waves pairwise -- every 128-wide variant
@@ -272,13 +253,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                     f32x2 t = sred[rl];
                     if (WN == 2) t += sred[BM + rl];
                     if (WN == 4) t = (t + sred[BM + rl]) + (sred[2 * BM + rl] + sred[3 * BM + rl]);
-                    *reinterpret_cast<f32x2*>(a.stats_out + ((int64_t)row * a.stats_out_slots + n0 / BN) * 2) = t;
+                    *reinterpret_cast<f32x2*>(a.stats + ((int64_t)row * a.stats_slots + n0 / BN) * 2) = t;
                 }
             }
         }
         return;
     }
-    const bool fold = a.ln_c1 != nullptr;
+    const bool fold = EPI == TOC3D_EPI_RESIDUAL && a.ln_c1 != nullptr;
     float bcol[NT][4], c1col[NT][4];
     int nok[NT];                                         // valid columns among the lane's 4 (0..4)
 #pragma unroll
@@ -291,61 +272,36 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             c1col[j][r] = (fold && r < nok[j]) ? a.ln_c1[col + r] : 0.f;
         }
     }
-    float p1[MT][NT], p2[MT][NT];                        // producer: per-row partial (sum, sum^2) of the lane's 4 columns per 16-column group
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) { p1[i][j] = 0.f; p2[i][j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int row = m0 + wm * TM + i * 16 + r16;
         if (row >= a.M) continue;
-        const int rl = wm * TM + i * 16 + r16;
-        const float mean = fold ? s_ln[2 * rl] : 0.f, rstd = fold ? s_ln[2 * rl + 1] : 1.f;
         if (EPI == TOC3D_EPI_RESIDUAL) {
             // the modular residual row and the representative-row test cost an integer division / a load each: once per row
             const int rr = a.res_mod > 0 ? row % a.res_mod : row;
             const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
             float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
-            T* arow = a.act_out ? reinterpret_cast<T*>(a.act_out) + (int64_t)row * a.ld_act : nullptr;
             float* reprow = nullptr;
             if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
+            const int rl = wm * TM + i * 16 + r16;
+            const float mean = fold ? s_ln[2 * rl] : 0.f, rstd = fold ? s_ln[2 * rl + 1] : 1.f;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if (nok[j] == 0) continue;
                 const int col = n0 + wn * TN + j * 16 + g * 4;
-                float raw[4], nv[4];
+                float raw[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)      // explicit FMAs: the rounding must not depend on how a tile variant's code gets contracted
                     raw[r] = fold ? __fmaf_rn(rstd, __fmaf_rn(-mean, c1col[j][r], acc[i][j][r]), bcol[j][r]) : acc[i][j][r] + bcol[j][r];
                 if (a.vec && nok[j] == 4) {
                     f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) nv[r] = rv[r] + raw[r];
-                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{nv[0], nv[1], nv[2], nv[3]};
+                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{rv[0] + raw[0], rv[1] + raw[1], rv[2] + raw[2], rv[3] + raw[3]};
                     if (reprow) *reinterpret_cast<f32x4*>(reprow + col) = f32x4{raw[0], raw[1], raw[2], raw[3]};
                 } else {
-                    for (int r = 0; r < 4; ++r) nv[r] = 0.f;
                     for (int r = 0; r < nok[j]; ++r) {
-                        nv[r] = (resrow ? resrow[col + r] : 0.f) + raw[r];
-                        orow[col + r] = nv[r];
+                        orow[col + r] = (resrow ? resrow[col + r] : 0.f) + raw[r];
                         if (reprow) reprow[col + r] = raw[r];
                     }
-                }
-                if (arow) {                      // producer for the LayerNorm folded into the next GEMM: its A operand and its row statistics
-                    T a4[4];
-                    float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        a4[r] = to_act<T>(nv[r]);
-                        const float hf = r < nok[j] ? from_act(a4[r]) : 0.f;
-                        t1 += hf;
-                        t2 = __fmaf_rn(hf, hf, t2);
-                    }
-                    p1[i][j] = t1;
-                    p2[i][j] = t2;
-                    if (a.vec && nok[j] == 4) store4(arow + col, a4);
-                    else for (int r = 0; r < nok[j]; ++r) arow[col + r] = a4[r];
                 }
             }
         } else {
@@ -357,38 +313,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                 T o4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float raw = fold ? __fmaf_rn(rstd, __fmaf_rn(-mean, c1col[j][r], acc[i][j][r]), bcol[j][r]) : acc[i][j][r] + bcol[j][r];
+                    const float raw = acc[i][j][r] + bcol[j][r];
                     o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
                 }
                 if (a.vec && nok[j] == 4) store4(orow + col, o4);
                 else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
-            }
-        }
-    }
-    if (EPI == TOC3D_EPI_RESIDUAL && a.stats_out) {
-        // canonical order, independent of the wave grid: lane (4 columns in order), the 4 lane groups of a 16-column group
-        // (butterfly), then a balanced binary tree over the tile's eight 16-column groups (inside a wave, then across waves)
-        f32x2* sred = reinterpret_cast<f32x2*>(smem);             // [WN][BM]
-        __syncthreads();                                           // every wave is done with the operand tiles (and with s_ln)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            float u1[NT], u2[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) { u1[j] = g4_sum(p1[i][j]); u2[j] = g4_sum(p2[i][j]); }
-#pragma unroll
-            for (int w = 1; w < NT; w <<= 1)                      // balanced tree over the 16-column groups (NT is a power of two)
-#pragma unroll
-                for (int j = 0; j + w < NT; j += 2 * w) { u1[j] += u1[j + w]; u2[j] += u2[j + w]; }
-            if (g == 0) sred[wn * BM + wm * TM + i * 16 + r16] = f32x2{u1[0], u2[0]};
-        }
-        __syncthreads();
-        for (int rl = tid; rl < BM; rl += NTHR) {
-            const int row = m0 + rl;
-            if (row < a.M) {
-                f32x2 t = sred[rl];
-                if (WN == 2) t += sred[BM + rl];
-                if (WN == 4) t = (t + sred[BM + rl]) + (sred[2 * BM + rl] + sred[3 * BM + rl]);
-                *reinterpret_cast<f32x2*>(a.stats_out + ((int64_t)row * a.stats_out_slots + n0 / BN) * 2) = t;
             }
         }
     }
@@ -399,7 +328,7 @@ thread_local bool g_bad_variant = false;               // variant cannot serve t
 
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = STAGES * (BM + BN) * RB;
+    constexpr int lds = STAGES * (BM + BN) * RB + (EPI == TOC3D_EPI_RESIDUAL ? BM * 8 : 0);
     static bool attr_set = false;      // > 64 KiB of dynamic LDS: raise the per-kernel limit once
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -408,7 +337,7 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
     if (EPI == TOC3D_EPI_SWIGLU && (BN / WN) % 32 != 0) { g_bad_variant = true; return; }   // a wave must own whole (w1, w2) 32-column groups
     if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
     const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
-    if (a.stats_out && (tn != a.stats_out_slots || BN != 128)) { g_slot_mismatch = true; return; }      // one slot per 128-wide N-tile
+    if (EPI == TOC3D_EPI_SWIGLU && a.stats && tn != a.stats_slots) { g_slot_mismatch = true; return; }
     const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
     hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
 }
@@ -626,23 +555,17 @@ int toc3d_im2col_patches_u8(int dtype, const uint8_t* img, int64_t V, int64_t H,
     return TOC3D_OK;
 }
 
-int toc3d_linear_chain(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                       void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                       float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                       const float* stats_in, int64_t stats_in_slots, const float* ln_c1, int64_t ln_n, float ln_eps,
-                       float* stats_out, int64_t stats_out_slots, void* act_out, int64_t ld_act, toc3d_stream_t stream) {
-    if (ln_c1) {
-        TOC3D_REQUIRE(stats_in && stats_in_slots > 0 && ln_n > 0, "toc3d_linear_chain: ln_c1 needs stats_in, stats_in_slots and ln_n (the folded LayerNorm's row statistics)");
+int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                        void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                        float* row_stats, int64_t stats_slots, const float* ln_c1, int64_t ln_n, float ln_eps,
+                        toc3d_stream_t stream) {
+    if (row_stats) {
+        TOC3D_REQUIRE(stats_slots > 0, "toc3d_linear_lnfold: stats_slots must be positive");
+        TOC3D_REQUIRE(epilogue == TOC3D_EPI_SWIGLU || (epilogue == TOC3D_EPI_RESIDUAL && ln_c1 && ln_n > 0),
+                      "toc3d_linear_lnfold: row_stats is produced by SWIGLU and consumed by RESIDUAL (+ ln_c1, ln_n)");
     } else {
-        TOC3D_REQUIRE(!stats_in, "toc3d_linear_chain: stats_in without ln_c1");
-    }
-    if (stats_out) {
-        TOC3D_REQUIRE(stats_out_slots > 0 && (epilogue == TOC3D_EPI_SWIGLU || (epilogue == TOC3D_EPI_RESIDUAL && act_out)),
-                      "toc3d_linear_chain: stats_out is produced by the SWIGLU epilogue (hidden) or the RESIDUAL epilogue together with act_out");
-        TOC3D_REQUIRE(epilogue == TOC3D_EPI_SWIGLU || N % 128 == 0, "toc3d_linear_chain: residual-row statistics need N to be a multiple of 128");
-    }
-    if (act_out) {
-        TOC3D_REQUIRE(epilogue == TOC3D_EPI_RESIDUAL && ld_act >= N, "toc3d_linear_chain: act_out belongs to the RESIDUAL epilogue, ld_act >= N");
+        TOC3D_REQUIRE(!ln_c1, "toc3d_linear_lnfold: ln_c1 without row_stats");
     }
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
@@ -667,37 +590,17 @@ int toc3d_linear_chain(int dtype, int epilogue, int variant, const void* A, int6
     // 4-wide epilogue accesses: every row start and column group must be 16-byte aligned in its own element size
     const int64_t osz = epilogue == TOC3D_EPI_RESIDUAL ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
     const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * osz) == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
-                     (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0)) &&
-                     (!act_out || (ld_act % 4 == 0 && (uintptr_t)act_out % 16 == 0));
+                     (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0));
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
-               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, stats_in, (int)stats_in_slots, ln_c1, (int)ln_n, ln_eps,
-               stats_out, (int)stats_out_slots, act_out, ld_act};
+               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, row_stats, (int)stats_slots, ln_c1, (int)ln_n, ln_eps};
     g_slot_mismatch = false;
     g_bad_variant = false;
     int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
     if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab < 32)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
-    if (g_slot_mismatch) { toc3d_set_error("toc3d_linear_chain: variant %d does not have stats_out_slots=%lld 128-wide N-tiles", variant, (long long)stats_out_slots); return TOC3D_ERR_ARG; }
+    if (g_slot_mismatch) { toc3d_set_error("toc3d_linear_lnfold: variant %d has %s N-tiles than stats_slots=%lld", variant, "a different number of", (long long)stats_slots); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
     return TOC3D_OK;
-}
-
-int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                        void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                        float* row_stats, int64_t stats_slots, const float* ln_c1, int64_t ln_n, float ln_eps,
-                        toc3d_stream_t stream) {
-    if (row_stats) {
-        TOC3D_REQUIRE(stats_slots > 0, "toc3d_linear_lnfold: stats_slots must be positive");
-        TOC3D_REQUIRE(epilogue == TOC3D_EPI_SWIGLU || (epilogue == TOC3D_EPI_RESIDUAL && ln_c1 && ln_n > 0),
-                      "toc3d_linear_lnfold: row_stats is produced by SWIGLU and consumed by RESIDUAL (+ ln_c1, ln_n)");
-    } else {
-        TOC3D_REQUIRE(!ln_c1, "toc3d_linear_lnfold: ln_c1 without row_stats");
-    }
-    const bool producer = epilogue == TOC3D_EPI_SWIGLU;
-    return toc3d_linear_chain(dtype, epilogue, variant, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index, M, N, K,
-                              n_valid, producer ? nullptr : row_stats, producer ? 0 : stats_slots, ln_c1, ln_n, ln_eps,
-                              producer ? row_stats : nullptr, producer ? stats_slots : 0, nullptr, 0, stream);
 }
 
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

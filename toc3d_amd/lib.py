@@ -23,7 +23,6 @@ _SIGS = {
     "toc3d_linear": "iiplplpplpllppllllp",
     "toc3d_linear_ex": "iiiplplpplpllppllllp",
     "toc3d_linear_lnfold": "iiiplplpplpllppllllplplfp",
-    "toc3d_linear_chain": "iiiplplpplpllppllllplplfplplp",
     "toc3d_pack_weight": "ipllpllp",
     "toc3d_pack_swiglu": "ippppllppllp",
     "toc3d_im2col_patches": "ippllllllp",

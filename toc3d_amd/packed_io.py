@@ -58,7 +58,7 @@ def fingerprint(model) -> Dict[str, Any]:
     fp = dict(cls=type(model).__name__, precision=model.precision, embed_dim=model.embed_dim, depth=model.depth, num_heads=model.num_heads,
               hidden_dim=model.hidden_dim, patch_size=model.patch_size, window_size=model.window_size,
               global_window_size=model.global_window_size, global_attn_indexes=list(model.global_attn_indexes),
-              fold_ffn_ln=bool(model.fold_ffn_ln), fold_norms=bool(model.fold_norms), abi=int(lib.load().toc3d_abi_version()))
+              fold_ffn_ln=bool(model.fold_ffn_ln), abi=int(lib.load().toc3d_abi_version()))
     for k in ("pruning_loc", "token_ratio", "pruning_num_queries", "accelerate_global"):
         if hasattr(model, k):
             v = getattr(model, k)

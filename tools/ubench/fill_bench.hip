@@ -13,7 +13,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int WAVES, int PF = 0>
+template <int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k(const char* __restrict__ A, const char* __restrict__ B, int64_t ld, int nk, int tiles_n, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 128, BN = 128, RB = 128, NTHR = 64 * WAVES;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(const char* __restrict__ A, cons
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        if (MODE >= 1 && PF == 0) {
+        if (MODE >= 1) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 fa[MT], fb[NT];
@@ -60,24 +60,6 @@ __global__ __launch_bounds__(64 * WAVES) void k(const char* __restrict__ A, cons
                 }
             }
         }
-        if (MODE >= 2 && PF == 1) {
-            // all fragments of the K-tile first (both 32-wide substeps), then the MFMAs: one LDS round trip per K-tile
-            bf16x8 fa[2][MT], fb[2][NT];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) { const int r = wm * TM + i * 16 + r16; fa[s][i] = *reinterpret_cast<const bf16x8*>(smem + r * RB + (((s * 4 + g) ^ (r & 7)) << 4)); }
-#pragma unroll
-                for (int j = 0; j < NT; ++j) { const int r = wn * TN + j * 16 + r16; fb[s][j] = *reinterpret_cast<const bf16x8*>(smem + BM * RB + r * RB + (((s * 4 + g) ^ (r & 7)) << 4)); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
-        }
         if (MODE != 3) __builtin_amdgcn_s_barrier();
     }
     float t = 0;
@@ -85,16 +67,16 @@ __global__ __launch_bounds__(64 * WAVES) void k(const char* __restrict__ A, cons
     if (t == 123.456f) sink[0] = t;
 }
 
-template <int MODE, int WAVES, int PF = 0>
+template <int MODE, int WAVES>
 void run(const char* name, const char* A, const char* B, int M, int N, int K, int pad_lds, float* sink) {
     const int tm = M / 128, tn = N / 128, nk = K * 2 / 128;
     const size_t lds = 32768 + pad_lds;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, WAVES, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k<MODE, WAVES, PF>), dim3(tm * tn), dim3(64 * WAVES), lds, 0, A, B, (int64_t)K * 2, nk, tn, sink);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k<MODE, WAVES>), dim3(tm * tn), dim3(64 * WAVES), lds, 0, A, B, (int64_t)K * 2, nk, tn, sink);
     hipEventRecord(e0);
     const int R = 10;
-    for (int r = 0; r < R; ++r) hipLaunchKernelGGL((k<MODE, WAVES, PF>), dim3(tm * tn), dim3(64 * WAVES), lds, 0, A, B, (int64_t)K * 2, nk, tn, sink);
+    for (int r = 0; r < R; ++r) hipLaunchKernelGGL((k<MODE, WAVES>), dim3(tm * tn), dim3(64 * WAVES), lds, 0, A, B, (int64_t)K * 2, nk, tn, sink);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= R;
     const double bytes = (double)tm * tn * nk * 32768.0, flops = 2.0 * M * N * K;
@@ -107,14 +89,12 @@ int main() {
     char *A, *B; float* sink;
     hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&sink, 4);
     hipMemset(A, 0, (size_t)M * K * 2); hipMemset(B, 0, (size_t)N * K * 2);
-    for (int pad : {0, 8192}) {
+    for (int pad : {0, 8192, 22000, 50000, 130000}) {
         printf("--- LDS per WG %d B (%d WG/CU by LDS)\n", 32768 + pad, 163840 / (32768 + pad));
         run<0, 8>("fill only", A, B, M, N, K, pad, sink);
         run<1, 8>("fill + ds_read", A, B, M, N, K, pad, sink);
         run<2, 8>("fill + ds_read + mfma", A, B, M, N, K, pad, sink);
         run<3, 8>("ds_read + mfma (no fill)", A, B, M, N, K, pad, sink);
-        run<2, 8, 1>("fill + all reads, then mfma", A, B, M, N, K, pad, sink);
-        run<3, 8, 1>("all reads, then mfma (no fill)", A, B, M, N, K, pad, sink);
         run<2, 4>("fill + ds_read + mfma", A, B, M, N, K, pad, sink);
         run<3, 4>("ds_read + mfma (no fill)", A, B, M, N, K, pad, sink);
     }
