@@ -368,7 +368,7 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 13: launch_cfg<T, EPI, 128, 64, 1>(a, s); break;
         case 14: launch_cfg<T, EPI, 64, 64, 2>(a, s); break;
         case 15: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 2, 4>(a, s); break;      // v8 forced to <= 128 registers: 4 workgroups / CU
-        case 16: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, 1>(a, s); break;      // 8 waves, 64x32 per wave
+        case 16: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 6 : 1)>(a, s); break;   // 8 waves, 64x32 per wave; bf16 held to 80 registers (6 waves / SIMD = 3 workgroups / CU; the SwiGLU epilogue would take 82)
         case 17: launch_cfg<T, EPI, 128, 128, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, double buffered (64 KiB)
         case 18: launch_cfg<T, EPI, 256, 128, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128 tile, double buffered (96 KiB)
         case 19: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128, single buffer (48 KiB)
