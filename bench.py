@@ -189,7 +189,7 @@ def main():
             e0.record()
             orig_call(name, *a)
             e1.record()
-            if name in ("toc3d_linear_ex", "toc3d_linear_lnfold"):
+            if name == "toc3d_linear_ex":
                 tag = f"[epi{a[1]} v{a[2]} M={a[15]} N={a[16]} K={a[17]}]"
             elif name == "toc3d_linear":
                 tag = f"[epi{a[1]} M={a[14]} N={a[15]} K={a[16]}]"

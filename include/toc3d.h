@@ -85,19 +85,6 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
                     float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                     toc3d_stream_t stream);
 
-/* LayerNorm folded across two GEMMs -- SwiGLU.ffn_ln (eva_vit.py:48-49) without a pass over the hidden:
- *     w3(LN(h)) = rstd * (h . (W3*gamma)^T - mean * c1) + c2,   c1[n] = sum_k (W3*gamma)[n,k],  c2 = W3.beta + b3
- * Producer (epilogue SWIGLU, row_stats != NULL): also writes per-row (sum h, sum h^2) of the stored hidden, one float2 slot per
- * row per N-tile: row_stats [M, stats_slots, 2]; the variant's tile width must give exactly stats_slots N-tiles (128-wide
- * tiles: stats_slots = N/128), else an error is returned.  Reduction order is fixed (deterministic).
- * Consumer (epilogue RESIDUAL, row_stats + ln_c1): A = the un-normalised hidden, W = packed (W3*gamma), bias = c2; mean /
- * rstd over ln_n columns from the slots; out = residual + rstd*(A.W^T - mean*c1) + c2 (rep capture stores that branch value).
- * With row_stats == NULL this is toc3d_linear_ex. */
-int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
-                        const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                        float* row_stats, int64_t stats_slots, const float* ln_c1, int64_t ln_n, float ln_eps,
-                        toc3d_stream_t stream);
 
 /* f32 [N, K] state-dict weight -> act [Np, Kp], zero padded (Np multiple of 128, Kp multiple of 64). */
 int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out, int64_t Np, int64_t Kp, toc3d_stream_t stream);

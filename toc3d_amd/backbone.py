@@ -19,6 +19,7 @@ Extra forward kwarg: ``gumbel_noise`` (list of 3 tensors (B*Nv, T, 2)) to make t
 from __future__ import annotations
 
 import math
+import os
 from functools import partial
 from typing import Dict, List, Optional
 
@@ -195,7 +196,6 @@ class _BackboneBase(nn.Module):
         self.alias_outputs = False      # True: returned tensors alias the reused workspace (benchmarks)
         self._side = None               # side stream: query-side scorer prep / image-level ranking overlap the blocks
         self.view_groups = 1            # > 1: split the views into groups that run concurrently on separate streams
-        self.fold_ffn_ln = precision == "bf16"   # strict-parity path keeps the two-pass LayerNorm kernel
         self._gstreams = []
 
     # -- state-dict hook: re-pack after new weights arrive ------------------------------------------
@@ -257,11 +257,6 @@ class _BackboneBase(nn.Module):
                      self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
             p["w12"], p["b12"] = w12, b12
             p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
-            if self.fold_ffn_ln:
-                w3f = m.w3.weight.detach().float()
-                p["w3g"] = self._pack_linear(w3f * m.ffn_ln.weight.detach().float()[None, :])
-                p["c1"] = p["w3g"][:C, :Hd].float().sum(dim=1).contiguous()            # of the *rounded* weights: a constant row cancels exactly
-                p["c2"] = (w3f @ m.ffn_ln.bias.detach().float() + m.w3.bias.detach().float()).contiguous()
             for n, mod in (("ln1", blk.norm1), ("ln2", blk.norm2), ("lnf", m.ffn_ln)):
                 p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
             p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
@@ -338,7 +333,6 @@ class _BackboneBase(nn.Module):
                     att=torch.empty(R, C, dtype=tdt, device=dev),
                     hid=torch.zeros(R, Hp, dtype=tdt, device=dev),
                     hln=torch.zeros(R, Hp, dtype=tdt, device=dev),
-                    stats=torch.empty(R, (2 * Hp) // 128, 2, dtype=torch.float32, device=dev),
                     col=torch.zeros(M, _round_up(Kc, 64), dtype=tdt, device=dev),
                     Kc=Kc)
         plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
@@ -349,18 +343,13 @@ class _BackboneBase(nn.Module):
     _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 110, 114, 116, 117, 126),
                  lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
-    # tile variants whose N-tile is 128 wide (the SwiGLU row-statistics slots of the folded ffn_ln assume that width)
-    _BN128 = (1, 8, 10, 15, 16, 17, 22, 24, 26, 28, 29, 110, 117, 126)
-
-    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid,
-                stats=None, stats_slots=0, ln_c1=None, ln_n=0, ln_eps=0.0):
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
         """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
         real operands the first time the shape is seen (never during hipGraph capture: shapes are warmed up eagerly).
         All variants accumulate K in the same order, so the choice does not change results."""
-        key = (epi, M, N, K, stats is not None)
+        key = (epi, M, N, K)
         var = self._tuned.get(key)
         s = lib.stream_ptr()
-        tail = (stats, stats_slots, ln_c1, ln_n, float(ln_eps), s)
         if var is None:
             var = 0
             if self.autotune and not torch.cuda.is_current_stream_capturing():
@@ -368,10 +357,7 @@ class _BackboneBase(nn.Module):
                 if epi == lib.EPI_RESIDUAL:                 # in-place residual add: tune into scratch
                     o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
                 rep_s = torch.empty_like(rep_out) if rep_out is not None else None
-                best = None
                 cands = self._VARIANTS[self._dt]
-                if epi == lib.EPI_SWIGLU and stats is not None:
-                    cands = [v for v in cands if v in self._BN128]
                 if epi == lib.EPI_SWIGLU:
                     cands = [v for v in cands if v != 33]          # 16-column wave slabs cannot pair w1 / w2 columns
                 # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
@@ -379,26 +365,26 @@ class _BackboneBase(nn.Module):
                 # tuner prefers shallow pipelines that lose in place (tools/ubench/n1024_all_variants.py).
                 if _BackboneBase._flush is None or _BackboneBase._flush.device != out.device:
                     _BackboneBase._flush = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=out.device)
-                for v in cands:
-                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid) + tail
-                    lib.call("toc3d_linear_lnfold", *args)
+
+                def cold_time(v, reps):
+                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, s)
+                    lib.call("toc3d_linear_ex", *args)
                     ts = []
-                    for _ in range(3):
+                    for _ in range(reps):
                         _BackboneBase._flush.zero_()
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        lib.call("toc3d_linear_lnfold", *args)
+                        lib.call("toc3d_linear_ex", *args)
                         e1.record()
                         e1.synchronize()
                         ts.append(e0.elapsed_time(e1))
-                    t = sorted(ts)[1]
-                    if best is None or t < best[0]:
-                        best = (t, v)
-                var = best[1]
-            elif epi == lib.EPI_SWIGLU and stats is not None:
-                var = 16
+                    return min(ts)
+                # two passes: a quick one over every candidate, then the four best again with more samples (single cold launches
+                # are noisy, and a wrong pick costs 10-20 % on that shape for the lifetime of the model)
+                short = sorted((cold_time(v, 3), v) for v in cands)[:4]
+                var = min((cold_time(v, 9), v) for _, v in short)[1]
             self._tuned[key] = var
-        lib.call("toc3d_linear_lnfold", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *tail)
+        lib.call("toc3d_linear_ex", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, s)
 
     def save_packed(self, path):
         """Write the packed device weights (what the kernels consume) to a safetensors file; see ``packed_io``."""
@@ -450,15 +436,6 @@ class _BackboneBase(nn.Module):
         Hp = plan["hid"].shape[1]
         dt = self._dt
         lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
-        if self.fold_ffn_ln:
-            # ffn_ln folded into w3 (eva_vit.py:48-49): the SwiGLU epilogue leaves per-row (sum, sum^2) slots, w3 multiplies the
-            # un-normalised hidden by W3*gamma and applies rstd*(. - mean*c1) + c2 in its epilogue -- no pass over the hidden
-            slots = (2 * Hp) // 128
-            self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                         stats=plan["stats"], stats_slots=slots)
-            self._linear(lib.EPI_RESIDUAL, plan["hid"], Hp, bp["w3g"], bp["w3g"].shape[1], bp["c2"], res, C, res, C, 0,
-                         rep_out, rep_index, rows, C, Hp, 0, stats=plan["stats"], stats_slots=slots, ln_c1=bp["c1"], ln_n=Hd, ln_eps=self.LN_EPS)
-            return
         self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)
         lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
         self._linear(lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,

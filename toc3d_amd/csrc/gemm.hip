@@ -33,10 +33,6 @@ struct GemmArgs {
     int M, N, K, n_valid;
     int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
     int vec;                                             // epilogue may use 4-element vector accesses (alignment checked on the host)
-    // LayerNorm folded across two GEMMs (SwiGLU.ffn_ln, eva_vit.py:48-49):  w3(LN(h)) = rstd*(h.(W3*gamma)^T - mean*c1) + c2
-    float* stats;                                        // [M, stats_slots, 2] per-row (sum h, sum h^2) partials, one slot per N-tile
-    int stats_slots;
-    const float* ln_c1; int ln_n; float ln_eps;          // consumer side: c1[n] = sum_k (W3*gamma)[n,k]; statistics over ln_n columns
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -158,19 +154,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             __builtin_amdgcn_s_setprio(0);
         }
     };
-    float* s_ln = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);   // [BM][2] mean, rstd (only with a.ln_c1)
-    if (EPI == TOC3D_EPI_RESIDUAL && a.ln_c1) {
-        for (int rl = tid; rl < BM; rl += NTHR) {
-            const int row = m0 + rl < a.M ? m0 + rl : a.M - 1;
-            const f32x2* st = reinterpret_cast<const f32x2*>(a.stats) + (int64_t)row * a.stats_slots;
-            float t1 = 0.f, t2 = 0.f;
-            for (int sl = 0; sl < a.stats_slots; ++sl) { const f32x2 v = st[sl]; t1 += v[0]; t2 += v[1]; }
-            const float mean = t1 / (float)a.ln_n;
-            const float var = fmaxf(__fmaf_rn(-mean, mean, t2 / (float)a.ln_n), 0.f);
-            s_ln[2 * rl] = mean;
-            s_ln[2 * rl + 1] = 1.0f / sqrtf(var + a.ln_eps);
-        }                                                      // visible after the first barrier of the K loop
-    }
     if (STAGES == 1) {
         // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
         for (int kt = 0; kt < nk; ++kt) {
@@ -201,76 +184,36 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     if (EPI == TOC3D_EPI_SWIGLU) {
         // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
         T* out = reinterpret_cast<T*>(a.out);
-        constexpr int NG = NT / 2 > 0 ? NT / 2 : 1;      // 16-unit groups per wave
-        float s1[MT][NG], s2[MT][NG];                    // per-row, per-group partial (sum, sum of squares) of the hidden, as stored
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = m0 + wm * TM + i * 16 + r16;
-#pragma unroll
-            for (int jp = 0; jp < NG; ++jp) { s1[i][jp] = 0.f; s2[i][jp] = 0.f; }
 #pragma unroll
             for (int jp = 0; jp < NT / 2; ++jp) {
                 const int pc = n0 + wn * TN + jp * 32 + g * 4;    // packed col of the w1 half, first of 4
                 const int unit0 = (pc >> 5) * 16 + g * 4;
                 if (pc < a.N && row < a.M) {
                     T hs[4];
-                    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x1 = acc[i][2 * jp][r] + a.bias[pc + r], x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
-                        const float h = unit0 + r < a.n_valid ? silu(x1) * x2 : 0.f;
-                        hs[r] = to_act<T>(h);
-                        const float hf = from_act(hs[r]);
-                        t1 += hf;
-                        t2 = __fmaf_rn(hf, hf, t2);
+                        hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu(x1) * x2 : 0.f);
                     }
-                    s1[i][jp] = t1;
-                    s2[i][jp] = t2;
                     T* dst = out + (int64_t)row * a.ldo + unit0;
                     if (a.vec) store4(dst, hs);
                     else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
                 }
             }
         }
-        if (a.stats) {
-            // deterministic row statistics for the LayerNorm folded into the next GEMM, one (sum, sum^2) slot per row per
-            // N-tile.  Canonical order, independent of the wave grid: the 4 units of a lane in order, the 4 lane groups of a
-            // 16-unit group (butterfly), groups in column order inside a wave, waves pairwise -- every 128-wide variant
-            // therefore produces the same bits.
-            f32x2* sred = reinterpret_cast<f32x2*>(smem);             // [WN][BM]
-            __syncthreads();                                           // every wave is done with the operand tiles
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                float t1 = g4_sum(s1[i][0]), t2 = g4_sum(s2[i][0]);
-#pragma unroll
-                for (int jp = 1; jp < NG; ++jp) { t1 += g4_sum(s1[i][jp]); t2 += g4_sum(s2[i][jp]); }
-                if (g == 0) sred[wn * BM + wm * TM + i * 16 + r16] = f32x2{t1, t2};
-            }
-            __syncthreads();
-            for (int rl = tid; rl < BM; rl += NTHR) {
-                const int row = m0 + rl;
-                if (row < a.M) {
-                    f32x2 t = sred[rl];
-                    if (WN == 2) t += sred[BM + rl];
-                    if (WN == 4) t = (t + sred[BM + rl]) + (sred[2 * BM + rl] + sred[3 * BM + rl]);
-                    *reinterpret_cast<f32x2*>(a.stats + ((int64_t)row * a.stats_slots + n0 / BN) * 2) = t;
-                }
-            }
-        }
         return;
     }
-    const bool fold = EPI == TOC3D_EPI_RESIDUAL && a.ln_c1 != nullptr;
-    float bcol[NT][4], c1col[NT][4];
+    float bcol[NT][4];
     int nok[NT];                                         // valid columns among the lane's 4 (0..4)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int col = n0 + wn * TN + j * 16 + g * 4;
         nok[j] = a.N - col < 0 ? 0 : (a.N - col > 4 ? 4 : a.N - col);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
-            c1col[j][r] = (fold && r < nok[j]) ? a.ln_c1[col + r] : 0.f;
-        }
+        for (int r = 0; r < 4; ++r) bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -283,16 +226,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
             float* reprow = nullptr;
             if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
-            const int rl = wm * TM + i * 16 + r16;
-            const float mean = fold ? s_ln[2 * rl] : 0.f, rstd = fold ? s_ln[2 * rl + 1] : 1.f;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if (nok[j] == 0) continue;
                 const int col = n0 + wn * TN + j * 16 + g * 4;
                 float raw[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)      // explicit FMAs: the rounding must not depend on how a tile variant's code gets contracted
-                    raw[r] = fold ? __fmaf_rn(rstd, __fmaf_rn(-mean, c1col[j][r], acc[i][j][r]), bcol[j][r]) : acc[i][j][r] + bcol[j][r];
+                for (int r = 0; r < 4; ++r) raw[r] = acc[i][j][r] + bcol[j][r];
                 if (a.vec && nok[j] == 4) {
                     f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(orow + col) = f32x4{rv[0] + raw[0], rv[1] + raw[1], rv[2] + raw[2], rv[3] + raw[3]};
@@ -323,12 +263,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     }
 }
 
-thread_local bool g_slot_mismatch = false;             // SwiGLU statistics: the chosen tile width must match stats_slots
 thread_local bool g_bad_variant = false;               // variant cannot serve the requested epilogue
 
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = STAGES * (BM + BN) * RB + (EPI == TOC3D_EPI_RESIDUAL ? BM * 8 : 0);
+    constexpr int lds = STAGES * (BM + BN) * RB;
     static bool attr_set = false;      // > 64 KiB of dynamic LDS: raise the per-kernel limit once
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -337,7 +276,6 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
     if (EPI == TOC3D_EPI_SWIGLU && (BN / WN) % 32 != 0) { g_bad_variant = true; return; }   // a wave must own whole (w1, w2) 32-column groups
     if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
     const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
-    if (EPI == TOC3D_EPI_SWIGLU && a.stats && tn != a.stats_slots) { g_slot_mismatch = true; return; }
     const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
     hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
 }
@@ -555,18 +493,10 @@ int toc3d_im2col_patches_u8(int dtype, const uint8_t* img, int64_t V, int64_t H,
     return TOC3D_OK;
 }
 
-int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                        void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                        float* row_stats, int64_t stats_slots, const float* ln_c1, int64_t ln_n, float ln_eps,
-                        toc3d_stream_t stream) {
-    if (row_stats) {
-        TOC3D_REQUIRE(stats_slots > 0, "toc3d_linear_lnfold: stats_slots must be positive");
-        TOC3D_REQUIRE(epilogue == TOC3D_EPI_SWIGLU || (epilogue == TOC3D_EPI_RESIDUAL && ln_c1 && ln_n > 0),
-                      "toc3d_linear_lnfold: row_stats is produced by SWIGLU and consumed by RESIDUAL (+ ln_c1, ln_n)");
-    } else {
-        TOC3D_REQUIRE(!ln_c1, "toc3d_linear_lnfold: ln_c1 without row_stats");
-    }
+int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                    void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                    float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                    toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && K > 0, "toc3d_linear: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -592,23 +522,13 @@ int toc3d_linear_lnfold(int dtype, int epilogue, int variant, const void* A, int
     const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * osz) == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
                      (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0));
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
-               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, row_stats, (int)stats_slots, ln_c1, (int)ln_n, ln_eps};
-    g_slot_mismatch = false;
+               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0};
     g_bad_variant = false;
     int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
     if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab < 32)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
-    if (g_slot_mismatch) { toc3d_set_error("toc3d_linear_lnfold: variant %d has %s N-tiles than stats_slots=%lld", variant, "a different number of", (long long)stats_slots); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
     return TOC3D_OK;
-}
-
-int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                    void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                    float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                    toc3d_stream_t stream) {
-    return toc3d_linear_lnfold(dtype, epilogue, variant, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index,
-                               M, N, K, n_valid, nullptr, 0, nullptr, 0, 0.f, stream);
 }
 
 int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

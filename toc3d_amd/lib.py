@@ -22,7 +22,6 @@ _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 _SIGS = {
     "toc3d_linear": "iiplplpplpllppllllp",
     "toc3d_linear_ex": "iiiplplpplpllppllllp",
-    "toc3d_linear_lnfold": "iiiplplpplpllppllllplplfp",
     "toc3d_pack_weight": "ipllpllp",
     "toc3d_pack_swiglu": "ippppllppllp",
     "toc3d_im2col_patches": "ippllllllp",

@@ -2,7 +2,7 @@
 
 The reference loads a ``.pth`` with ``load_checkpoint(model, ckpt, map_location='cpu')`` (``tools/test.py:207``) on every start.
 Here the weights additionally go through a device-side packing step (fused q|k|v, interleaved w1|w2, 2730 -> 2752 padding,
-``W3*gamma`` of the folded ``ffn_ln``, kept-pad q|k|v rows, motion-query tables, bicubic-resized abs-pos per resolution).
+kept-pad q|k|v rows, motion-query tables, bicubic-resized abs-pos per resolution).
 ``save_packed`` writes exactly what the kernels consume as one ``safetensors`` file next to the checkpoint;
 ``load_packed`` restores it without the state dict and without re-packing.
 
@@ -58,7 +58,7 @@ def fingerprint(model) -> Dict[str, Any]:
     fp = dict(cls=type(model).__name__, precision=model.precision, embed_dim=model.embed_dim, depth=model.depth, num_heads=model.num_heads,
               hidden_dim=model.hidden_dim, patch_size=model.patch_size, window_size=model.window_size,
               global_window_size=model.global_window_size, global_attn_indexes=list(model.global_attn_indexes),
-              fold_ffn_ln=bool(model.fold_ffn_ln), abi=int(lib.load().toc3d_abi_version()))
+              abi=int(lib.load().toc3d_abi_version()))
     for k in ("pruning_loc", "token_ratio", "pruning_num_queries", "accelerate_global"):
         if hasattr(model, k):
             v = getattr(model, k)
