@@ -657,3 +657,33 @@ def test_im2col_u8_equals_im2col_of_normalized_images(name, dt, tdt, H, W):
     assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
     with pytest.raises(RuntimeError, match="multiple of the patch"):
         lib.call("toc3d_im2col_patches_u8", dt, img, V, H, W, torch.tensor(IMG_NORM["mean"]), torch.tensor(IMG_NORM["std"]), 0, b, Kp, Hp + 1, Wp, p, S())
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+def test_linear_unaligned_outputs_take_the_scalar_epilogue(name, dt, tdt):
+    """The epilogue stores 4 columns per lane as one 8 / 16-byte access when leading dims and base pointers allow it; ragged
+    N, odd leading dimensions and offset views fall back to per-element accesses with the same values."""
+    M, N, K = 333, 130, 128
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
+    res = rnd(M, N, seed=4)
+    ref = A.to(tdt).double() @ W.to(tdt).double().T + b.double()
+    tol = 1e-5 if dt == lib.F32 else 6e-3
+    for ldo, off in ((N, 0), (N + 1, 0), (N + 2, 1), (136, 4)):
+        buf = torch.zeros(M * ldo + 8, dtype=tdt, device=DEV)
+        out = buf[off:off + M * ldo].view(M, ldo)
+        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, 16, a_d, K, w_d, K, b.to(DEV), out, ldo, None, 0, 0, None, None, M, N, K, 0, S())
+        assert relerr(out[:, :N].float(), ref) < tol, (ldo, off)
+        assert float(out[:, N:].abs().sum()) == 0 and float(buf[:off].abs().sum()) == 0 and float(buf[off + M * ldo:].abs().sum()) == 0
+        b32 = torch.zeros(M * ldo + 8, device=DEV)
+        o32 = b32[off:off + M * ldo].view(M, ldo)
+        r32 = torch.zeros(M * ldo + 8, device=DEV)
+        rv = r32[off:off + M * ldo].view(M, ldo)
+        rv[:, :N] = res.to(DEV)
+        rep = torch.zeros(M // 5 + 1, N, device=DEV)
+        rep_index = torch.full((M,), -1, dtype=torch.int32)
+        rep_index[4::5] = torch.arange(len(rep_index[4::5]), dtype=torch.int32)
+        lib.call("toc3d_linear_ex", dt, lib.EPI_RESIDUAL, 8, a_d, K, w_d, K, b.to(DEV), o32, ldo, rv, ldo, 0, rep, rep_index.to(DEV), M, N, K, 0, S())
+        assert relerr(o32[:, :N], ref + res.double()) < tol, (ldo, off)
+        assert relerr(rep[: len(rep_index[4::5])], ref[4::5]) < tol
+        assert float(o32[:, N:].abs().sum()) == 0
