@@ -369,3 +369,26 @@ def test_memory_bank_full_size_feeds_the_backbone():
     assert float((fa - b.img_feats["last_feat"]).abs().max()) < 1e-3 * float(fa.abs().max())
     for s in range(3):
         assert iou(ka[s], b.keep_idx[s].cpu()) > 0.99
+
+
+def test_carried_compact_set_matches_scatter_gather_between_blocks():
+    """Consecutive accelerated blocks of one window type continue on the same compact rows (no scatter + gather in between;
+    bf16 path by default).  Proven on the fp32 kernels, where nothing else differs: features equal the block-by-block form to
+    1e-5 and the token selections are identical; in bf16 the two forms differ like any two bf16 roundings (top-k flips)."""
+    inp = synth.make_inputs(configs.get("toc3d_faster"), views_per_frame=6)
+    for precision, tol, min_iou in (("fp32", 1e-5, 1.0), ("bf16", 1e-1, 0.95)):
+        outs = {}
+        for carry in (True, False):
+            _, m = build("toc3d_faster", precision)
+            m.carry_compact, m.autotune = carry, False
+            o = run_toc3d(m, inp, True)
+            outs[carry] = (o.img_feats["last_feat"].float().clone(), [k.clone() for k in o.keep_idx])
+            del m
+        a, b = outs[True], outs[False]
+        rel = float((a[0] - b[0]).norm() / b[0].norm())
+        print(f"[carry {precision}] rel l2 between carried and block-by-block features: {rel:.3e}")
+        assert rel < tol, (precision, rel)
+        for s in range(3):
+            assert iou(a[1][s], b[1][s].cpu()) >= min_iou
+    _, m32 = build("toc3d_tiny", "fp32")
+    assert not m32.carry_compact, "the strict-parity path keeps the reference's scatter / gather between all blocks by default"

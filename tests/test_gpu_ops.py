@@ -377,7 +377,7 @@ def test_gather_merge_ln_and_scatter(name, dt, tdt, C, L, ratio):
     outw.scatter_(1, order[:, :k, None].expand(-1, -1, C), slow_out[:, :k])
     outw.scatter_(1, order[:, k:, None].expand(-1, -1, C), fast)
     ref_x = O.window_unpartition(outw.reshape(nW, L, L, C), L, pad_hw, (h, w)).reshape(-1, C)
-    lib.call("toc3d_scatter_update", xd, C, b["tok"], b["prow"], nW, N, k, slow_c.to(DEV), r1.to(DEV), r2.to(DEV), S())
+    lib.call("toc3d_scatter_update", xd, C, b["tok"], b["prow"], nW, N, k, slow_c.to(DEV), r1.to(DEV), r2.to(DEV), None, None, S())
     assert relerr(xd, ref_x) < 1e-6
 
 

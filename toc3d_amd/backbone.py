@@ -196,6 +196,7 @@ class _BackboneBase(nn.Module):
         self.alias_outputs = False      # True: returned tensors alias the reused workspace (benchmarks)
         self._side = None               # side stream: query-side scorer prep / image-level ranking overlap the blocks
         self.view_groups = 1            # > 1: split the views into groups that run concurrently on separate streams
+        self.carry_compact = precision == "bf16" and os.environ.get("TOC3D_CARRY", "1") != "0"   # see _accel_block
         self._gstreams = []
 
     # -- state-dict hook: re-pack after new weights arrive ------------------------------------------
@@ -707,6 +708,8 @@ class ToC3DEVAViT(_BackboneBase):
         plan["slow"] = torch.empty(max_rows, C, **f32)
         plan["rep1"] = torch.empty(max_nw, C, **f32)
         plan["rep2"] = torch.empty(max_nw, C, **f32)
+        plan["rep3"] = torch.empty(max_nw, C, **f32)          # second block of a carried pair (carry_compact)
+        plan["rep4"] = torch.empty(max_nw, C, **f32)
         plan["sel"] = {}
         for key, (nW, N, k, ms) in sel_geo.items():
             L = key[1]
@@ -826,23 +829,40 @@ class ToC3DEVAViT(_BackboneBase):
             prep["ev"] = torch.cuda.Event()
             prep["ev"].record(self._side)
 
-    def _accel_block(self, i, st, plan, P):
-        """ToC3DEVAViTBlock.forward (toc3d_eva_vit.py:395-477)."""
+    def _accel_block(self, i, st, plan, P, carry_in=False, carry_out=False):
+        """ToC3DEVAViTBlock.forward (toc3d_eva_vit.py:395-477).
+        carry_out / carry_in (bf16 path, ``carry_compact``): two consecutive blocks of one window type and stage select the same
+        tokens, so the second one continues on the first one's compact rows -- no scatter + gather in between.  Exact for the kept
+        rows; the representative row it would re-merge from the updated dropped tokens, sum_j w_j (x_j + delta) = rep_in + W*delta,
+        is rebuilt from the first block's updated row (toc3d_rep_rebase; W != 1 in ragged windows, whose -1e6 pad scores enter the
+        weight normalisation).  The dropped tokens receive all four updates at the end."""
         s = lib.stream_ptr()
         bp = P["blocks"][i]
         C, dt = self.embed_dim, self._dt
         sel = plan["sel"][(st, self._block_side(i))]
         nW, N, k, rows = sel["nW"], sel["N"], sel["k"], sel["rows"]
         slow = plan["slow"]
-        lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
-                 bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, s)
+        if carry_in:
+            lib.call("toc3d_rep_rebase", slow, C, sel["rep_row"], sel["tok"], sel["wgt"], nW, N, k, plan["rep1"], plan["rep2"], s)
+            lib.call("toc3d_layernorm_rows", dt, slow, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, rows, C, s)
+        else:
+            lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
+                     bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, s)
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, rows, 3 * C, C, 0)
         lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"],
                  None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], None, 64 ** -0.5, s)
-        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0, plan["rep1"], sel["rep_index"],
+        ra, rb = (plan["rep3"], plan["rep4"]) if carry_in else (plan["rep1"], plan["rep2"])
+        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0, ra, sel["rep_index"],
                      rows, C, C, 0)
-        self._mlp(bp, plan, rows, slow, plan["rep2"], sel["rep_index"])
-        lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"], s)
+        self._mlp(bp, plan, rows, slow, rb, sel["rep_index"])
+        if not carry_out:
+            lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"],
+                     plan["rep3"] if carry_in else None, plan["rep4"] if carry_in else None, s)
+
+    def _carries(self, i):
+        """Block i hands its compact rows to block i + 1 (same stage, same window type, both accelerated)."""
+        return (self.carry_compact and i + 1 < self.depth and self._accelerated(i) and self._accelerated(i + 1)
+                and (i + 1) not in self.pruning_loc and self._block_side(i) == self._block_side(i + 1))
 
     @torch.no_grad()
     def forward(self, x, temp_queries=None, prev_exists=None, temp_ref_points=None, temp_vel=None, temp_timestamp=None,
@@ -895,7 +915,9 @@ class ToC3DEVAViT(_BackboneBase):
                         r0, r1 = gp["v0"] * T, (gp["v0"] + gp["nv"]) * T
                         self._score_stage(st, gp, P, inputs, prev, [gm[r0:r1] for gm in gumbel])
                     if self._accelerated(i):
-                        self._accel_block(i, st, gp, P)
+                        # at most two blocks per carried set: the scatter takes four updates
+                        cin = i > 0 and self._carries(i - 1) and not (i > 1 and self._carries(i - 2))
+                        self._accel_block(i, st, gp, P, carry_in=cin, carry_out=self._carries(i) and not cin)
                     else:
                         self._dense_block(i, gp, P)
         for g, gp in enumerate(groups):

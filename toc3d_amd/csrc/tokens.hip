@@ -379,7 +379,8 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
 __global__ __launch_bounds__(256) void scatter_update_kernel(float* __restrict__ x, int C, const int32_t* __restrict__ tok,
                                                              const int32_t* __restrict__ prow, int nW, int N, int k,
                                                              const float* __restrict__ slow_out, const float* __restrict__ r1,
-                                                             const float* __restrict__ r2) {
+                                                             const float* __restrict__ r2, const float* __restrict__ r3,
+                                                             const float* __restrict__ r4) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t id = (int64_t)blockIdx.x * 4 + wave;
     if (id >= (int64_t)nW * N) return;
@@ -397,12 +398,36 @@ __global__ __launch_bounds__(256) void scatter_update_kernel(float* __restrict__
         for (int vi = lane; vi < nvec; vi += 64) {
             f32x4 v = *reinterpret_cast<const f32x4*>(xr + 4 * vi);
             v = (v + *reinterpret_cast<const f32x4*>(a + 4 * vi)) + *reinterpret_cast<const f32x4*>(b + 4 * vi);   // toc3d_eva_vit.py:454-456
+            if (r3) {                                // a second block on the same kept set: its two updates, in the reference's order
+                v = (v + *reinterpret_cast<const f32x4*>(r3 + (int64_t)win * C + 4 * vi)) + *reinterpret_cast<const f32x4*>(r4 + (int64_t)win * C + 4 * vi);
+            }
             *reinterpret_cast<f32x4*>(xr + 4 * vi) = v;
         }
     }
 }
 
 // [V, T, C] -> [V, C, T] through a 32x32 LDS tile (materialised permute(0,3,1,2), toc3d_eva_vit.py:294)
+// Carried compact set (backbone carry_compact): the second block of a pair would re-merge its representative token from the
+// updated dropped tokens,  sum_j w_j (x_j + delta) = rep_in + W * delta  with W = sum of the merge weights of the window's REAL
+// dropped tokens (1 for a full window; ~0 for a ragged one, whose -1e6 pad scores swallow the normalisation, toc3d_utils.py:65-70).
+// The first block left rep_in + delta in its compact row: subtract (1 - W) * delta, delta = rep1 + rep2.
+__global__ __launch_bounds__(256) void rep_rebase_kernel(float* __restrict__ slow, int C, const int32_t* __restrict__ rep_row,
+                                                         const int32_t* __restrict__ tok, const float* __restrict__ wgt, int N, int k,
+                                                         const float* __restrict__ r1, const float* __restrict__ r2) {
+    const int win = blockIdx.x;
+    __shared__ float s_w[4];
+    float w = 0.f;
+    for (int j = k + threadIdx.x; j < N; j += 256)
+        if (tok[(int64_t)win * N + j] >= 0) w += wgt[(int64_t)win * N + j];
+    w = wave_sum(w);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = w;
+    __syncthreads();
+    const float W = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    const float f = 1.0f - W;
+    float* row = slow + (int64_t)rep_row[win] * C;
+    for (int c = threadIdx.x; c < C; c += 256) row[c] -= f * (r1[(int64_t)win * C + c] + r2[(int64_t)win * C + c]);
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C) {
     __shared__ float tile[32][33];
     const int v = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -519,13 +544,25 @@ int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* t
 }
 
 int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k,
-                         const float* slow_out, const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream) {
+                         const float* slow_out, const float* rep_raw1, const float* rep_raw2, const float* rep_raw3, const float* rep_raw4,
+                         toc3d_stream_t stream) {
     TOC3D_REQUIRE(x && tok && prow && slow_out && rep_raw1 && rep_raw2, "toc3d_scatter_update: null buffer");
+    TOC3D_REQUIRE((rep_raw3 == nullptr) == (rep_raw4 == nullptr), "toc3d_scatter_update: rep_raw3 and rep_raw4 come as a pair");
     TOC3D_REQUIRE(C > 0 && C % 4 == 0 && k >= 0 && k < N, "toc3d_scatter_update: bad dims");
     if (nW <= 0 || N <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((nW * N + 3) / 4));
-    hipLaunchKernelGGL(scatter_update_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)C, tok, prow, (int)nW, (int)N, (int)k, slow_out, rep_raw1, rep_raw2);
+    hipLaunchKernelGGL(scatter_update_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)C, tok, prow, (int)nW, (int)N, (int)k, slow_out, rep_raw1, rep_raw2, rep_raw3, rep_raw4);
     TOC3D_LAUNCH_CHECK("toc3d_scatter_update");
+    return TOC3D_OK;
+}
+
+int toc3d_rep_rebase(float* slow, int64_t C, const int32_t* rep_row, const int32_t* tok, const float* wgt, int64_t nW, int64_t N, int64_t k,
+                     const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(slow && rep_row && tok && wgt && rep_raw1 && rep_raw2, "toc3d_rep_rebase: null buffer");
+    TOC3D_REQUIRE(C > 0 && k >= 0 && k < N, "toc3d_rep_rebase: bad dims");
+    if (nW <= 0) return TOC3D_OK;
+    hipLaunchKernelGGL(rep_rebase_kernel, dim3((unsigned)nW), dim3(256), 0, as_stream(stream), slow, (int)C, rep_row, tok, wgt, (int)N, (int)k, rep_raw1, rep_raw2);
+    TOC3D_LAUNCH_CHECK("toc3d_rep_rebase");
     return TOC3D_OK;
 }
 
