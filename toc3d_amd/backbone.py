@@ -783,13 +783,20 @@ class ToC3DEVAViT(_BackboneBase):
                          M, C // 4, q["w_o2"].shape[1], 0)
             lib.call("toc3d_score_head", dt, u2, u2.shape[1], C // 4, q["w_o4"], q["b_o4"], g, M, pred, score, mask, s)
         # image-level keep/drop lists are only returned to the caller (vis / loss): rank them beside the blocks
-        self._fork_side(plan)
-        with torch.cuda.stream(self._side):
-            lib.call("toc3d_rank_desc", score, V, T, plan["order"][st], lib.stream_ptr())
-        for L in {self.window_size, self.global_window_size}:
+        # ... and so is the selection for the window type the next block does not use (first needed two blocks later)
+        def topk(L, stream_ptr):
             sel = plan["sel"][(st, L)]
             lib.call("toc3d_window_topk", score, V, plan["h"], plan["w"], L, sel["k"], sel["order"], sel["tok"], sel["wgt"], sel["prow"],
-                     sel["crow_tok"], sel["rep_index"], sel["rep_row"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], s)
+                     sel["crow_tok"], sel["rep_index"], sel["rep_row"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], stream_ptr)
+        first = self._block_side(self.pruning_loc[st])
+        self._fork_side(plan)
+        plan["side_L"] = None
+        with torch.cuda.stream(self._side):
+            lib.call("toc3d_rank_desc", score, V, T, plan["order"][st], lib.stream_ptr())
+            for L in {self.window_size, self.global_window_size} - {first}:
+                topk(L, lib.stream_ptr())
+                plan["side_L"] = L
+        topk(first, s)
 
     # -- side stream: work that does not gate the block chain --------------------------------------------
     def _fork_side(self, plan):
@@ -839,6 +846,9 @@ class ToC3DEVAViT(_BackboneBase):
         s = lib.stream_ptr()
         bp = P["blocks"][i]
         C, dt = self.embed_dim, self._dt
+        if plan.get("side_L") == self._block_side(i):     # this window type's selection was computed on the side stream
+            self._join_side(plan)
+            plan["side_L"] = None
         sel = plan["sel"][(st, self._block_side(i))]
         nW, N, k, rows = sel["nW"], sel["N"], sel["k"], sel["rows"]
         slow = plan["slow"]
