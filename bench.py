@@ -112,6 +112,11 @@ def main():
     model.load_state_dict(sd_cpu)
     model = model.to(dev).eval()
     model.alias_outputs = True
+    if args.graph and args.groups > 1:
+        # capturing the two view-group streams into one hipGraph segfaults inside the ROCm 7.2 runtime on replay (multi-stream
+        # capture with cross-stream events); a single group captures fine and eager launches are as fast
+        print("[bench] --graph: using one view group (multi-stream capture is not usable on this runtime)", file=sys.stderr)
+        args.groups = 1
     model.view_groups = args.groups
     neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision=args.precision))
     neck.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG))
