@@ -205,11 +205,13 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
 int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                           const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
                           const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, toc3d_stream_t stream);
-/* toc3d_rep_rebase: for a block that continues on the previous block's compact rows instead of re-gathering them: turns the
- *   previous block's updated representative row into what merge_tokens (toc3d_utils.py:65-70) would produce from the updated dropped
- *   tokens: slow[rep_row[i]] -= (1 - W_i) * (rep_raw1[i] + rep_raw2[i]), W_i = sum of wgt over the window's real dropped tokens. */
-int toc3d_rep_rebase(float* slow, int64_t C, const int32_t* rep_row, const int32_t* tok, const float* wgt, int64_t nW, int64_t N, int64_t k,
-                     const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream);
+/* toc3d_rebase_layernorm_rows: norm1 (toc3d_eva_vit.py:372) of a block that continues on the previous block's compact rows instead
+ *   of re-gathering them (shortcut rows f32 [rows, C], in place; LN -> out act [rows, ldo]).  Representative rows (rep_index[r] = window
+ *   i >= 0) are first turned into what merge_tokens (toc3d_utils.py:65-70) would produce from the updated dropped tokens:
+ *   slow[r] -= (1 - W_i) * (rep_raw1[i] + rep_raw2[i]), W_i = sum of wgt over the window's real dropped tokens. */
+int toc3d_rebase_layernorm_rows(int dtype, float* slow, int64_t C, const int32_t* rep_index, const int32_t* tok, const float* wgt, int64_t N,
+                                int64_t k, const float* rep_raw1, const float* rep_raw2, const float* gamma, const float* beta, float eps,
+                                void* out, int64_t ldo, int64_t rows, toc3d_stream_t stream);
 int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k,
                          const float* slow_out, const float* rep_raw1, const float* rep_raw2, const float* rep_raw3, const float* rep_raw4,
                          toc3d_stream_t stream);

@@ -841,7 +841,7 @@ class ToC3DEVAViT(_BackboneBase):
         carry_out / carry_in (bf16 path, ``carry_compact``): two consecutive blocks of one window type and stage select the same
         tokens, so the second one continues on the first one's compact rows -- no scatter + gather in between.  Exact for the kept
         rows; the representative row it would re-merge from the updated dropped tokens, sum_j w_j (x_j + delta) = rep_in + W*delta,
-        is rebuilt from the first block's updated row (toc3d_rep_rebase; W != 1 in ragged windows, whose -1e6 pad scores enter the
+        is rebuilt from the first block's updated row (toc3d_rebase_layernorm_rows; W != 1 in ragged windows, whose -1e6 pad scores enter the
         weight normalisation).  The dropped tokens receive all four updates at the end."""
         s = lib.stream_ptr()
         bp = P["blocks"][i]
@@ -853,8 +853,8 @@ class ToC3DEVAViT(_BackboneBase):
         nW, N, k, rows = sel["nW"], sel["N"], sel["k"], sel["rows"]
         slow = plan["slow"]
         if carry_in:
-            lib.call("toc3d_rep_rebase", slow, C, sel["rep_row"], sel["tok"], sel["wgt"], nW, N, k, plan["rep1"], plan["rep2"], s)
-            lib.call("toc3d_layernorm_rows", dt, slow, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, rows, C, s)
+            lib.call("toc3d_rebase_layernorm_rows", dt, slow, C, sel["rep_index"], sel["tok"], sel["wgt"], N, k, plan["rep1"], plan["rep2"],
+                     bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, rows, s)
         else:
             lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, s)

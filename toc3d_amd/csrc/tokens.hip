@@ -407,25 +407,47 @@ __global__ __launch_bounds__(256) void scatter_update_kernel(float* __restrict__
 }
 
 // [V, T, C] -> [V, C, T] through a 32x32 LDS tile (materialised permute(0,3,1,2), toc3d_eva_vit.py:294)
-// Carried compact set (backbone carry_compact): the second block of a pair would re-merge its representative token from the
-// updated dropped tokens,  sum_j w_j (x_j + delta) = rep_in + W * delta  with W = sum of the merge weights of the window's REAL
-// dropped tokens (1 for a full window; ~0 for a ragged one, whose -1e6 pad scores swallow the normalisation, toc3d_utils.py:65-70).
-// The first block left rep_in + delta in its compact row: subtract (1 - W) * delta, delta = rep1 + rep2.
-__global__ __launch_bounds__(256) void rep_rebase_kernel(float* __restrict__ slow, int C, const int32_t* __restrict__ rep_row,
-                                                         const int32_t* __restrict__ tok, const float* __restrict__ wgt, int N, int k,
-                                                         const float* __restrict__ r1, const float* __restrict__ r2) {
-    const int win = blockIdx.x;
-    __shared__ float s_w[4];
-    float w = 0.f;
-    for (int j = k + threadIdx.x; j < N; j += 256)
-        if (tok[(int64_t)win * N + j] >= 0) w += wgt[(int64_t)win * N + j];
-    w = wave_sum(w);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = w;
-    __syncthreads();
-    const float W = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-    const float f = 1.0f - W;
-    float* row = slow + (int64_t)rep_row[win] * C;
-    for (int c = threadIdx.x; c < C; c += 256) row[c] -= f * (r1[(int64_t)win * C + c] + r2[(int64_t)win * C + c]);
+// Carried compact set (backbone carry_compact): norm1 of a block that continues on the previous block's compact rows.  The block
+// would re-merge its representative token from the updated dropped tokens,  sum_j w_j (x_j + delta) = rep_in + W * delta  with W =
+// sum of the merge weights of the window's REAL dropped tokens (1 for a full window; ~0 for a ragged one, whose -1e6 pad scores
+// swallow the normalisation, toc3d_utils.py:65-70).  The previous block left rep_in + delta in its compact row: representative rows
+// first subtract (1 - W) * delta, delta = rep1 + rep2 (written back to the f32 rows), then every row is normalised as usual.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_rebase_kernel(float* __restrict__ slow, int C, const int32_t* __restrict__ rep_index,
+                                                        const int32_t* __restrict__ tok, const float* __restrict__ wgt, int N, int k,
+                                                        const float* __restrict__ r1, const float* __restrict__ r2,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        T* __restrict__ out, int64_t ldo, int M) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int nvec = C >> 2;
+    const int win = rep_index[row];                      // wave-uniform
+    float* xr = slow + (int64_t)row * C;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + 64 * i;
+        v[i] = vi < nvec ? *reinterpret_cast<const f32x4*>(xr + 4 * vi) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (win >= 0) {
+        float w = 0.f;
+        for (int j = k + lane; j < N; j += 64)
+            if (tok[(int64_t)win * N + j] >= 0) w += wgt[(int64_t)win * N + j];
+        const float f = 1.0f - wave_sum(w);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(r1 + (int64_t)win * C + 4 * vi) + *reinterpret_cast<const f32x4*>(r2 + (int64_t)win * C + 4 * vi);
+                v[i] -= f * d;
+                *reinterpret_cast<f32x4*>(xr + 4 * vi) = v[i];
+            }
+        }
+    }
+    float mean, rstd;
+    wave_ln_stats<MAXV>(v, nvec, lane, C, eps, mean, rstd);
+    wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, out + (int64_t)row * ldo);
 }
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C) {
@@ -556,13 +578,20 @@ int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t*
     return TOC3D_OK;
 }
 
-int toc3d_rep_rebase(float* slow, int64_t C, const int32_t* rep_row, const int32_t* tok, const float* wgt, int64_t nW, int64_t N, int64_t k,
-                     const float* rep_raw1, const float* rep_raw2, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(slow && rep_row && tok && wgt && rep_raw1 && rep_raw2, "toc3d_rep_rebase: null buffer");
-    TOC3D_REQUIRE(C > 0 && k >= 0 && k < N, "toc3d_rep_rebase: bad dims");
-    if (nW <= 0) return TOC3D_OK;
-    hipLaunchKernelGGL(rep_rebase_kernel, dim3((unsigned)nW), dim3(256), 0, as_stream(stream), slow, (int)C, rep_row, tok, wgt, (int)N, (int)k, rep_raw1, rep_raw2);
-    TOC3D_LAUNCH_CHECK("toc3d_rep_rebase");
+int toc3d_rebase_layernorm_rows(int dtype, float* slow, int64_t C, const int32_t* rep_index, const int32_t* tok, const float* wgt, int64_t N,
+                                int64_t k, const float* rep_raw1, const float* rep_raw2, const float* gamma, const float* beta, float eps,
+                                void* out, int64_t ldo, int64_t rows, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(slow && rep_index && tok && wgt && rep_raw1 && rep_raw2 && gamma && beta && out, "toc3d_rebase_layernorm_rows: null buffer");
+    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 2048 && ldo >= C && ldo % 4 == 0 && k >= 0 && k < N, "toc3d_rebase_layernorm_rows: bad dims");
+    if (rows <= 0) return TOC3D_OK;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = as_stream(stream);
+#define LNB(T, MV) hipLaunchKernelGGL((ln_rebase_kernel<T, MV>), grid, block, 0, s, slow, (int)C, rep_index, tok, wgt, (int)N, (int)k, rep_raw1, rep_raw2, gamma, beta, eps, (T*)out, ldo, (int)rows)
+    if (dtype == TOC3D_BF16) { if (C <= 1024) LNB(bf16_t, 4); else LNB(bf16_t, 8); }
+    else if (dtype == TOC3D_F32) { if (C <= 1024) LNB(float, 4); else LNB(float, 8); }
+    else { toc3d_set_error("toc3d_rebase_layernorm_rows: bad dtype"); return TOC3D_ERR_ARG; }
+#undef LNB
+    TOC3D_LAUNCH_CHECK("toc3d_rebase_layernorm_rows");
     return TOC3D_OK;
 }
 

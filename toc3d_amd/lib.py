@@ -36,7 +36,7 @@ _SIGS = {
     "toc3d_window_topk": "plllllpppppppppppp",
     "toc3d_gather_merge_ln": "iplppppllllppfpplp",
     "toc3d_scatter_update": "plpplllpppppp",
-    "toc3d_rep_rebase": "plppplllppp",
+    "toc3d_rebase_layernorm_rows": "iplpppllppppfpllp",
     "toc3d_pack_motion_weights": "p" * 24 + "p",
     "toc3d_motion_queries": "pllppppippllpp",
     "toc3d_collapse_query_scorer": "ppppplllfppp",
