@@ -392,3 +392,63 @@ def test_carried_compact_set_matches_scatter_gather_between_blocks():
             assert iou(a[1][s], b[1][s].cpu()) >= min_iou
     _, m32 = build("toc3d_tiny", "fp32")
     assert not m32.carry_compact, "the strict-parity path keeps the reference's scatter / gather between all blocks by default"
+
+
+def test_streaming_loop_uint8_images_memory_bank_backbone_neck():
+    """All SURVEY.md 8f rows in the order the detector runs them (detectors/petr3d.py:105-190, streampetr_head.py:322-377):
+    uint8 camera images -> memory bank slice -> ToC3D backbone -> CPFPN, then the bank absorbs (synthetic) head outputs; four frames
+    with a scene start.  The fp32 HIP path tracks the oracle composition frame by frame; a second run of the loop returns the same bits."""
+    from oracle import image_oracle as I
+    from oracle.memory_oracle import MemoryBank
+    cfg = configs.get("toc3d_tiny")
+    norm = dict(mean=[103.530, 116.280, 123.675], std=[57.375, 57.120, 58.395], to_rgb=False)
+    sd, nsd = synth.make_state_dict(cfg), synth.neck_state_dict(configs.CPFPN_TINY)
+    mcfg = dict(memory_len=96, topk_proposals=32, num_propagated=32, embed_dims=256, pc_range=cfg["pc_range"])
+    Q = cfg["pruning_num_queries"]
+    minp = synth.memory_inputs(mcfg, 1, 120, 10, 4, seed=3)
+    rng = np.random.default_rng(21)
+    imgs = [rng.integers(0, 256, (2, 320, 800, 3), dtype=np.uint8) for _ in range(4)]
+    base = synth.make_inputs(cfg, views_per_frame=2)
+
+    def run_loop():
+        bb = toc3d_amd.build_backbone(dict(cfg, precision="fp32", img_norm_cfg=norm))
+        bb.load_state_dict(sd)
+        bb = bb.to(DEV).eval()
+        neck = toc3d_amd.build_neck(dict(configs.CPFPN_TINY, precision="fp32"))
+        neck.load_state_dict(nsd)
+        neck = neck.to(DEV)
+        mem = toc3d_amd.TemporalMemory(pseudo_reference_points=minp["pseudo"], **mcfg)
+        outs = []
+        for f in range(4):
+            fr = minp["frames"][f]
+            data = {k: v.to(DEV) for k, v in fr["data"].items()}
+            mem.pre_update_memory(data)
+            q = mem.backbone_queries(Q, prev_exists=data["prev_exists"])
+            o = bb(torch.from_numpy(imgs[f]).to(DEV), ego_pose_inv=data["ego_pose_inv"], gumbel_noise=base["gumbel"], **q)
+            n0, n1 = neck([o.img_feats["last_feat"]])
+            mem.post_update_memory(data, fr["rec_ego_pose"].to(DEV), fr["cls"].to(DEV)[None], fr["bbox"].to(DEV)[None], fr["dec"].to(DEV)[None])
+            outs.append((n0.clone(), n1.clone(), [k.clone() for k in o.keep_idx]))
+        return outs
+
+    got = run_loop()
+    # oracle composition on the host
+    ora = MemoryBank(pseudo_reference_points=minp["pseudo"], **mcfg)
+    for f in range(4):
+        fr = minp["frames"][f]
+        ora.pre_update_memory(fr["data"])
+        mid = bool(fr["data"]["prev_exists"][0] > 0)
+        q = ora.backbone_queries(Q, mid)
+        x = torch.from_numpy(I.prepare_images(imgs[f], norm["mean"], norm["std"], norm["to_rgb"], 32))
+        with torch.no_grad():
+            ref = O.forward_toc3d(sd, cfg, x, q["temp_queries"], q["temp_ref_points"], q["temp_vel"], q["temp_timestamp"], q["temp_ego_pose"],
+                                  fr["data"]["ego_pose_inv"], mid, base["gumbel"])
+            rn = O.cpfpn(nsd, ref["last_feat"])
+        ora.post_update_memory(fr["data"], fr["rec_ego_pose"], fr["cls"], fr["bbox"], fr["dec"])
+        e0 = rel_max(got[f][0], rn[0])
+        print(f"[loop] frame {f} prev_exists={mid}: neck level-0 rel max err vs oracle {e0:.3e}")
+        assert e0 < 1e-3
+    again = run_loop()
+    for a, b in zip(got, again):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for s in range(3):
+            assert torch.equal(a[2][s], b[2][s])
