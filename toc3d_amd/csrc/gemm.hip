@@ -146,12 +146,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, s, g, T());
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, s, g, T());
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) mma_step(acc[i][j], fb[j], fa[i]);   // swapped: C^T tile layout, see the epilogue
-            __builtin_amdgcn_s_setprio(0);
         }
     };
     if (STAGES == 1) {
