@@ -81,6 +81,18 @@ TOC3D_DEV float silu(float x) { return x / (1.0f + expf(-x)); }
 
 template <int N> TOC3D_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Workgroup barrier of the K loop.  __builtin_amdgcn_s_barrier() alone does not order memory operations for the compiler: without
+// the fences the scheduler may hoist the next K-tile's global_load_lds above the barrier (or sink this tile's ds_reads below it),
+// and another wavefront then reads an operand piece that is being overwritten -- 8-row pieces of a tile came out wrong a few times
+// per thousand launches, only with other kernels co-resident on the CU (tests/test_gpu_ops.py::test_linear_is_bit_stable_under_load).
+TOC3D_DEV void tile_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+}
+
 // Multi-stage pipeline: the LDS ring holds STAGES K-tiles; tile t+STAGES-1 is requested while tile t is
 // multiplied, so a K step no longer exposes an HBM/L2 round trip.  The in-flight global_load_lds are
 // tracked with a *counted* s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain them to
@@ -157,10 +169,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         for (int kt = 0; kt < nk; ++kt) {
             request(kt);
             wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+            tile_barrier();                              // every wave's pieces of tile kt have landed
             multiply(kt);
-            __builtin_amdgcn_s_barrier();
+            tile_barrier();                              // every wave is done reading: the buffer may be overwritten
         }
     } else {
 #pragma unroll
@@ -169,8 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         for (int kt = 0; kt < nk; ++kt) {
             if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
             else wait_vmcnt<0>();                                                                   // pipeline tail
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+            tile_barrier();
             if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);
             multiply(kt);
         }
