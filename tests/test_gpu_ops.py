@@ -687,3 +687,36 @@ def test_linear_unaligned_outputs_take_the_scalar_epilogue(name, dt, tdt):
         assert relerr(o32[:, :N], ref + res.double()) < tol, (ldo, off)
         assert relerr(rep[: len(rep_index[4::5])], ref[4::5]) < tol
         assert float(o32[:, N:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("variant", [1, 8, 10, 13, 14, 15, 16, 17, 22, 24, 26, 28, 29, 30, 116, 117, 126])
+def test_every_tuned_gemm_pipeline_is_bit_stable_beside_attention(variant):
+    """Each K-loop flavour the autotuner may pick (single buffer, rings of 2-4 stages, K-tiles of 32 / 64 / 128 / 256, 4 and 8
+    wavefronts, banded order) launched repeatedly while the flash-attention kernel of another stream shares the CUs: regression
+    for the raw-barrier scheduling race of the single-buffer loop, which only showed under that kind of co-residency."""
+    dt, tdt = lib.BF16, torch.bfloat16
+    M, C, N = 6000, 1024, 3072
+    a_d = as_act(rnd(M, C, seed=1), tdt)
+    wq, bq = pack(rnd(N, C, seed=2, scale=C ** -0.5), dt, tdt), rnd(N, seed=3).to(DEV)
+    V, h, w, L, heads = 6, 20, 50, 16, 16
+    qkv = torch.zeros(M, 3 * C, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, 0, a_d, C, wq, C, bq, qkv, 3 * C, None, 0, 0, None, None, M, N, C, 0, S())
+    nW, NN = V * 2 * 4, L * L
+    rows = torch.empty(nW, NN, dtype=torch.int32, device=DEV)
+    wslots, count, npad = torch.empty_like(rows), torch.empty(nW, dtype=torch.int32, device=DEV), torch.empty(nW, dtype=torch.int32, device=DEV)
+    lib.call("toc3d_window_map_dense", V, h, w, L, rows, wslots, count, npad, S())
+    cosT, sinT, vb = rnd(NN, 64, seed=11).to(DEV), rnd(NN, 64, seed=12).to(DEV), rnd(C, seed=13).to(DEV)
+    att = torch.zeros(M, C, dtype=tdt, device=DEV)
+    outs = [torch.zeros(M, N, dtype=tdt, device=DEV) for _ in range(24)]
+    torch.cuda.synchronize()
+    side, mc = torch.cuda.Stream(), int(count.max())
+    for o in outs:
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                lib.call("toc3d_window_attention", dt, qkv, 3 * C, att, C, rows, wslots, count, None, npad, None, NN, nW, mc, heads,
+                         cosT, sinT, L, vb, 0.125, S())
+        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, variant, a_d, C, wq, C, bq, o, N, None, 0, 0, None, None, M, N, C, 0, S())
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs[1:]):
+        assert torch.equal(o.view(torch.uint8), outs[0].view(torch.uint8)), f"variant {variant}: launch {i + 1} differs from launch 0"
+    assert torch.equal(outs[0], qkv), "and equals the heuristic variant's result"
