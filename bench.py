@@ -210,6 +210,32 @@ def main():
         for _ in range(2):
             step()                                     # builds / autotunes the single-group plan outside the instrumented pass
         torch.cuda.synchronize()
+        # the paper times the backbone's block loop only (toc3d_eva_vit.py:262,293): two events per step, one behind the
+        # patch-embedding GEMM and one in front of the neck's first launch (single stream, no per-launch instrumentation)
+        marks, state = [], {"stem": False}
+
+        def marking_call(name, *a):
+            if name == "toc3d_pack_weight" and marks and len(marks[-1]) == 1:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks[-1].append(e)
+            orig_call(name, *a)
+            if name in ("toc3d_im2col_patches", "toc3d_im2col_patches_u8"):
+                state["stem"] = True
+            elif state["stem"] and name == "toc3d_linear_ex":
+                state["stem"] = False
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append([e])
+        try:
+            lib.call = marking_call
+            for _ in range(max(n_inst, 5)):
+                step()
+            torch.cuda.synchronize()
+        finally:
+            lib.call = orig_call
+        loops = sorted(m[0].elapsed_time(m[1]) for m in marks if len(m) == 2)
+        block_loop_ms = loops[len(loops) // 2] if loops else None
         try:
             lib.call = timed_call
             for _ in range(n_inst):
@@ -277,6 +303,10 @@ def main():
                        "view_groups": args.groups,
                        "baseline_note": "vs_baseline divides by the paper's 4.78 backbone-frames/s (fp32, GPU model unstated, BASELINE.md section 1)"},
             "whole_path_tflops": (alg / (ms * 1e-3)) / 1e12,
+            "paper_protocol": None if roof is None or block_loop_ms is None else {
+                "block_loop_ms": block_loop_ms, "block_loop_frames_per_s": 1e3 / block_loop_ms,
+                "note": "block loop only, single stream, event-timed (the span the paper's 209 ms covers); the headline value also "
+                        "includes patch embedding, the scorer-side query preparation and the CPFPN neck"},
         }
         if roof is not None:
             res["roofline"] = roof
