@@ -149,3 +149,20 @@ def test_memory_bank_oracle_matches_reference_golden(golden_dir):
         for k, v in m.state().items():
             ref = torch.from_numpy(g[f"f{f}_post_{k}"])
             assert v.dtype == ref.dtype and torch.equal(v, ref), (f, "post", k)
+
+
+def test_head_tokens_oracle_matches_reference_golden(golden_dir):
+    """oracle/head_tokens_oracle.py against tests/golden/head_tokens.npz, written by the reference's own position_embeding, MLN and
+    SELayer_Linear composed as StreamPETRHead.forward :627-639 (oracle/gen_golden_head.py)."""
+    from oracle import head_tokens_oracle as HO
+    from oracle.gen_golden_head import CFG, B, N, H, W
+    g = np.load(os.path.join(golden_dir, "head_tokens.npz"))
+    sd = synth.head_tokens_state_dict(CFG)
+    inp = synth.head_tokens_inputs(CFG, B, N, H, W)
+    pad_h, pad_w = H * CFG["stride"], W * CFG["stride"]
+    pos, cone = HO.position_embedding(sd, CFG, inp["intrinsics"], inp["lidar2img"], H, W, pad_h, pad_w)
+    memory, pos_embed = HO.token_embeddings(sd, CFG, inp["feats"], inp["intrinsics"], inp["lidar2img"], pad_h, pad_w)
+    for name, got in (("pos_raw", pos), ("cone", cone), ("memory", memory), ("pos_embed", pos_embed)):
+        ref = torch.from_numpy(g[name])
+        assert got.shape == ref.shape, name
+        assert torch.equal(got, ref), (name, float((got - ref).abs().max()))

@@ -266,3 +266,48 @@ def memory_inputs(cfg: dict, B: int, num_query: int, num_classes: int, frames: i
         out["frames"].append(dict(data=data, rec_ego_pose=torch.eye(4).repeat(B, Q, 1, 1), cls=r(B, Q, num_classes) * 2.0,
                                   bbox=r(B, Q, 10) * 5.0, dec=r(B, Q, cfg["embed_dims"])))
     return out
+
+
+HEAD_TOKENS_CFG = dict(in_channels=256, embed_dims=256, depth_num=64, depth_start=1.0, LID=True, stride=16,
+                       position_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0])       # projects/configs/ToC3D/ToC3D_faster.py:99-112
+HEAD_TOKENS_TINY = dict(in_channels=32, embed_dims=64, depth_num=64, depth_start=1.0, LID=True, stride=16,
+                        position_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0])
+
+
+def head_tokens_state_dict(cfg: dict, seed: int = 0):
+    """Seeded weights of the head's token-side modules (state-dict names of StreamPETRHead, streampetr_head.py:262-288)."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    C, E, P = cfg["in_channels"], cfg["embed_dims"], cfg["depth_num"] * 3
+    lin = lambda o, i, s=None: ((torch.randn(o, i, generator=g) * (s if s is not None else i ** -0.5)), torch.randn(o, generator=g) * 0.1)
+    sd = {}
+    for name, (o, i) in {"position_encoder.0": (4 * E, P), "position_encoder.2": (E, 4 * E), "memory_embed.0": (E, C), "memory_embed.2": (E, E),
+                         "spatial_alignment.reduce.0": (E, 8), "spatial_alignment.gamma": (E, E), "spatial_alignment.beta": (E, E),
+                         "featurized_pe.conv_reduce": (E, E), "featurized_pe.conv_expand": (E, E)}.items():
+        wgt, b = lin(o, i, 0.05 if name == "position_encoder.0" else None)
+        if name == "spatial_alignment.gamma":
+            b = b + 1.0                                          # MLN.reset_parameters: gamma bias starts at one
+        sd[name + ".weight"], sd[name + ".bias"] = wgt, b
+    return sd
+
+
+def head_tokens_inputs(cfg: dict, B: int, N: int, h: int, w: int, seed: int = 0):
+    """Neck features (B, N, C, h, w) and nuScenes-like camera matrices: intrinsics (B, N, 4, 4), lidar2img (B, N, 4, 4)."""
+    import math
+    g = torch.Generator().manual_seed(5000 + seed)
+    feats = torch.randn(B, N, cfg["in_channels"], h, w, generator=g)
+    intr = torch.eye(4).repeat(B, N, 1, 1)
+    l2i = torch.empty(B, N, 4, 4)
+    for b in range(B):
+        for n in range(N):
+            f = 500.0 + 20.0 * float(torch.rand(1, generator=g))
+            K = torch.eye(4)
+            K[0, 0], K[1, 1], K[0, 2], K[1, 2] = f, f * 1.01, 0.5 * w * cfg["stride"], 0.5 * h * cfg["stride"]
+            yaw = 2 * math.pi * n / N + 0.05 * float(torch.randn(1, generator=g))
+            # camera looks along its +z: lidar -> camera = R_cam * R_yaw, plus a small translation
+            Ry = torch.tensor([[math.cos(yaw), math.sin(yaw), 0.0], [-math.sin(yaw), math.cos(yaw), 0.0], [0.0, 0.0, 1.0]])
+            Rc = torch.tensor([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])
+            E = torch.eye(4)
+            E[:3, :3] = Rc @ Ry
+            E[:3, 3] = torch.tensor([0.1, -0.3, -1.5]) + 0.1 * torch.randn(3, generator=g)
+            intr[b, n], l2i[b, n] = K, K @ E
+    return dict(feats=feats, intrinsics=intr, lidar2img=l2i)
