@@ -297,6 +297,26 @@ int toc3d_memory_post_update(const float* emb_in, const float* ref_in, const dou
                              const double* timestamp, int64_t B, int64_t Q, int64_t capacity, int64_t memory_len, int64_t topk, int64_t embed_dims,
                              toc3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Token side of StreamPETRHead.forward (second half; dense_heads/streampetr_head.py:378-422,627-639): the
+ * consumers of the neck's features.  Linear layers run on toc3d_linear; these are the kernels around them.
+ * toc3d_head_frustum_inputs: position_embeding up to the position_encoder's input.  For V = B*N views of h x w tokens and D depth
+ *   bins (coords_d [D], device): pixel centres (misc.py:70-77) * depth through img2lidar [V, 4, 4] (= lidar2img^-1, device),
+ *   normalised by position_range (HOST float[6]), inverse_sigmoid -> pos_in act [V*h*w, ld_pos] (3*D valid columns, the rest
+ *   untouched: pre-zero the buffer once); cone f32 [V*h*w, 8] = [|fx|, |fy|] / 1e3 of camera (token % N) -- the reference's repeat
+ *   order, :385-386 -- then the normalised points of the last depth bin and of bin D-30 (:419-420), also as act rows (ld_cone).
+ * toc3d_relu_inplace: nn.ReLU between the Linear pairs.  toc3d_nchw_to_rows: neck output NCHW f32 -> [V*hw, ldo] act rows (:629).
+ * toc3d_mln_apply: MLN.forward (models/utils/misc.py:181-188): gamma * LayerNorm(x, no affine, eps 1e-5) + beta -> f32 + act copy.
+ * toc3d_se_gate: SELayer_Linear (misc.py:151): out = pos * sigmoid(se). */
+int toc3d_head_frustum_inputs(int dtype, const float* img2lidar, const float* intrinsics, const float* coords_d, const float* position_range,
+                              int64_t B, int64_t N, int64_t h, int64_t w, int64_t D, int64_t stride, int64_t pad_h, int64_t pad_w,
+                              void* pos_in, int64_t ld_pos, void* cone_act, int64_t ld_cone, float* cone, toc3d_stream_t stream);
+int toc3d_relu_inplace(int dtype, void* x, int64_t n, toc3d_stream_t stream);
+int toc3d_nchw_to_rows(int dtype, const float* x, void* out, int64_t ldo, int64_t V, int64_t C, int64_t hw, toc3d_stream_t stream);
+int toc3d_mln_apply(int dtype, const float* x, const float* gamma, const float* beta, int64_t M, int64_t E, float* out, void* out_act, int64_t ld_act,
+                    toc3d_stream_t stream);
+int toc3d_se_gate(const float* pos, const float* se, float* out, int64_t n, toc3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

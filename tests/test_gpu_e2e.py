@@ -452,3 +452,39 @@ def test_streaming_loop_uint8_images_memory_bank_backbone_neck():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         for s in range(3):
             assert torch.equal(a[2][s], b[2][s])
+
+
+# ---------------------------------------------------------------------------------------------------
+# token side of the head (second half)
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+def test_head_token_embedding_matches_reference_golden(golden_dir, precision, tol):
+    """toc3d_amd.HeadTokenEmbedding against tests/golden/head_tokens.npz (the reference's position_embeding + MLN + SELayer_Linear)."""
+    from oracle.gen_golden_head import CFG, B, N, H, W
+    g = np.load(os.path.join(golden_dir, "head_tokens.npz"))
+    m = toc3d_amd.HeadTokenEmbedding(precision=precision, **CFG)
+    m.load_state_dict(synth.head_tokens_state_dict(CFG), strict=True)
+    m = m.to(DEV).eval()
+    inp = synth.head_tokens_inputs(CFG, B, N, H, W)
+    memory, pos, cone = m(inp["feats"].to(DEV), inp["intrinsics"].to(DEV), inp["lidar2img"].to(DEV), (H * CFG["stride"], W * CFG["stride"], 3))
+    e_cone = rel_max(cone, torch.from_numpy(g["cone"]))
+    e_mem, e_pos = rel_max(memory, torch.from_numpy(g["memory"])), rel_max(pos, torch.from_numpy(g["pos_embed"]))
+    print(f"[head tokens {precision}] rel max err: cone {e_cone:.2e} memory {e_mem:.2e} pos_embed {e_pos:.2e}")
+    assert e_cone < (1e-5 if precision == "fp32" else 1e-5) and e_mem < tol and e_pos < tol
+    with pytest.raises(RuntimeError, match="CUDA/HIP"):
+        m(inp["feats"], inp["intrinsics"], inp["lidar2img"], (64, 96))
+
+
+def test_head_token_embedding_full_size_matches_oracle():
+    """Shipped sizes (6 views x 20 x 50 tokens, 256 channels, 64 LID depth bins) on the fp32 kernels against the oracle on the host."""
+    from oracle import head_tokens_oracle as HO
+    cfg = synth.HEAD_TOKENS_CFG
+    sd = synth.head_tokens_state_dict(cfg, seed=1)
+    inp = synth.head_tokens_inputs(cfg, 1, 6, 20, 50, seed=1)
+    m = toc3d_amd.HeadTokenEmbedding(precision="fp32", **cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    memory, pos, _ = m(inp["feats"].to(DEV), inp["intrinsics"].to(DEV), inp["lidar2img"].to(DEV), (320, 800, 3))
+    with torch.no_grad():
+        rm, rp = HO.token_embeddings(sd, cfg, inp["feats"], inp["intrinsics"], inp["lidar2img"], 320, 800)
+    assert tuple(memory.shape) == (1, 6000, 256)
+    assert rel_max(memory, rm) < 2e-4 and rel_max(pos, rp) < 2e-4

@@ -7,8 +7,9 @@ from .backbone import EVA_ViT, ToC3DEVAViT, ToC3DViTReturnType
 from .neck import CPFPN
 from .preprocess import prepare_images
 from .memory import TemporalMemory
+from .head_tokens import HeadTokenEmbedding
 from .registry import BACKBONES, NECKS, build_backbone, build_neck, register_all
 
 register_all()
 
-__all__ = ["ToC3DEVAViT", "EVA_ViT", "CPFPN", "ToC3DViTReturnType", "BACKBONES", "NECKS", "build_backbone", "build_neck", "prepare_images", "TemporalMemory"]
+__all__ = ["ToC3DEVAViT", "EVA_ViT", "CPFPN", "ToC3DViTReturnType", "BACKBONES", "NECKS", "build_backbone", "build_neck", "prepare_images", "TemporalMemory", "HeadTokenEmbedding"]

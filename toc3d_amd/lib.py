@@ -45,6 +45,11 @@ _SIGS = {
     "toc3d_score_head": "ipllppplpppp",
     "toc3d_nhwc_to_nchw": "pplllp",
     "toc3d_im2col_3x3": "ipplllllp",
+    "toc3d_head_frustum_inputs": "ippppllllllllplplpp",
+    "toc3d_relu_inplace": "iplp",
+    "toc3d_nchw_to_rows": "ippllllp",
+    "toc3d_mln_apply": "ipppllpplp",
+    "toc3d_se_gate": "ppplp",
     "toc3d_memory_pre_update": "pppppppppplllllip",
     "toc3d_memory_scores": "pllpp",
     "toc3d_memory_post_update": "ppppppppppppplpppllllllp",
