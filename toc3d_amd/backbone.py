@@ -341,7 +341,7 @@ class _BackboneBase(nn.Module):
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
     _flush = None               # 256 MB scratch shared by all models: evicts L2 + Infinity Cache between tuning launches
-    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 110, 114, 116, 117, 126),
+    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 110, 114, 116, 117, 126, 145, 147),
                  lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
@@ -360,7 +360,7 @@ class _BackboneBase(nn.Module):
                 rep_s = torch.empty_like(rep_out) if rep_out is not None else None
                 cands = self._VARIANTS[self._dt]
                 if epi == lib.EPI_SWIGLU:
-                    cands = [v for v in cands if v != 33]          # 16-column wave slabs cannot pair w1 / w2 columns
+                    cands = [v for v in cands if v not in (33, 45, 145)]   # wave slabs that are not whole (w1, w2) 32-column groups
                 # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
                 # L2 / Infinity Cache): time single launches behind a cache-sized memset, not a warm back-to-back loop, or the
                 # tuner prefers shallow pipelines that lose in place (tools/ubench/n1024_all_variants.py).

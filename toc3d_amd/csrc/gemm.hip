@@ -345,6 +345,13 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 40: launch_cfg<T, EPI, 128, 256, 1, 128, 2, 4, 1>(a, s); break;      // 128x256, 64x64 per wave, 48 KiB
         case 41: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 256, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 128x256, K-tile 32 x 2, 48 KiB
         case 42: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 256, 128, 2, 64, 4, 2, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 256x128, K-tile 32 x 2, 48 KiB
+        // N-tiles that are not powers of two (the vendor library's answer to tile-count quantisation on N = 3072 / 1024)
+        case 43: launch_cfg<T, EPI, 128, 192, 1, 128, 2, 4, 1>(a, s); break;      // 128x192, 64x48 per wave, 40 KiB
+        case 44: launch_cfg<T, EPI, 128, 96, 1, 128, 2, 2, 1>(a, s); break;       // 128x96, 4 waves, 64x48 per wave, 28 KiB
+        case 45: launch_cfg<T, EPI, 128, 192, 2, 128, 2, 4, 1>(a, s); break;      // 128x192 double buffered, 80 KiB
+        case 46: launch_cfg<T, EPI, 128, 96, 2, 128, 2, 2, 1>(a, s); break;       // 128x96 double buffered, 56 KiB
+        case 47: launch_cfg<T, EPI, 128, 192, 2, 128, 4, 2, 1>(a, s); break;      // 128x192 double buffered, 32x96 per wave (serves SwiGLU)
+        case 48: launch_cfg<T, EPI, 128, 192, 3, 128, 2, 4, 1>(a, s); break;      // 128x192, 3-deep ring, 120 KiB
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;

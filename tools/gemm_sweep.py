@@ -15,7 +15,7 @@ C, Hp = 1024, 2752
 shapes = []   # (name, epi, M, N, K)
 for M in (6000, 3744):
     shapes += [("qkv", lib.EPI_BIAS, M, 3072, 1024), ("proj", lib.EPI_RESIDUAL, M, 1024, 1024),
-               ("w12", lib.EPI_SWIGLU, M, 2 * Hp, 1024), ("w3", lib.EPI_RESIDUAL, M, 1024, Hp)]
+               ("w3", lib.EPI_RESIDUAL, M, 1024, Hp)] + ([("w12", lib.EPI_SWIGLU, M, 2 * Hp, 1024)] if not os.environ.get("NO_SWIGLU") else [])
 variants = [int(v) for v in os.environ.get('VARIANTS', '16,17,19,38,39,40,41,42').split(',')]
 res = {}
 for name, epi, M, N, K in shapes:
