@@ -532,7 +532,7 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
     ref = None
-    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 110, 116, 126, 145, 147] + ([11, 12, 30, 31] if dt == lib.BF16 else [])):
+    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 49, 50, 110, 116, 126, 145, 147, 149] + ([11, 12, 30, 31] if dt == lib.BF16 else [])):
         out = torch.zeros(M, N, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, None, M, N, K, 0, S())
         if ref is None:
@@ -550,7 +550,7 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
     lib.call("toc3d_pack_swiglu", dt, rnd(Hd, K, seed=5, scale=K ** -0.5).to(DEV), rnd(Hd, K, seed=6, scale=K ** -0.5).to(DEV), rnd(Hd, seed=7).to(DEV),
              rnd(Hd, seed=8).to(DEV), Hd, K, w12, b12, Hp, K, S())
     ref_r = ref_s = None
-    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 110, 116, 126, 145, 147]):
+    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 49, 50, 110, 116, 126, 145, 147, 149]):
         o32 = torch.zeros(M, N, device=DEV)
         lib.call("toc3d_linear_ex", dt, lib.EPI_RESIDUAL, v, a_d, K, w_d, K, b.to(DEV), o32, N, res, N, 0, None, None, M, N, K, 0, S())
         ref_r = o32.clone() if ref_r is None else ref_r
@@ -689,7 +689,7 @@ def test_linear_unaligned_outputs_take_the_scalar_epilogue(name, dt, tdt):
         assert float(o32[:, N:].abs().sum()) == 0
 
 
-@pytest.mark.parametrize("variant", [1, 8, 10, 13, 14, 15, 16, 17, 22, 24, 26, 28, 29, 30, 45, 47, 116, 117, 126, 145, 147])
+@pytest.mark.parametrize("variant", [1, 8, 10, 13, 14, 15, 16, 17, 22, 24, 26, 28, 29, 30, 45, 47, 49, 116, 117, 126, 145, 147, 149])
 def test_every_tuned_gemm_pipeline_is_bit_stable_beside_attention(variant):
     """Each K-loop flavour the autotuner may pick (single buffer, rings of 2-4 stages, K-tiles of 32 / 64 / 128 / 256, 4 and 8
     wavefronts, banded order) launched repeatedly while the flash-attention kernel of another stream shares the CUs: regression

@@ -341,7 +341,7 @@ class _BackboneBase(nn.Module):
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
     _flush = None               # 256 MB scratch shared by all models: evicts L2 + Infinity Cache between tuning launches
-    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 110, 114, 116, 117, 126, 145, 147),
+    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 110, 114, 116, 117, 126, 145, 147, 149),
                  lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):

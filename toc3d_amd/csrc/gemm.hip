@@ -352,6 +352,8 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 46: launch_cfg<T, EPI, 128, 96, 2, 128, 2, 2, 1>(a, s); break;       // 128x96 double buffered, 56 KiB
         case 47: launch_cfg<T, EPI, 128, 192, 2, 128, 4, 2, 1>(a, s); break;      // 128x192 double buffered, 32x96 per wave (serves SwiGLU)
         case 48: launch_cfg<T, EPI, 128, 192, 3, 128, 2, 4, 1>(a, s); break;      // 128x192, 3-deep ring, 120 KiB
+        case 49: launch_cfg<T, EPI, 192, 128, 2, 128, 2, 4, 1>(a, s); break;      // 192x128 double buffered, 96x32 per wave (serves SwiGLU), 80 KiB
+        case 50: launch_cfg<T, EPI, 192, 128, 1, 128, 2, 4, 1>(a, s); break;      // 192x128 single buffer, 40 KiB
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;
