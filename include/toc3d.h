@@ -78,8 +78,12 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
  * 20 = 128x256, 21 = 256x256 (8 wavefronts, double buffer); 22-27 = K tiles of 128 / 256 elements (22: 128x128 K128,
  * 23: 128x128 K256, 24: 64x128 K256, 25: 128x128 K128 double buffer, 26: 64x128 K128, 27: 64x64 K256).  (1-7, 9-14, 27:
  * 4 wavefronts); 28/29 = 128x128 on 8 wavefronts with a 3-/4-deep ring, 30/31 = the same with 32-wide K tiles 4-/6-deep
- * (bf16), 32 = 256x128 3-deep, 33 = 128x64 on 8 wavefronts 4-deep.  variant + 100 = the same tile with the per-XCD band order (each XCD keeps its A row band in L2 and
- * walks the W panels once).  Every variant accumulates K in the same order: outputs are bit-identical across variants. */
+ * (bf16), 32 = 256x128 3-deep, 33 = 128x64 on 8 wavefronts 4-deep; 34-37 = 16-wavefront 256x128 / 256x256 / 128x256 tiles;
+ * 38/39 = 128x128 on 8 wavefronts with 32-wide K tiles 2-/3-deep, 40-42 = 128x256 / 256x128 single buffer and K32 rings;
+ * 43-48 = 128x192 and 128x96 tiles (43/44 single buffer, 45/46 double buffer, 47 = 128x192 with 32x96 per wavefront so that
+ * it serves SWIGLU, 48 = 3-deep); 49/50 = 192x128 double / single buffer.  A variant whose per-wavefront column slab is not a
+ * multiple of 32 cannot serve EPI_SWIGLU (error TOC3D_ERR_UNSUPPORTED).  variant + 100 = the same tile with the per-XCD band
+ * order (each XCD keeps its A row band in L2 and walks the W panels once).  Every variant accumulates K in the same order: outputs are bit-identical across variants. */
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
                     const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                     float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
