@@ -194,19 +194,21 @@ __global__ __launch_bounds__(256) void window_topk_kernel(const float* __restric
     extern __shared__ char s_raw[];
     const int N = L * L;
     float* s_sc = reinterpret_cast<float*>(s_raw);              // [N] score by slot
-    int32_t* s_tok = reinterpret_cast<int32_t*>(s_sc + N);       // [N] token row by slot
-    int32_t* s_ord = s_tok + N;                                  // [N] slot by rank
+    int32_t* s_pref = reinterpret_cast<int32_t*>(s_sc + N);      // [N] real tokens ranked before rank p
+    int32_t* s_ord = s_pref + N;                                 // [N] slot by rank
     float* s_red = reinterpret_cast<float*>(s_ord + N);          // [4] wave partials
-    int32_t* s_ired = reinterpret_cast<int32_t*>(s_red + 4);     // [8] int partials
+    int32_t* s_ired = reinterpret_cast<int32_t*>(s_red + 4);     // [8] int partials + [4] scan partials
     const int nWh = (h + L - 1) / L, nWw = (w + L - 1) / L;
     const int win = blockIdx.x;
     const int v = win / (nWh * nWw), wr = (win / nWw) % nWh, wc = win % nWw;
-    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    // token row of a window slot, -1 for a padded slot
+    auto slot_tok = [&](int j) -> int {
         const int r = wr * L + j / L, c = wc * L + j % L;
-        const bool real = r < h && c < w;
-        const int t = (v * h + r) * w + c;
-        s_sc[j] = real ? scores[t] : PAD_SCORE;
-        s_tok[j] = real ? t : -1;
+        return (r < h && c < w) ? (v * h + r) * w + c : -1;
+    };
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        const int t = slot_tok(j);
+        s_sc[j] = t >= 0 ? scores[t] : PAD_SCORE;
     }
     // compact-row offset of this window: sum of the (static) capacities of the windows before it
     int offp = 0;
@@ -226,8 +228,28 @@ __global__ __launch_bounds__(256) void window_topk_kernel(const float* __restric
     // number of real tokens among the kept; window offset
     float part = 0.f;
     for (int p = k + threadIdx.x; p < N; p += blockDim.x) part += s_sc[s_ord[p]];
+    // exclusive prefix count of real tokens by rank (block scan, 256 ranks per round)
     int nreal = 0;
-    for (int p = threadIdx.x; p < k; p += blockDim.x) nreal += s_tok[s_ord[p]] >= 0 ? 1 : 0;
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int carry = 0;
+        for (int base = 0; base < N; base += 256) {
+            const int p = base + (int)threadIdx.x;
+            const int f = (p < N && slot_tok(s_ord[p]) >= 0) ? 1 : 0;
+            if (p < k) nreal += f;
+            int x = f;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            if (lane == 63) s_ired[8 + wave] = x;
+            __syncthreads();
+            int woff = 0;
+            for (int i = 0; i < wave; ++i) woff += s_ired[8 + i];
+            const int tot = s_ired[8] + s_ired[9] + s_ired[10] + s_ired[11];
+            if (p < N) s_pref[p] = carry + woff + x - f;
+            carry += tot;
+            __syncthreads();
+        }
+    }
     part = wave_sum(part);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { nreal += __shfl_xor(nreal, o, 64); offp += __shfl_xor(offp, o, 64); }
@@ -241,14 +263,13 @@ __global__ __launch_bounds__(256) void window_topk_kernel(const float* __restric
     const int kk = k + 1;
     for (int p = threadIdx.x; p < N; p += blockDim.x) {
         const int slot = s_ord[p];
-        const int t = s_tok[slot];
+        const int t = slot_tok(slot);
         order[(int64_t)win * N + p] = slot;
         tok[(int64_t)win * N + p] = t;
         wgt[(int64_t)win * N + p] = p >= k ? s_sc[slot] / denom : 0.f;
         int pr = -1;
         if (p < k) {
-            int nr = 0;                                          // real tokens ranked before p
-            for (int q = 0; q < p; ++q) nr += s_tok[s_ord[q]] >= 0 ? 1 : 0;
+            const int nr = s_pref[p];                            // real tokens ranked before p
             int j;                                               // position in the window's key list
             if (t >= 0) j = nr;
             else { const int q = p - nr; j = q < e_w ? r_w + q : cap + (q - e_w); }
