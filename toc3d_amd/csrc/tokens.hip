@@ -155,21 +155,39 @@ __global__ __launch_bounds__(256) void ln_act_kernel(const T* __restrict__ x, in
 // ---------------------------------------------------------------------------------------------------
 // Ranking.  rank_j = #{i : s_i > s_j  or (s_i == s_j and i < j)}  == position of j in a stable descending sort.
 // ---------------------------------------------------------------------------------------------------
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+// One 64-bit key per slot whose unsigned order is the stable descending order: the score's bits made monotone
+// (-0 folded onto +0 so equal scores tie), then the complemented slot so the earlier slot wins a tie.
+TOC3D_DEV unsigned long long sort_key(float f, int i) {
+    unsigned int u = __float_as_uint(f + 0.0f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)i);
+}
+
+// number of keys in [lo, hi) that sort before kj; lo even, keys 16-byte aligned (one compare + one add per key)
+TOC3D_DEV int count_before(const unsigned long long* keys, int lo, int hi, unsigned long long kj) {
+    int r = 0, i = lo;
+    for (; i + 8 <= hi; i += 8) {
+        u64x2 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const u64x2*>(keys + i + 2 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r += (q[u].x > kj ? 1 : 0) + (q[u].y > kj ? 1 : 0);
+    }
+    for (; i < hi; ++i) r += keys[i] > kj ? 1 : 0;
+    return r;
+}
+
 __global__ __launch_bounds__(256) void rank_desc_kernel(const float* __restrict__ scores, int n, int64_t* __restrict__ order) {
-    extern __shared__ float s_sc[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
     const int b = blockIdx.y;
     const float* sc = scores + (int64_t)b * n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s_sc[i] = sc[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s_key[i] = sort_key(sc[i], i);
     __syncthreads();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const float sj = s_sc[j];
-    int rank = 0;
-    for (int i = 0; i < n; ++i) {
-        const float si = s_sc[i];
-        rank += (si > sj || (si == sj && i < j)) ? 1 : 0;
-    }
-    order[(int64_t)b * n + rank] = j;
+    order[(int64_t)b * n + count_before(s_key, 0, n, s_key[j])] = j;
 }
 
 // number of real (non-padded) slots of window `win` of side L over an h x w token grid
@@ -185,83 +203,102 @@ TOC3D_DEV int window_real_count(int win, int h, int w, int L) {
 // rows [off_i, off_i + cap_i) = kept real tokens (sorted order), then -- only if a real token ever lost against a pad,
 // which needs a log-prob <= -1e6 -- explicit zero rows, then the representative token.  The remaining kept pads are
 // *virtual attention keys* (arows = -1, RoPE slot in aslots): cap_i + virtual_i = k + 1 keys, cap_i queries.
-__global__ __launch_bounds__(256) void window_topk_kernel(const float* __restrict__ scores, int V, int h, int w, int L, int k,
-                                                          int32_t* __restrict__ order, int32_t* __restrict__ tok, float* __restrict__ wgt,
-                                                          int32_t* __restrict__ prow, int32_t* __restrict__ crow_tok,
-                                                          int32_t* __restrict__ rep_index, int32_t* __restrict__ rep_row,
-                                                          int32_t* __restrict__ arows, int32_t* __restrict__ aslots,
-                                                          int32_t* __restrict__ acount_q, int32_t* __restrict__ acount_k) {
-    extern __shared__ char s_raw[];
+// 1024 threads rank the window (up to eight threads share a slot's sweep over the keys); the first 256 then do the
+// bookkeeping, in the reduction orders the compact layout was validated with.
+__global__ __launch_bounds__(1024) void window_topk_kernel(const float* __restrict__ scores, int V, int h, int w, int L, int k,
+                                                           int32_t* __restrict__ order, int32_t* __restrict__ tok, float* __restrict__ wgt,
+                                                           int32_t* __restrict__ prow, int32_t* __restrict__ crow_tok,
+                                                           int32_t* __restrict__ rep_index, int32_t* __restrict__ rep_row,
+                                                           int32_t* __restrict__ arows, int32_t* __restrict__ aslots,
+                                                           int32_t* __restrict__ acount_q, int32_t* __restrict__ acount_k) {
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    constexpr int WORKERS = 256;
     const int N = L * L;
-    float* s_sc = reinterpret_cast<float*>(s_raw);              // [N] score by slot
-    int32_t* s_pref = reinterpret_cast<int32_t*>(s_sc + N);      // [N] real tokens ranked before rank p
+    const int Ne = (N + 1) & ~1;
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_raw);   // [N] sort key by slot
+    float* s_sc = reinterpret_cast<float*>(s_key + Ne);          // [N] score by slot
+    int32_t* s_pref = reinterpret_cast<int32_t*>(s_sc + N);      // [N] rank by slot, then real tokens ranked before rank p
     int32_t* s_ord = s_pref + N;                                 // [N] slot by rank
     float* s_red = reinterpret_cast<float*>(s_ord + N);          // [4] wave partials
     int32_t* s_ired = reinterpret_cast<int32_t*>(s_red + 4);     // [8] int partials + [4] scan partials
     const int nWh = (h + L - 1) / L, nWw = (w + L - 1) / L;
     const int win = blockIdx.x;
     const int v = win / (nWh * nWw), wr = (win / nWw) % nWh, wc = win % nWw;
+    const int tid = threadIdx.x;
+    const bool worker = tid < WORKERS;
     // token row of a window slot, -1 for a padded slot
     auto slot_tok = [&](int j) -> int {
         const int r = wr * L + j / L, c = wc * L + j % L;
         return (r < h && c < w) ? (v * h + r) * w + c : -1;
     };
-    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    for (int j = tid; j < N; j += blockDim.x) {
         const int t = slot_tok(j);
-        s_sc[j] = t >= 0 ? scores[t] : PAD_SCORE;
+        const float sc = t >= 0 ? scores[t] : PAD_SCORE;
+        s_sc[j] = sc;
+        s_key[j] = sort_key(sc, j);
+        s_pref[j] = 0;
     }
     // compact-row offset of this window: sum of the (static) capacities of the windows before it
     int offp = 0;
-    for (int i = threadIdx.x; i < win; i += blockDim.x) offp += min(k, window_real_count(i, h, w, L)) + 1;
+    if (worker)
+        for (int i = tid; i < win; i += WORKERS) offp += min(k, window_real_count(i, h, w, L)) + 1;
     __syncthreads();
-    for (int j = threadIdx.x; j < N; j += blockDim.x) {
-        const float sj = s_sc[j];
-        int rank = 0;
-        for (int i = 0; i < N; ++i) {
-            const float si = s_sc[i];
-            rank += (si > sj || (si == sj && i < j)) ? 1 : 0;
+    // rank of slot j = number of slots that sort before it (descending score, ties by slot): `parts` threads per
+    // slot each count over one slice of the keys and add into the slot's rank (integer LDS atomics)
+    {
+        const int parts = max(1, min(8, (int)blockDim.x / N));
+        const int chunk = (((N + parts - 1) / parts) + 1) & ~1;
+        for (int id = tid; id < N * parts; id += blockDim.x) {
+            const int j = id % N, part = id / N;
+            const int lo = part * chunk, hi = min(N, lo + chunk);
+            if (lo < hi) atomicAdd(&s_pref[j], count_before(s_key, lo, hi, s_key[j]));
         }
-        s_ord[rank] = j;
     }
+    __syncthreads();
+    for (int j = tid; j < N; j += blockDim.x) s_ord[s_pref[j]] = j;
     __syncthreads();
     // denominator of merge_tokens: sum of the fast (dropped) scores, pads included (toc3d_utils.py:68);
     // number of real tokens among the kept; window offset
     float part = 0.f;
-    for (int p = k + threadIdx.x; p < N; p += blockDim.x) part += s_sc[s_ord[p]];
-    // exclusive prefix count of real tokens by rank (block scan, 256 ranks per round)
+    if (worker)
+        for (int p = k + tid; p < N; p += WORKERS) part += s_sc[s_ord[p]];
+    // exclusive prefix count of real tokens by rank (block scan over the workers, 256 ranks per round)
     int nreal = 0;
     {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = tid & 63, wave = tid >> 6;
         int carry = 0;
-        for (int base = 0; base < N; base += 256) {
-            const int p = base + (int)threadIdx.x;
-            const int f = (p < N && slot_tok(s_ord[p]) >= 0) ? 1 : 0;
+        for (int base = 0; base < N; base += WORKERS) {
+            const int p = base + tid;
+            const int f = (worker && p < N && slot_tok(s_ord[p]) >= 0) ? 1 : 0;
             if (p < k) nreal += f;
             int x = f;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-            if (lane == 63) s_ired[8 + wave] = x;
+            if (worker && lane == 63) s_ired[8 + wave] = x;
             __syncthreads();
-            int woff = 0;
-            for (int i = 0; i < wave; ++i) woff += s_ired[8 + i];
-            const int tot = s_ired[8] + s_ired[9] + s_ired[10] + s_ired[11];
-            if (p < N) s_pref[p] = carry + woff + x - f;
-            carry += tot;
+            if (worker) {
+                int woff = 0;
+                for (int i = 0; i < wave; ++i) woff += s_ired[8 + i];
+                const int tot = s_ired[8] + s_ired[9] + s_ired[10] + s_ired[11];
+                if (p < N) s_pref[p] = carry + woff + x - f;
+                carry += tot;
+            }
             __syncthreads();
         }
     }
     part = wave_sum(part);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { nreal += __shfl_xor(nreal, o, 64); offp += __shfl_xor(offp, o, 64); }
-    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = part; s_ired[threadIdx.x >> 6] = nreal; s_ired[4 + (threadIdx.x >> 6)] = offp; }
+    if (worker && (tid & 63) == 0) { s_red[tid >> 6] = part; s_ired[tid >> 6] = nreal; s_ired[4 + (tid >> 6)] = offp; }
     __syncthreads();
+    if (!worker) return;
     const float denom = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     const int r_w = s_ired[0] + s_ired[1] + s_ired[2] + s_ired[3];
     const int off = s_ired[4] + s_ired[5] + s_ired[6] + s_ired[7];
     const int cap = min(k, window_real_count(win, h, w, L)) + 1;
     const int e_w = cap - 1 - r_w;                               // explicit zero rows (0 unless a real token scored <= -1e6)
     const int kk = k + 1;
-    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+    for (int p = tid; p < N; p += WORKERS) {
         const int slot = s_ord[p];
         const int t = slot_tok(slot);
         order[(int64_t)win * N + p] = slot;
@@ -283,7 +320,7 @@ __global__ __launch_bounds__(256) void window_topk_kernel(const float* __restric
         }
         prow[(int64_t)win * N + p] = pr;
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const int rr = off + cap - 1;                            // representative token: last row of the window, RoPE slot k
         crow_tok[rr] = -2;
         rep_index[rr] = win;
@@ -531,7 +568,9 @@ int toc3d_rank_desc(const float* scores, int64_t B, int64_t n, int64_t* order, t
     TOC3D_REQUIRE(n >= 0 && n <= 16000, "toc3d_rank_desc: n=%lld exceeds the LDS-resident limit 16000", (long long)n);
     if (B <= 0 || n == 0) return TOC3D_OK;
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)B);
-    hipLaunchKernelGGL(rank_desc_kernel, grid, dim3(256), (size_t)n * 4, as_stream(stream), scores, (int)n, order);
+    const size_t lds = (size_t)n * 8;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_desc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(rank_desc_kernel, grid, dim3(256), lds, as_stream(stream), scores, (int)n, order);
     TOC3D_LAUNCH_CHECK("toc3d_rank_desc");
     return TOC3D_OK;
 }
@@ -557,7 +596,9 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
     const int64_t N = L * L;
     TOC3D_REQUIRE(k >= 0 && k < N, "toc3d_window_topk: k=%lld outside [0, %lld) (keep-all is the dense Block path)", (long long)k, (long long)N);
     const int nW = (int)(V * ((h + L - 1) / L) * ((w + L - 1) / L));
-    hipLaunchKernelGGL(window_topk_kernel, dim3(nW), dim3(256), (size_t)N * 12 + 64, as_stream(stream), scores, (int)V, (int)h, (int)w,
+    const size_t lds = (size_t)((N + 1) & ~(int64_t)1) * 8 + (size_t)N * 12 + 64;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipLaunchKernelGGL(window_topk_kernel, dim3(nW), dim3(1024), lds, as_stream(stream), scores, (int)V, (int)h, (int)w,
                        (int)L, (int)k, order, tok, wgt, prow, crow_tok, rep_index, rep_row, arows, aslots, acount_q, acount_k);
     TOC3D_LAUNCH_CHECK("toc3d_window_topk");
     return TOC3D_OK;

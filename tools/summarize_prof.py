@@ -12,7 +12,7 @@ out = os.path.join(root, "gpurun_out")
 
 
 def family(name):
-    for key in ("gemm_kernel", "attn_small_kernel", "attn_kernel", "ln_rows_kernel", "ln_act_kernel", "gather_merge_ln_kernel", "scatter_update_kernel",
+    for key in ("gemm_kernel", "attn_small_kernel", "attn_kernel", "ln_rows_kernel", "ln_act_kernel", "ln_rebase_kernel", "gather_merge_ln_kernel", "scatter_update_kernel",
                 "window_topk_kernel", "rank_desc_kernel", "motion_queries_kernel", "collapse_kernel", "score_tokens_kernel", "im2col", "nhwc_to_nchw",
                 "abs_pos", "pack_", "window_map_dense", "score_head", "global_mean_half"):
         if key in name:
