@@ -63,130 +63,196 @@ TOC3D_DEV float block_sum256(float v, float* s_red) {
     return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// ---- motion-aware queries: one 1024-thread workgroup per query.  Thread (t, part): t = output feature (256),
-// part = quarter of the input range it accumulates; the four partial dot products are combined through LDS in a
-// fixed order, so the result is deterministic.  The matvecs are L2-latency bound; the 4-way split cuts the
-// dependent chain 4x.
-TOC3D_DEV float matvec256(const float* __restrict__ Wt, const float* __restrict__ b, const float* in, int n_in, int t, int part,
-                          float (*s_mv)[QD]) {
-    float acc = 0.f;
-    for (int i = part; i < n_in; i += 4) acc = fmaf(in[i], Wt[(int64_t)i * QD + t], acc);
+// ---- motion-aware queries: one 1024-thread workgroup per QB queries.  Thread (t, part): t = output feature (256),
+// part = the input indices i = part (mod 4) it accumulates, for all QB queries at once: each weight is fetched once
+// per workgroup and used QB times (the matvecs were L2-bandwidth bound at one query per workgroup: 2.3 MB of weights
+// each).  Inputs sit in LDS as [i][QB] so one 32-byte read feeds the QB FMAs of a weight; weights are fetched eight
+// rows ahead of the FMAs.  Per query the arithmetic (FMA order, the fixed-order 4-way combine, the LN reductions) is
+// the same as with one query per workgroup, so results do not depend on QB or on the grouping.
+constexpr int QB = 8;
+
+TOC3D_DEV void matvec256(const float* __restrict__ Wt, const float* __restrict__ b, const float (*in)[QB], int n_in, int t, int part,
+                         float (*s_mv)[4][QD], float (&res)[QB]) {
+    float acc[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) acc[q] = 0.f;
+    int i = part;
+    for (; i + 28 < n_in; i += 32) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = Wt[(int64_t)(i + 4 * u) * QD + t];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(&in[i + 4 * u][0]), hi = *reinterpret_cast<const f32x4*>(&in[i + 4 * u][4]);
+            acc[0] = fmaf(lo.x, wv[u], acc[0]); acc[1] = fmaf(lo.y, wv[u], acc[1]); acc[2] = fmaf(lo.z, wv[u], acc[2]); acc[3] = fmaf(lo.w, wv[u], acc[3]);
+            acc[4] = fmaf(hi.x, wv[u], acc[4]); acc[5] = fmaf(hi.y, wv[u], acc[5]); acc[6] = fmaf(hi.z, wv[u], acc[6]); acc[7] = fmaf(hi.w, wv[u], acc[7]);
+        }
+    }
+    for (; i < n_in; i += 4) {
+        const float wv = Wt[(int64_t)i * QD + t];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) acc[q] = fmaf(in[i][q], wv, acc[q]);
+    }
     __syncthreads();
-    s_mv[part][t] = acc;
+#pragma unroll
+    for (int q = 0; q < QB; ++q) s_mv[q][part][t] = acc[q];
     __syncthreads();
-    return ((s_mv[0][t] + s_mv[1][t]) + (s_mv[2][t] + s_mv[3][t])) + b[t];
+    const float bt = b[t];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) res[q] = ((s_mv[q][0][t] + s_mv[q][1][t]) + (s_mv[q][2][t] + s_mv[q][3][t])) + bt;
 }
 
-// sum over the 256 features (each held identically by the 4 `part` copies; only part 0 contributes)
-TOC3D_DEV float feat_sum(float v, int part, float* s_red) {
-    v = wave_sum(part == 0 ? v : 0.f);
+// per query: sum over the 256 features (each held identically by the 4 `part` copies; only part 0 contributes)
+TOC3D_DEV void feat_sum(const float (&v)[QB], int part, float (*s_red)[4], float (&out)[QB]) {
+    float w[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) w[q] = wave_sum(part == 0 ? v[q] : 0.f);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    if (part == 0 && (threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q) s_red[q][threadIdx.x >> 6] = w[q];                     // part 0 = waves 0..3
+    }
     __syncthreads();
-    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);       // part 0 = waves 0..3
+#pragma unroll
+    for (int q = 0; q < QB; ++q) out[q] = (s_red[q][0] + s_red[q][1]) + (s_red[q][2] + s_red[q][3]);
 }
 
-TOC3D_DEV float ln256_noaffine(float v, float eps, int part, float* s_red) {
-    const float mean = feat_sum(v, part, s_red) * (1.0f / QD);
-    const float d = v - mean;
-    const float var = feat_sum(d * d, part, s_red) * (1.0f / QD);
-    return d * (1.0f / sqrtf(var + eps));
+TOC3D_DEV void ln256_noaffine(const float (&v)[QB], float eps, int part, float (*s_red)[4], float (&out)[QB]) {
+    float m[QB], d[QB], dd[QB], var[QB];
+    feat_sum(v, part, s_red, m);
+#pragma unroll
+    for (int q = 0; q < QB; ++q) { d[q] = v[q] - m[q] * (1.0f / QD); dd[q] = d[q] * d[q]; }
+    feat_sum(dd, part, s_red, var);
+#pragma unroll
+    for (int q = 0; q < QB; ++q) out[q] = d[q] * (1.0f / sqrtf(var[q] * (1.0f / QD) + eps));
 }
 
 __global__ __launch_bounds__(1024) void motion_queries_kernel(const float* __restrict__ w_all, int64_t w_stride, const float* __restrict__ queries,
                                                               const float* __restrict__ ref, const float* __restrict__ vel,
                                                               const void* __restrict__ ts, int ts_f64, const float* __restrict__ pose,
-                                                              const float* __restrict__ pose_inv, int Q, int BQ, float* __restrict__ out) {
-    __shared__ float s_emb[PE3];
-    __shared__ float s_h[QD];
-    __shared__ float s_e[MD + 12];
-    __shared__ float s_mv[4][QD];
-    __shared__ float s_red[16];
-    __shared__ float s_pts[4];
-    const int stage = blockIdx.x / BQ, bq = blockIdx.x % BQ, b = bq / Q;
+                                                              const float* __restrict__ pose_inv, int Q, int BQ, int groups,
+                                                              float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_emb[PE3][QB];
+    __shared__ __attribute__((aligned(16))) float s_h[QD][QB];
+    __shared__ __attribute__((aligned(16))) float s_e[MD + 12][QB];
+    __shared__ float s_mv[QB][4][QD];
+    __shared__ float s_red[QB][4];
+    __shared__ float s_pts[QB][4];
+    __shared__ float s_ego[QB][16];
+    const int stage = blockIdx.x / groups, bq0 = (blockIdx.x % groups) * QB;
     const int t = threadIdx.x & 255, part = threadIdx.x >> 8;
     const float* w = w_all + (int64_t)stage * w_stride;
     out += (int64_t)stage * BQ * QD;
     const float kTorchLnEps = 1e-5f;
     const float two_pi = 6.283185307179586f;              // float(2 * math.pi)
+    // a short last group repeats its last query in the unused lanes (computed, never written)
+    auto query_of = [&](int q) { return min(bq0 + q, BQ - 1); };
 
     // 1. reference points -> current ego frame -> normalised by pc_range (misc.py:191-200, toc3d_utils.py:346-348)
-    if (threadIdx.x < 3) {
-        const int c = threadIdx.x;
-        const float* m = pose_inv + (int64_t)b * 16 + c * 4;
+    if (threadIdx.x < 4 * QB && (threadIdx.x & 3) < 3) {
+        const int q = threadIdx.x >> 2, c = threadIdx.x & 3, bq = query_of(q);
+        const float* m = pose_inv + (int64_t)(bq / Q) * 16 + c * 4;
         const float* p = ref + (int64_t)bq * 3;
         const float v = ((m[0] * p[0] + m[1] * p[1]) + m[2] * p[2]) + m[3];
         const float* pc = w + MW::pc_range;
-        s_pts[c] = (v - pc[c]) / (pc[3 + c] - pc[c]);
+        s_pts[q][c] = (v - pc[c]) / (pc[3 + c] - pc[c]);
     }
-    // 3a. ego-motion vector [vel(2), t(1), pose[:3,:](12)] as f32 (toc3d_utils.py:351), staged in s_h[0..14]
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 15) {
-        const int j = threadIdx.x - 64;
+    // 3a. ego-motion vector [vel(2), t(1), pose[:3,:](12)] as f32 (toc3d_utils.py:351)
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 16 * QB && ((threadIdx.x - 64) & 15) < 15) {
+        const int q = (threadIdx.x - 64) >> 4, j = (threadIdx.x - 64) & 15, bq = query_of(q);
         float v;
         if (j < 2) v = vel[(int64_t)bq * 2 + j];
         else if (j == 2) v = ts_f64 ? (float)reinterpret_cast<const double*>(ts)[bq] : reinterpret_cast<const float*>(ts)[bq];
         else v = pose[(int64_t)bq * 16 + (j - 3)];
-        s_h[j] = v;
+        s_ego[q][j] = v;
     }
     __syncthreads();
     // 2. pos2posemb3d, concatenated (y, x, z) (positional_encoding.py:14-26)
-    for (int i = threadIdx.x; i < PE3; i += 1024) {
+    for (int e = threadIdx.x; e < PE3 * QB; e += 1024) {
+        const int i = e / QB, q = e % QB;
         const int blk = i >> 7, f = i & 127;
         const int coord = blk == 0 ? 1 : (blk == 1 ? 0 : 2);
-        const float a = (s_pts[coord] * two_pi) / w[MW::dimt3 + f];
-        s_emb[i] = (f & 1) ? cosf(a) : sinf(a);
+        const float a = (s_pts[q][coord] * two_pi) / w[MW::dimt3 + f];
+        s_emb[i][q] = (f & 1) ? cosf(a) : sinf(a);
     }
     // 3b. NeRF encoding, frequency-major: [sin(2^k e), cos(2^k e)] for k = 0..5 (positional_encoding.py:73-75)
-    if (threadIdx.x >= 512 && threadIdx.x < 512 + MD) {
-        const int i = threadIdx.x - 512;
+    for (int e = threadIdx.x; e < MD * QB; e += 1024) {
+        const int i = e / QB, q = e % QB;
         const int k = i / 30, r = i % 30;
-        const float a = s_h[r % 15] * (float)(1 << k);
-        s_e[i] = r < 15 ? sinf(a) : cosf(a);
+        const float a = s_ego[q][r % 15] * (float)(1 << k);
+        s_e[i][q] = r < 15 ? sinf(a) : cosf(a);
     }
     __syncthreads();
+    float pos[QB], tmp[QB], gam[QB], bet[QB], nrm[QB];
     // query_embedding: Linear(384,256) - ReLU - Linear(256,256) (toc3d_utils.py:322-326,349)
-    const float h1 = fmaxf(matvec256(w + MW::qe0_w, w + MW::qe0_b, s_emb, PE3, t, part, s_mv), 0.f);
+    matvec256(w + MW::qe0_w, w + MW::qe0_b, s_emb, PE3, t, part, s_mv, tmp);
     __syncthreads();
-    s_h[t] = h1;
+    if (part == 0) {
+#pragma unroll
+        for (int q = 0; q < QB; ++q) s_h[t][q] = fmaxf(tmp[q], 0.f);
+    }
     __syncthreads();
-    float pos = matvec256(w + MW::qe2_w, w + MW::qe2_b, s_h, QD, t, part, s_mv);
+    matvec256(w + MW::qe2_w, w + MW::qe2_b, s_h, QD, t, part, s_mv, pos);
     // MLN over pos (misc.py:181-188)
     {
-        const float hr = fmaxf(matvec256(w + MW::pe_red_w, w + MW::pe_red_b, s_e, MD, t, part, s_mv), 0.f);
+        matvec256(w + MW::pe_red_w, w + MW::pe_red_b, s_e, MD, t, part, s_mv, tmp);
         __syncthreads();
-        s_h[t] = hr;
+        if (part == 0) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) s_h[t][q] = fmaxf(tmp[q], 0.f);
+        }
         __syncthreads();
-        const float gam = matvec256(w + MW::pe_gam_w, w + MW::pe_gam_b, s_h, QD, t, part, s_mv);
-        const float bet = matvec256(w + MW::pe_bet_w, w + MW::pe_bet_b, s_h, QD, t, part, s_mv);
-        pos = gam * ln256_noaffine(pos, kTorchLnEps, part, s_red) + bet;
+        matvec256(w + MW::pe_gam_w, w + MW::pe_gam_b, s_h, QD, t, part, s_mv, gam);
+        matvec256(w + MW::pe_bet_w, w + MW::pe_bet_b, s_h, QD, t, part, s_mv, bet);
+        ln256_noaffine(pos, kTorchLnEps, part, s_red, nrm);
+#pragma unroll
+        for (int q = 0; q < QB; ++q) pos[q] = gam[q] * nrm[q] + bet[q];
     }
     // time embedding: pos2posemb1d in the timestamp's dtype (f64 when the head promoted it), then .float()
     {
-        float e;
         const float dt = w[MW::dimt1 + t];
-        if (ts_f64) {
-            const double a = (reinterpret_cast<const double*>(ts)[bq] * 6.283185307179586) / (double)dt;
-            e = (float)((t & 1) ? cos(a) : sin(a));
-        } else {
-            const float a = (reinterpret_cast<const float*>(ts)[bq] * two_pi) / dt;
-            e = (t & 1) ? cosf(a) : sinf(a);
+        __syncthreads();
+        {
+#pragma unroll 1
+            for (int qq = 0; qq < QB / 4; ++qq) {                // two queries' embeddings per thread
+                const int q = part * (QB / 4) + qq, bq = query_of(q);
+                float e;
+                if (ts_f64) {
+                    const double a = (reinterpret_cast<const double*>(ts)[bq] * 6.283185307179586) / (double)dt;
+                    e = (float)((t & 1) ? cos(a) : sin(a));
+                } else {
+                    const float a = (reinterpret_cast<const float*>(ts)[bq] * two_pi) / dt;
+                    e = (t & 1) ? cosf(a) : sinf(a);
+                }
+                s_emb[t][q] = e;
+            }
         }
         __syncthreads();
-        s_emb[t] = e;
-        __syncthreads();
-        const float te = matvec256(w + MW::te_w, w + MW::te_b, s_emb, QD, t, part, s_mv);
-        pos += ln256_noaffine(te, kTorchLnEps, part, s_red) * w[MW::te_ln_w + t] + w[MW::te_ln_b + t];
+        matvec256(w + MW::te_w, w + MW::te_b, s_emb, QD, t, part, s_mv, tmp);
+        ln256_noaffine(tmp, kTorchLnEps, part, s_red, nrm);
+        const float lw = w[MW::te_ln_w + t], lb = w[MW::te_ln_b + t];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) pos[q] += nrm[q] * lw + lb;
     }
     // MLN over the memory queries, then add pos (toc3d_utils.py:356-358)
     {
-        const float hr = fmaxf(matvec256(w + MW::q_red_w, w + MW::q_red_b, s_e, MD, t, part, s_mv), 0.f);
+        matvec256(w + MW::q_red_w, w + MW::q_red_b, s_e, MD, t, part, s_mv, tmp);
         __syncthreads();
-        s_h[t] = hr;
+        if (part == 0) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q) s_h[t][q] = fmaxf(tmp[q], 0.f);
+        }
         __syncthreads();
-        const float gam = matvec256(w + MW::q_gam_w, w + MW::q_gam_b, s_h, QD, t, part, s_mv);
-        const float bet = matvec256(w + MW::q_bet_w, w + MW::q_bet_b, s_h, QD, t, part, s_mv);
-        const float qn = ln256_noaffine(queries[(int64_t)bq * QD + t], kTorchLnEps, part, s_red);
-        if (part == 0) out[(int64_t)bq * QD + t] = (gam * qn + bet) + pos;
+        matvec256(w + MW::q_gam_w, w + MW::q_gam_b, s_h, QD, t, part, s_mv, gam);
+        matvec256(w + MW::q_bet_w, w + MW::q_bet_b, s_h, QD, t, part, s_mv, bet);
+#pragma unroll
+        for (int q = 0; q < QB; ++q) tmp[q] = queries[(int64_t)query_of(q) * QD + t];
+        ln256_noaffine(tmp, kTorchLnEps, part, s_red, nrm);
+        if (part == 0) {
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+                if (bq0 + q < BQ) out[(int64_t)(bq0 + q) * QD + t] = (gam[q] * nrm[q] + bet[q]) + pos[q];
+        }
     }
 }
 
@@ -198,7 +264,18 @@ __global__ __launch_bounds__(256) void collapse_kernel(const float* __restrict__
     __shared__ float s_red[4];
     const int b = blockIdx.y, t = threadIdx.x;
     float u0 = 0.f, u1 = 0.f;
-    for (int q = 0; q < Q; ++q) {
+    int q = 0;
+    for (; q + 8 <= Q; q += 8) {                 // eight rows in flight; the FMA order is the plain q order
+        float m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = mq[((int64_t)b * Q + q + u) * QD + t];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            u0 = fmaf(m[u], w_agg[q + u], u0);
+            u1 = fmaf(m[u], w_agg[Q + q + u], u1);
+        }
+    }
+    for (; q < Q; ++q) {
         const float m = mq[((int64_t)b * Q + q) * QD + t];
         u0 = fmaf(m, w_agg[q], u0);
         u1 = fmaf(m, w_agg[Q + q], u1);
@@ -209,10 +286,15 @@ __global__ __launch_bounds__(256) void collapse_kernel(const float* __restrict__
     const int i = blockIdx.x * 256 + t;
     if (i < C) {
         float a0 = 0.f, a1 = 0.f;
-        for (int c = 0; c < QD; ++c) {
-            const float wv = w_in[(int64_t)c * C + i];
-            a0 = fmaf(wv, s_u[c][0], a0);
-            a1 = fmaf(wv, s_u[c][1], a1);
+        for (int c = 0; c < QD; c += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w_in[(int64_t)(c + u) * C + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a0 = fmaf(wv[u], s_u[c + u][0], a0);
+                a1 = fmaf(wv[u], s_u[c + u][1], a1);
+            }
         }
         wc[((int64_t)b * C + i) * 2 + 0] = a0 * scale;
         wc[((int64_t)b * C + i) * 2 + 1] = a1 * scale;
@@ -391,8 +473,9 @@ int toc3d_motion_queries(const float* w, int64_t n_stages, int64_t w_stride, con
     TOC3D_REQUIRE(w && queries && ref_points && vel && timestamp && ego_pose && ego_pose_inv && out, "toc3d_motion_queries: null buffer");
     TOC3D_REQUIRE(n_stages >= 1 && (n_stages == 1 || w_stride >= MW::total), "toc3d_motion_queries: bad n_stages / w_stride");
     if (B <= 0 || Q <= 0) return TOC3D_OK;
-    hipLaunchKernelGGL(motion_queries_kernel, dim3((unsigned)(n_stages * B * Q)), dim3(1024), 0, as_stream(stream), w, w_stride, queries, ref_points, vel,
-                       timestamp, timestamp_is_f64, ego_pose, ego_pose_inv, (int)Q, (int)(B * Q), out);
+    const int64_t groups = (B * Q + QB - 1) / QB;
+    hipLaunchKernelGGL(motion_queries_kernel, dim3((unsigned)(n_stages * groups)), dim3(1024), 0, as_stream(stream), w, w_stride, queries, ref_points, vel,
+                       timestamp, timestamp_is_f64, ego_pose, ego_pose_inv, (int)Q, (int)(B * Q), (int)groups, out);
     TOC3D_LAUNCH_CHECK("toc3d_motion_queries");
     return TOC3D_OK;
 }
