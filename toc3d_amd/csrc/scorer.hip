@@ -66,33 +66,36 @@ TOC3D_DEV float block_sum256(float v, float* s_red) {
 // ---- motion-aware queries: one 1024-thread workgroup per QB queries.  Thread (t, part): t = output feature (256),
 // part = the input indices i = part (mod 4) it accumulates, for all QB queries at once: each weight is fetched once
 // per workgroup and used QB times (the matvecs were L2-bandwidth bound at one query per workgroup: 2.3 MB of weights
-// each).  Inputs sit in LDS as [i][QB] so one 32-byte read feeds the QB FMAs of a weight; weights are fetched eight
+// each).  Inputs sit in LDS as [i][QB] so one 32-byte read feeds the QB FMAs of a weight; weights are fetched sixteen
 // rows ahead of the FMAs.  Per query the arithmetic (FMA order, the fixed-order 4-way combine, the LN reductions) is
 // the same as with one query per workgroup, so results do not depend on QB or on the grouping.
 constexpr int QB = 8;
 
+// R weight rows (i, i+4, ...) fetched together, then their FMAs in row order
+template <int R>
+TOC3D_DEV void matvec_rows(const float* __restrict__ Wt, const float (*in)[QB], int i, int t, float (&acc)[QB]) {
+    float wv[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) wv[u] = Wt[(int64_t)(i + 4 * u) * QD + t];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&in[i + 4 * u][0]), hi = *reinterpret_cast<const f32x4*>(&in[i + 4 * u][4]);
+        acc[0] = fmaf(lo.x, wv[u], acc[0]); acc[1] = fmaf(lo.y, wv[u], acc[1]); acc[2] = fmaf(lo.z, wv[u], acc[2]); acc[3] = fmaf(lo.w, wv[u], acc[3]);
+        acc[4] = fmaf(hi.x, wv[u], acc[4]); acc[5] = fmaf(hi.y, wv[u], acc[5]); acc[6] = fmaf(hi.z, wv[u], acc[6]); acc[7] = fmaf(hi.w, wv[u], acc[7]);
+    }
+}
+
 TOC3D_DEV void matvec256(const float* __restrict__ Wt, const float* __restrict__ b, const float (*in)[QB], int n_in, int t, int part,
                          float (*s_mv)[4][QD], float (&res)[QB]) {
+    static_assert(QB == 8, "matvec_rows reads the eight queries of a row as two float4");
     float acc[QB];
 #pragma unroll
     for (int q = 0; q < QB; ++q) acc[q] = 0.f;
     int i = part;
-    for (; i + 28 < n_in; i += 32) {
-        float wv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = Wt[(int64_t)(i + 4 * u) * QD + t];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(&in[i + 4 * u][0]), hi = *reinterpret_cast<const f32x4*>(&in[i + 4 * u][4]);
-            acc[0] = fmaf(lo.x, wv[u], acc[0]); acc[1] = fmaf(lo.y, wv[u], acc[1]); acc[2] = fmaf(lo.z, wv[u], acc[2]); acc[3] = fmaf(lo.w, wv[u], acc[3]);
-            acc[4] = fmaf(hi.x, wv[u], acc[4]); acc[5] = fmaf(hi.y, wv[u], acc[5]); acc[6] = fmaf(hi.z, wv[u], acc[6]); acc[7] = fmaf(hi.w, wv[u], acc[7]);
-        }
-    }
-    for (; i < n_in; i += 4) {
-        const float wv = Wt[(int64_t)i * QD + t];
-#pragma unroll
-        for (int q = 0; q < QB; ++q) acc[q] = fmaf(in[i][q], wv, acc[q]);
-    }
+    for (; i + 4 * 15 < n_in; i += 4 * 16) matvec_rows<16>(Wt, in, i, t, acc);
+    if (i + 4 * 7 < n_in) { matvec_rows<8>(Wt, in, i, t, acc); i += 4 * 8; }
+    if (i + 4 * 3 < n_in) { matvec_rows<4>(Wt, in, i, t, acc); i += 4 * 4; }
+    for (; i < n_in; i += 4) matvec_rows<1>(Wt, in, i, t, acc);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < QB; ++q) s_mv[q][part][t] = acc[q];
@@ -265,12 +268,12 @@ __global__ __launch_bounds__(256) void collapse_kernel(const float* __restrict__
     const int b = blockIdx.y, t = threadIdx.x;
     float u0 = 0.f, u1 = 0.f;
     int q = 0;
-    for (; q + 8 <= Q; q += 8) {                 // eight rows in flight; the FMA order is the plain q order
-        float m[8];
+    for (; q + 16 <= Q; q += 16) {               // sixteen rows in flight; the FMA order is the plain q order
+        float m[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) m[u] = mq[((int64_t)b * Q + q + u) * QD + t];
+        for (int u = 0; u < 16; ++u) m[u] = mq[((int64_t)b * Q + q + u) * QD + t];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             u0 = fmaf(m[u], w_agg[q + u], u0);
             u1 = fmaf(m[u], w_agg[Q + q + u], u1);
         }
@@ -286,12 +289,12 @@ __global__ __launch_bounds__(256) void collapse_kernel(const float* __restrict__
     const int i = blockIdx.x * 256 + t;
     if (i < C) {
         float a0 = 0.f, a1 = 0.f;
-        for (int c = 0; c < QD; c += 8) {
-            float wv[8];
+        for (int c = 0; c < QD; c += 16) {
+            float wv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) wv[u] = w_in[(int64_t)(c + u) * C + i];
+            for (int u = 0; u < 16; ++u) wv[u] = w_in[(int64_t)(c + u) * C + i];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 a0 = fmaf(wv[u], s_u[c + u][0], a0);
                 a1 = fmaf(wv[u], s_u[c + u][1], a1);
             }
