@@ -933,15 +933,16 @@ class ToC3DEVAViT(_BackboneBase):
         for g, gp in enumerate(groups):
             with torch.cuda.stream(streams[g]):
                 self._join_side(gp)
+                if len(groups) > 1:
+                    # private per-group buffers -> the contiguous outputs, on the group's own stream (write-only, disjoint
+                    # bytes; nothing reads the shared buffers before the join below)
+                    v0, nv = gp["v0"], gp["nv"]
+                    for st_ in range(ns):
+                        plan["mask"][st_][v0 * T:(v0 + nv) * T].copy_(gp["mask"][st_])
+                        plan["order"][st_][v0:v0 + nv].copy_(gp["order"][st_])
         self._join(streams)
         if prev and ns and plan["prep"]["ev"] is not None:
             torch.cuda.current_stream().wait_event(plan["prep"]["ev"])      # keeps the side stream joined (graph capture)
-        if len(groups) > 1:
-            for gp in groups:                                                # private per-group buffers -> contiguous outputs
-                v0, nv = gp["v0"], gp["nv"]
-                for st_ in range(ns):
-                    plan["mask"][st_][v0 * T:(v0 + nv) * T].copy_(gp["mask"][st_])
-                    plan["order"][st_][v0:v0 + nv].copy_(gp["order"][st_])
         h, w = plan["h"], plan["w"]
         cl = (lambda t: t) if self.alias_outputs else (lambda t: t.clone())
         masks = [cl(plan["mask"][s]).view(V, h, w, 1) for s in range(ns)]
