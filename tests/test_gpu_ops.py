@@ -265,6 +265,8 @@ def test_rank_desc_is_a_stable_descending_sort():
         sc = torch.randn(B, n, generator=g)
         sc[:, ::7] = sc[:, 3:4]                                   # plenty of exact ties
         sc[0, : n // 2] = -1e6
+        sc[1, 1], sc[1, 5], sc[1, 9] = 0.0, -0.0, 0.0             # signed zeros compare equal: slot order decides
+        sc[1, 2], sc[1, 11] = float("-inf"), float("inf")
         order = torch.empty(B, n, dtype=torch.int64, device=DEV)
         lib.call("toc3d_rank_desc", sc.to(DEV), B, n, order, S())
         ref = torch.sort(sc, dim=1, descending=True, stable=True)[1]
@@ -289,7 +291,7 @@ def _run_topk(scores, V, h, w, L, k):
     return b
 
 
-@pytest.mark.parametrize("L,ratio", [(16, 0.5), (16, 0.3), (20, 0.4), (20, 0.7)])
+@pytest.mark.parametrize("L,ratio", [(16, 0.5), (16, 0.3), (20, 0.4), (20, 0.7), (7, 0.5), (14, 0.6), (33, 0.3), (64, 0.1)])
 def test_window_topk_matches_oracle(L, ratio):
     V, h, w = 3, 20, 50
     g = torch.Generator().manual_seed(5)
