@@ -84,8 +84,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--hw", default="320x800")
     ap.add_argument("--groups", type=int, default=2, help="concurrent view groups (independent views on separate HIP streams)")
-    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph instead of launching eagerly (measured: no faster)")
-    ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly")
+    ap.add_argument("--launch", default="plan", choices=["plan", "graph", "eager"],
+                    help="plan: the frame's launch sequence recorded once and replayed from C on HIP streams (toc3d_plan_run); "
+                         "graph: the same recording as an explicitly built hipGraph; eager: every launch issued from Python")
     ap.add_argument("--tune-cache", default=None, help="JSON file: load the GEMM variant table if present, save it after warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
@@ -112,15 +113,13 @@ def main():
     model.load_state_dict(sd_cpu)
     model = model.to(dev).eval()
     model.alias_outputs = True
-    if args.graph and args.groups > 1:
-        # capturing the two view-group streams into one hipGraph segfaults inside the ROCm 7.2 runtime on replay (multi-stream
-        # capture with cross-stream events); a single group captures fine and eager launches are as fast
-        print("[bench] --graph: using one view group (multi-stream capture is not usable on this runtime)", file=sys.stderr)
-        args.groups = 1
     model.view_groups = args.groups
+    model.launch_mode = args.launch
     neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision=args.precision))
     neck.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG))
     neck = neck.to(dev).eval()
+    neck.alias_outputs = True
+    neck.launch_mode = args.launch
 
     # every rank gets its own frame (seed = rank): independent units, weak scaling
     inp_cpu = synth.make_inputs(cfg, n_frames=1, views_per_frame=6, hw=(H, W), seed=rank)
@@ -156,19 +155,7 @@ def main():
     torch.cuda.synchronize()
     if args.tune_cache and rank == 0:
         model.save_tuning(args.tune_cache)
-    graph = None
-    if args.graph and world == 1:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            graph.replay()
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
+    run = step
 
     # ---- timed region ------------------------------------------------------------------------------------
     barrier()
@@ -207,6 +194,7 @@ def main():
         n_inst = min(args.steps, 5)
         world_saved, world = world, 1                  # no collective in the instrumented pass
         model.view_groups = 1                          # one stream: per-launch durations are not inflated by co-running kernels
+        model.launch_mode = neck.launch_mode = "eager" # per-launch events need one host call per launch
         for _ in range(2):
             step()                                     # builds / autotunes the single-group plan outside the instrumented pass
         torch.cuda.synchronize()
@@ -245,6 +233,7 @@ def main():
             lib.call = orig_call
             world = world_saved
             model.view_groups = args.groups
+            model.launch_mode = neck.launch_mode = args.launch
         detail = {}
         for name, tag, e0, e1 in rec:
             t = e0.elapsed_time(e1)
@@ -299,7 +288,8 @@ def main():
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config} EVA-02 ViT-L backbone + CPFPN neck, 6 views x 3x{H}x{W} per frame, 1 frame per rank per step, "
                                    f"random-init weights, prev_exists=True, injected Gumbel noise",
-                       "frames_per_step": world, "launch": "hipGraph replay" if graph is not None else "eager",
+                       "frames_per_step": world, "launch": {"plan": "recorded launch plan replayed from C (toc3d_plan_run, HIP streams)", "graph": "recorded launch plan as an explicit hipGraph",
+                                  "eager": "eager (Python issues every launch)"}[args.launch],
                        "view_groups": args.groups,
                        "baseline_note": "vs_baseline divides by the paper's 4.78 backbone-frames/s (fp32, GPU model unstated, BASELINE.md section 1)"},
             "whole_path_tflops": (alg / (ms * 1e-3)) / 1e12,

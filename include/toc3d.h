@@ -321,6 +321,38 @@ int toc3d_mln_apply(int dtype, const float* x, const float* gamma, const float* 
                     toc3d_stream_t stream);
 int toc3d_se_gate(const float* pos, const float* se, float* out, int64_t n, toc3d_stream_t stream);
 
+/* Plain device-to-device copy as a kernel (recordable into a launch plan, unlike hipMemcpyAsync). */
+int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Launch plans: the per-frame host loop (the block loop of ToC3DEVAViT.forward, backbones/toc3d_eva_vit.py:263-291, and of
+ * EVA_ViT.forward, backbones/eva_vit.py:419-426; CPFPN.forward, necks/cp_fpn.py:156-208) recorded once and replayed from C.
+ * All shapes and buffers of a frame are static per (config, input shape), so the host records the sequence of toc3d_* calls ONCE:
+ *   toc3d_plan_create(&p); toc3d_plan_begin(p);
+ *   ... any toc3d_* entry points, passing toc3d_plan_lane_stream(lane) as `stream`: nothing runs, every kernel launch
+ *       (function, grid, block, LDS bytes, argument values) is stored in the plan ...
+ *   toc3d_plan_wait(p, a, b): lane a's next launch runs after everything recorded so far on lane b (fork / join of concurrent lanes);
+ *   toc3d_plan_end(p, mode);
+ * and then enqueues the whole frame with ONE call per frame, toc3d_plan_run(p, stream):
+ *   mode 0: hipLaunchKernel on one HIP stream per lane (lane 0 = `stream`, other lanes = streams owned by the plan), cross-lane
+ *           edges as hipEvent record / wait; lanes other than 0 start behind the work already on `stream` and are joined into it
+ *           at the end, so `stream` orders the frame against its neighbours;
+ *   mode 1: one explicitly constructed hipGraph (hipGraphAddKernelNode; lane order and cross-lane edges become node dependencies --
+ *           no stream capture), launched on `stream`.
+ * Recording is per host thread (begin .. end on one thread; other threads keep launching normally).  Buffers named by the recorded
+ * calls are the caller's and must stay allocated and in place while the plan lives; a plan belongs to the device that was current at
+ * toc3d_plan_end and must not be run concurrently with itself.  Up to 16 lanes.  Host-side arguments that a call reads on the host
+ * (e.g. position_range of toc3d_head_frustum_inputs) are consumed at record time. */
+typedef void* toc3d_plan_t;
+int toc3d_plan_create(toc3d_plan_t* plan);
+int toc3d_plan_destroy(toc3d_plan_t plan);
+toc3d_stream_t toc3d_plan_lane_stream(int64_t lane);
+int toc3d_plan_begin(toc3d_plan_t plan);
+int toc3d_plan_wait(toc3d_plan_t plan, int64_t waiting_lane, int64_t on_lane);
+int toc3d_plan_end(toc3d_plan_t plan, int mode);
+int64_t toc3d_plan_num_launches(toc3d_plan_t plan);
+int toc3d_plan_run(toc3d_plan_t plan, toc3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

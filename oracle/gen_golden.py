@@ -42,6 +42,10 @@ def run_reference_toc3d(cfg, sd, inp, prev_exists, capture_blocks=()):
     hooks = []
     for i in capture_blocks:
         hooks.append(model.blocks[i].register_forward_hook(lambda m, a, o, i=i: caps.__setitem__(f"block{i}.out", o.detach().clone())))
+    # image-level log-prob scores of every scorer stage = element [-2] of the selector's return tuple (toc3d_utils.py:415-420);
+    # with_kwargs: the backbone calls the selectors with keyword arguments only (toc3d_eva_vit.py:266-279)
+    for s_, sp in enumerate(model.score_predictor):
+        hooks.append(sp.register_forward_hook(lambda m, a, kw, o, s_=s_: caps.__setitem__(f"stage{s_}.score", o[-2].detach().clone()), with_kwargs=True))
     with torch.no_grad(), RH.deterministic_reference(inp["gumbel"]) as calls:
         out = model(inp["x"], temp_queries=inp["temp_queries"], prev_exists=prev_exists,
                     temp_ref_points=inp["temp_ref_points"], temp_vel=inp["temp_vel"],
@@ -189,32 +193,39 @@ def gen_tiny_e2e():
     _save("tiny_neck", level0=_np(n0), level1=_np(n1))
 
 
-def gen_vitl(names=("toc3d_faster", "toc3d_fast", "eva_dense"), hw=(320, 800)):
-    """Full-size ViT-L fixtures, stored as every-16th-channel slices + per-view norms (SURVEY.md 8c 'F-L-e2e')."""
+def gen_vitl(names=("toc3d_faster", "toc3d_fast", "eva_dense"), hw=(320, 800), prev=True):
+    """Full-size ViT-L fixtures, stored as every-16th-channel slices + per-view norms (SURVEY.md 8c 'F-L-e2e').
+    Larger inputs (BASELINE.json config 4: 640x1600, and the reference's own hi-res 800x1600,
+    projects/configs/ToC3D_1600_resolution/ToC3D_faster_1600.py:43,177) keep every 32nd channel and no block captures.
+    ``stage{s}.score`` (the scorers' image-level log-probs) lets a test force the reference's token selection."""
+    cstep = 16 if hw == (320, 800) else 32
     for name in names:
         cfg = configs.get(name)
         t0 = time.time()
         sd = synth.make_state_dict(cfg)
         inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
         if synth.is_toc3d(cfg):
-            out, caps, _ = run_reference_toc3d(cfg, sd, inp, True, capture_blocks=(5, 6, 11, 17))
+            out, caps, _ = run_reference_toc3d(cfg, sd, inp, prev, capture_blocks=(5, 6, 11, 17) if (hw == (320, 800) and prev) else ())
             feat = out.img_feats["last_feat"]
             arrs = {}
             for s in range(3):
                 arrs[f"keep_idx{s}"] = _np(out.keep_idx[s]).astype(np.int32)
                 arrs[f"token_mask{s}"] = _np(out.token_masks[s]).astype(np.float32)[..., 0]
             for k, v in caps.items():
-                arrs[k + ".c16"] = _np(v[..., ::16])
+                if k.endswith(".score"):
+                    arrs[k] = _np(v).astype(np.float32).reshape(v.shape[0], -1)
+                else:
+                    arrs[k + ".c16"] = _np(v[..., ::16])
         else:
             m = RH.build_reference_eva(cfg)
             m.load_state_dict(sd, strict=True)
             with torch.no_grad():
                 feat = m(inp["x"])["last_feat"]
             arrs = {}
-        arrs["last_feat.c16"] = _np(feat[:, ::16])
+        arrs[f"last_feat.c{cstep}"] = _np(feat[:, ::cstep])
         arrs["last_feat.view_l2"] = _np(feat.flatten(1).double().norm(dim=1))
         arrs["last_feat.token_l2"] = _np(feat.double().norm(dim=1))
-        suffix = "" if hw == (320, 800) else f"_{hw[1]}x{hw[0]}"
+        suffix = ("" if hw == (320, 800) else f"_{hw[1]}x{hw[0]}") + ("" if prev else "_first")
         _save(f"vitl_{name}{suffix}", **arrs)
         print(f"  {name}: reference forward + weights {time.time() - t0:.1f}s")
 
@@ -234,6 +245,11 @@ def main(argv):
         gen_tiny_e2e()
     if "vitl" in what:
         gen_vitl()
+    if "vitl_first" in what:                              # first frame of a scene (prev_exists=False), full size
+        gen_vitl(names=("toc3d_faster",), prev=False)
+    if "vitl1600" in what:                                # BASELINE.json config 4 and the reference's own hi-res input
+        gen_vitl(names=("toc3d_faster",), hw=(640, 1600))
+        gen_vitl(names=("toc3d_faster",), hw=(800, 1600))
 
 
 if __name__ == "__main__":

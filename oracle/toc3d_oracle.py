@@ -22,6 +22,41 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as F
 
+# --------------------------------------------------------------------------------------
+# Contraction precision.  The oracle proper is fp32 (the reference's inference dtype).  ``contractions("bf16")`` turns the
+# SAME code into the torch-bf16 control of BASELINE.md section 4 / SURVEY.md 7(b,c): every nn.Linear on the block path and
+# both attention matmuls take bf16 operands and return bf16 (torch accumulates in f32 and rounds the result once, like
+# torch.autocast), everything else -- LayerNorm, softmax, RoPE, residual stream, scorers, token merge -- stays fp32.
+# Runs on whatever device the inputs live on, so the control can use torch's own bf16 GEMMs on the same GPU as the HIP path.
+# --------------------------------------------------------------------------------------
+_CONTRACT = {"mode": "fp32"}
+
+
+class contractions:
+    def __init__(self, mode: str):
+        assert mode in ("fp32", "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _CONTRACT["mode"]
+        _CONTRACT["mode"] = self.mode
+
+    def __exit__(self, *a):
+        _CONTRACT["mode"] = self.prev
+
+
+def _linear(x, w, b=None):
+    if _CONTRACT["mode"] == "bf16":
+        return F.linear(x.bfloat16(), w.bfloat16(), None if b is None else b.bfloat16()).float()
+    return F.linear(x, w, b)
+
+
+def _matmul(a, b):
+    if _CONTRACT["mode"] == "bf16":
+        return (a.bfloat16() @ b.bfloat16()).float()
+    return a @ b
+
+
 LN_EPS = 1e-6            # toc3d_eva_vit.py:38 norm_layer=partial(nn.LayerNorm, eps=1e-6)
 TORCH_LN_EPS = 1e-5      # nn.LayerNorm default, used inside the scorers (toc3d_utils.py:100,331; misc.py:172)
 PAD_SCORE = -1e6         # toc3d_eva_vit.py:415
@@ -65,6 +100,8 @@ def abs_pos(pos_embed: torch.Tensor, has_cls: bool, hw):
 def patch_embed(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
     """backbones/eva_utils.py:279-287: Conv2d(k=s=patch) then NCHW->NHWC."""
     p = w.shape[-1]
+    if _CONTRACT["mode"] == "bf16":
+        return F.conv2d(x.bfloat16(), w.bfloat16(), b.bfloat16(), stride=p).float().permute(0, 2, 3, 1)
     return F.conv2d(x, w, b, stride=p).permute(0, 2, 3, 1)
 
 
@@ -90,25 +127,25 @@ def attention(x: torch.Tensor, sd, pre: str, num_heads: int, cos, sin):
     """
     B, N, C = x.shape
     hd = C // num_heads
-    q = F.linear(x, sd[pre + "q_proj.weight"], sd[pre + "q_bias"])
-    k = F.linear(x, sd[pre + "k_proj.weight"], None)
-    v = F.linear(x, sd[pre + "v_proj.weight"], sd[pre + "v_bias"])
+    q = _linear(x, sd[pre + "q_proj.weight"], sd[pre + "q_bias"])
+    k = _linear(x, sd[pre + "k_proj.weight"], None)
+    v = _linear(x, sd[pre + "v_proj.weight"], sd[pre + "v_bias"])
     q, k, v = (t.reshape(B, N, num_heads, hd).permute(0, 2, 1, 3) for t in (q, k, v))
     if cos.dim() == 3:
         cos, sin = cos[:, None], sin[:, None]
     q = rope_rotate(q, cos, sin)
     k = rope_rotate(k, cos, sin)
     q = q * hd ** -0.5
-    a = (q @ k.transpose(-2, -1)).softmax(dim=-1)
-    o = (a @ v).transpose(1, 2).reshape(B, N, C)
-    return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    a = _matmul(q, k.transpose(-2, -1)).softmax(dim=-1)
+    o = _matmul(a, v).transpose(1, 2).reshape(B, N, C)
+    return _linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
 
 
 def swiglu(x: torch.Tensor, sd, pre: str):
     """backbones/eva_vit.py:44-51 with subln=True (eva_vit.py:231): w3(LN(silu(w1 x) * (w2 x)))."""
-    h = F.silu(F.linear(x, sd[pre + "w1.weight"], sd[pre + "w1.bias"])) * F.linear(x, sd[pre + "w2.weight"], sd[pre + "w2.bias"])
+    h = F.silu(_linear(x, sd[pre + "w1.weight"], sd[pre + "w1.bias"])) * _linear(x, sd[pre + "w2.weight"], sd[pre + "w2.bias"])
     h = layer_norm(h, sd[pre + "ffn_ln.weight"], sd[pre + "ffn_ln.bias"])
-    return F.linear(h, sd[pre + "w3.weight"], sd[pre + "w3.bias"])
+    return _linear(h, sd[pre + "w3.weight"], sd[pre + "w3.bias"])
 
 
 def block_window_side(cfg, i: int) -> int:
@@ -176,7 +213,7 @@ def accel_block(x: torch.Tensor, scores: torch.Tensor, ratio: float, sd, i: int,
     if has_rep:
         rep = merge_tokens(fast, fast_score)                                  # :427
         slow = torch.cat([slow, rep], dim=1)                                  # :430
-        rope_idx = torch.cat([slow_idx, torch.full((nW, 1), k, dtype=torch.long)], dim=1)   # :434-435 (slot k)
+        rope_idx = torch.cat([slow_idx, torch.full((nW, 1), k, dtype=torch.long, device=slow_idx.device)], dim=1)   # :434-435 (slot k)
     else:
         rope_idx = slow_idx
     cos = sd[pre + "attn.rope.freqs_cos"][rope_idx]                           # eva_utils.py:400-401
@@ -207,7 +244,7 @@ def accel_block(x: torch.Tensor, scores: torch.Tensor, ratio: float, sd, i: int,
 def pos2posemb(pos: torch.Tensor, num_feats: int, temperature: float = 10000.0):
     """utils/positional_encoding.py:14-37 core: per coordinate, interleaved sin/cos of 2*pi*p / T^(2*floor(i/2)/F)."""
     pos = pos * (2 * math.pi)
-    dim_t = torch.arange(num_feats, dtype=torch.float32)
+    dim_t = torch.arange(num_feats, dtype=torch.float32, device=pos.device)
     dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_feats)
     a = pos[..., None] / dim_t
     return torch.stack((a[..., 0::2].sin(), a[..., 1::2].cos()), dim=-1).flatten(-2)
@@ -228,7 +265,7 @@ def nerf_encoding(x: torch.Tensor, n_freq: int = 6):
     """utils/positional_encoding.py:39-81 (include_input=False, log sampling): [sin(2^k x), cos(2^k x)] k-major."""
     parts = []
     for kk in range(n_freq):
-        f = torch.tensor(2.0 ** kk, dtype=x.dtype)
+        f = torch.tensor(2.0 ** kk, dtype=x.dtype, device=x.device)
         parts += [torch.sin(x * f), torch.cos(x * f)]
     return torch.cat(parts, dim=-1)
 
@@ -308,13 +345,18 @@ def forward_eva(sd, cfg, img, capture: Optional[dict] = None):
 
 
 def forward_toc3d(sd, cfg, img, temp_queries, temp_ref_points, temp_vel, temp_timestamp, temp_ego_pose,
-                  ego_pose_inv, prev_exists: bool, gumbel: List[torch.Tensor], capture: Optional[dict] = None):
-    """backbones/toc3d_eva_vit.py:230-310 (eval).  Returns dict(last_feat, token_masks, keep_idx, drop_idx)."""
+                  ego_pose_inv, prev_exists: bool, gumbel: List[torch.Tensor], capture: Optional[dict] = None,
+                  forced: Optional[List[tuple]] = None):
+    """backbones/toc3d_eva_vit.py:230-310 (eval).  Returns dict(last_feat, token_masks, keep_idx, drop_idx).
+
+    ``forced`` (tests only): per stage ``(score (B, H*W), mask (B, H*W))`` that REPLACE the scorer's image-level log-probs
+    and soft mask, e.g. the real reference's own values from a golden fixture -- every later block then selects exactly the
+    reference's tokens, which takes the top-k flips of a reduced-precision run out of the error."""
     x = stem(sd, cfg, img)
     B, H, W, C = x.shape
     if capture is not None:
         capture["stem"] = x
-    masks = torch.ones(B, H, W, 1)                                            # :251
+    masks = torch.ones(B, H, W, 1, device=x.device)                           # :251
     scores, ratio, stage = None, None, 0
     token_masks, keep_idx, drop_idx = [], [], []
     for i in range(cfg["depth"]):
@@ -330,6 +372,12 @@ def forward_toc3d(sd, cfg, img, temp_queries, temp_ref_points, temp_vel, temp_ti
             ki, di, m = sample_image_level(pred, ratio, gumbel[stage])
             masks = m.reshape(B, H, W, 1)                                     # replaced, not multiplied (:266)
             scores = pred[:, :, 0].reshape(B, H, W)                           # toc3d_utils.py:415,420
+            if forced is not None:
+                scores = forced[stage][0].to(x.device).float().reshape(B, H, W)
+                masks = forced[stage][1].to(x.device).float().reshape(B, H, W, 1)
+                _, order = sort_desc_stable(scores.reshape(B, H * W))
+                kk = int(H * W * ratio)
+                ki, di = order[:, :kk], order[:, kk:]
             token_masks.append(masks)
             keep_idx.append(ki)
             drop_idx.append(di)

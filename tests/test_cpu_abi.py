@@ -35,7 +35,7 @@ def test_ctypes_signatures_match_header():
             continue                      # int64_t-returning helpers are matched by the second regex below
         sig = ""
         for a in (x.strip() for x in args.split(",")):
-            if "*" in a or "toc3d_stream_t" in a:
+            if "*" in a or "toc3d_stream_t" in a or "toc3d_plan_t" in a:
                 sig += "p"
             elif a.startswith("int64_t"):
                 sig += "l"
@@ -82,3 +82,22 @@ def test_no_cpu_fallback():
     n = toc3d_amd.build_neck(configs.CPFPN_TINY)
     with pytest.raises(RuntimeError, match="no CPU"):
         n([torch.zeros(2, 128, 20, 50)])
+
+
+def test_launch_plan_api_validates_without_gpu():
+    """toc3d_plan_*: handles, lane handles and the recording state machine work (and fail loudly) without a GPU."""
+    l = lib.load()
+    h = ctypes.c_void_p()
+    assert l.toc3d_plan_create(ctypes.addressof(h)) == 0 and h.value
+    assert l.toc3d_plan_lane_stream(0) and l.toc3d_plan_lane_stream(3) and not l.toc3d_plan_lane_stream(16)
+    assert l.toc3d_plan_num_launches(h.value) == 0
+    assert l.toc3d_plan_wait(h.value, 1, 0) == -1 and b"not recording" in l.toc3d_last_error()
+    assert l.toc3d_plan_run(h.value, None) == -1 and b"not finalized" in l.toc3d_last_error()
+    assert l.toc3d_plan_begin(h.value) == 0
+    h2 = ctypes.c_void_p()
+    assert l.toc3d_plan_create(ctypes.addressof(h2)) == 0
+    assert l.toc3d_plan_begin(h2.value) == -1 and b"already recording" in l.toc3d_last_error()
+    assert l.toc3d_plan_wait(h.value, 1, 0) == 0 and l.toc3d_plan_wait(h.value, 1, 99) == -1
+    assert l.toc3d_plan_end(h.value, 0) == -1 and b"nothing was recorded" in l.toc3d_last_error()
+    assert l.toc3d_plan_destroy(h.value) == 0 and l.toc3d_plan_destroy(h2.value) == 0
+    assert l.toc3d_plan_begin(None) == -1

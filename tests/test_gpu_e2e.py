@@ -154,7 +154,9 @@ def test_vitl_bf16_reported(golden_dir, name):
     ref = torch.from_numpy(g["last_feat.c16"])
     l2 = rel_l2(feat[:, ::16], ref)
     print(f"[vitl {name} bf16] free-running rel l2 vs fp32 reference {l2:.3e}")
-    assert torch.isfinite(feat).all() and l2 < 0.6          # torch's own bf16 autocast scores 0.39 on this chaotic random-weight net
+    # dense: no discrete decisions, pure bf16 arithmetic (measured 2.1e-2).  ToC3D free-running: 0.118 measured, top-k flips included;
+    # the arithmetic part alone (forced selection) and the torch-bf16 control are bounded in tests/test_gpu_parity_bf16.py
+    assert torch.isfinite(feat).all() and l2 < (3e-2 if name == "eva_dense" else 0.16)
 
 
 def test_state_dict_reload_repacks(golden_dir):
@@ -392,6 +394,32 @@ def test_carried_compact_set_matches_scatter_gather_between_blocks():
             assert iou(a[1][s], b[1][s].cpu()) >= min_iou
     _, m32 = build("toc3d_tiny", "fp32")
     assert not m32.carry_compact, "the strict-parity path keeps the reference's scatter / gather between all blocks by default"
+
+
+def test_carried_compact_set_on_long_runs_of_one_window_type():
+    """A layout the shipped configs do not have: up to six consecutive accelerated blocks of one window type within a stage
+    (global_attn_indexes=(2, 11), pruning_loc=[3, 9]).  Carried sets must pair up (3,4) (5,6) (7,8); a block after a pair starts from
+    the scattered stream again -- regression for a pairing rule that lost the third block's update in runs of four or more."""
+    cfg = dict(configs.get("toc3d_tiny"), global_attn_indexes=(2, 11), pruning_loc=[3, 9], token_ratio=[0.5, 0.3])
+    sd = synth.make_state_dict(cfg)
+    inp = synth.make_inputs(cfg, views_per_frame=2)
+    inp["gumbel"] = inp["gumbel"][:2]
+    with torch.no_grad():
+        ref = O.forward_toc3d(sd, cfg, inp["x"], inp["temp_queries"], inp["temp_ref_points"], inp["temp_vel"], inp["temp_timestamp"],
+                              inp["temp_ego_pose"], inp["ego_pose_inv"], True, inp["gumbel"])["last_feat"]
+    outs = {}
+    for carry in (True, False):
+        m = toc3d_amd.build_backbone(dict(cfg, precision="fp32"))
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        m.carry_compact, m.autotune = carry, False
+        pairs = []
+        m.block_hook = lambda i, gp, carried: pairs.append((i, carried))
+        outs[carry] = run_toc3d(m, inp, True).img_feats["last_feat"].clone()
+        if carry:
+            assert [i for i, c in pairs if c] == [3, 5, 7, 9], pairs          # 9->10 pairs too; block 11 is global
+    assert rel_max(outs[False], ref) < 1e-3
+    assert rel_max(outs[True], ref) < 1e-3 and rel_max(outs[True], outs[False]) < 1e-4
 
 
 def test_streaming_loop_uint8_images_memory_bank_backbone_neck():

@@ -1,0 +1,218 @@
+"""GPU: parity of the BENCHMARKED precision (bf16 operands, f32 accumulate, f32 residual stream), bounded tightly.
+
+BASELINE.md section 4 / SURVEY.md 7(b,c): a bf16 run of this network has two error sources -- the arithmetic itself, and the
+chaos of top-k flips (a token whose score moves by one bf16 ulp changes every later block).  They are separated here:
+
+* **forced selection**: the reference's own image-level scores and soft masks (``stage{s}.score`` / ``token_mask{s}`` of the
+  golden fixtures, produced by the REAL reference, oracle/gen_golden.py) replace every scorer stage's output, so every block
+  selects exactly the reference's tokens; what is left is arithmetic error, measured against the reference's fp32 features;
+* **torch-bf16 control**: the oracle's own code with every nn.Linear / attention matmul in torch bf16 on the same GPU
+  (``oracle.toc3d_oracle.contractions("bf16")``), forced and free-running.  The HIP path must be no worse than 1.2x the control.
+
+Per-block budgets: with forced selection the residual stream after every block is compared with the fp32 oracle's, HIP-bf16 next
+to the control, block by block.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import toc3d_amd
+from oracle import toc3d_oracle as O
+from toc3d_amd import configs, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ARGS = ("x", "temp_queries", "temp_ref_points", "temp_vel", "temp_timestamp", "temp_ego_pose", "ego_pose_inv")
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def rel_max(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def iou(a, b):
+    res = []
+    for ra, rb in zip(np.asarray(a.cpu()), np.asarray(b)):
+        sa, sb = set(ra.tolist()), set(rb.tolist())
+        res.append(len(sa & sb) / max(1, len(sa | sb)))
+    return min(res)
+
+
+def build(name, precision):
+    cfg = configs.get(name)
+    m = toc3d_amd.build_backbone(dict(cfg, precision=precision))
+    m.load_state_dict(synth.make_state_dict(cfg), strict=True)
+    m = m.to(DEV).eval()
+    m.autotune = False                    # every tile variant accumulates in the same order: the choice cannot change a bit
+    return cfg, m
+
+
+def run_hip(m, inp, prev=True, forced=None):
+    d = lambda t: t.to(DEV)
+    return m(d(inp["x"]), temp_queries=d(inp["temp_queries"]), prev_exists=prev, temp_ref_points=d(inp["temp_ref_points"]),
+             temp_vel=d(inp["temp_vel"]), temp_timestamp=d(inp["temp_timestamp"]), temp_ego_pose=d(inp["temp_ego_pose"]),
+             ego_pose_inv=d(inp["ego_pose_inv"]), gumbel_noise=inp["gumbel"], forced_scores=forced)
+
+
+_SD_DEV = {}
+
+
+def oracle_on_gpu(name, cfg, inp, mode, prev=True, forced=None, capture=None):
+    """The oracle's code on the GPU: fp32 (checker) or with torch-bf16 contractions (control)."""
+    if name not in _SD_DEV:
+        _SD_DEV.clear()                   # one ViT-L state dict (1.2 GB) on the device at a time
+        _SD_DEV[name] = {k: v.to(DEV) for k, v in synth.make_state_dict(cfg).items()}
+    sd = _SD_DEV[name]
+    a = [inp[k].to(DEV) for k in ARGS]
+    with torch.no_grad(), O.contractions(mode):
+        return O.forward_toc3d(sd, cfg, *a, prev, [g.to(DEV) for g in inp["gumbel"]], capture=capture,
+                               forced=None if forced is None else [(s.to(DEV), m.to(DEV)) for s, m in forced])
+
+
+def forced_from_golden(g):
+    return [(torch.from_numpy(g[f"stage{s}.score"]), torch.from_numpy(g[f"token_mask{s}"]).reshape(g[f"stage{s}.score"].shape)) for s in range(3)]
+
+
+def golden_feat(g):
+    key = "last_feat.c16" if "last_feat.c16" in g else "last_feat.c32"
+    return torch.from_numpy(g[key]), int(key.rsplit("c", 1)[1])
+
+
+# (fixture, config, hw, prev): BASELINE.json configs 1, 2, 4 (+ the reference's own 1600x800 input and a first frame)
+CASES = [("vitl_toc3d_faster", "toc3d_faster", (320, 800), True),
+         ("vitl_toc3d_fast", "toc3d_fast", (320, 800), True),
+         ("vitl_toc3d_faster_first", "toc3d_faster", (320, 800), False),
+         ("vitl_toc3d_faster_1600x640", "toc3d_faster", (640, 1600), True),
+         ("vitl_toc3d_faster_1600x800", "toc3d_faster", (800, 1600), True)]
+
+
+@pytest.mark.parametrize("fixture,name,hw,prev", CASES)
+def test_vitl_bf16_forced_selection_within_control(golden_dir, fixture, name, hw, prev):
+    """Arithmetic error of the bf16 path with the reference's token selection forced, next to the torch-bf16 control."""
+    cfg, m = build(name, "bf16")
+    inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    forced = forced_from_golden(g)
+    ref, step = golden_feat(g)
+    out = run_hip(m, inp, prev, forced)
+    feat = out.img_feats["last_feat"]
+    for s in range(3):                    # forced scores -> the image-level lists are the reference's, bit for bit
+        assert np.array_equal(out.keep_idx[s].cpu().numpy(), g[f"keep_idx{s}"]), f"stage {s}"
+    ctl = oracle_on_gpu(name, cfg, inp, "bf16", prev, forced)["last_feat"]
+    e_hip, e_ctl = rel_l2(feat[:, ::step], ref), rel_l2(ctl[:, ::step], ref)
+    m_hip, m_ctl = rel_max(feat[:, ::step], ref), rel_max(ctl[:, ::step], ref)
+    tl2 = (feat.double().norm(dim=1).cpu() - torch.from_numpy(g["last_feat.token_l2"])).abs().max().item() / g["last_feat.token_l2"].max()
+    print(f"[{fixture} bf16 forced] rel l2: hip {e_hip:.3e}  torch-bf16 control {e_ctl:.3e}   rel max: hip {m_hip:.3e} control {m_ctl:.3e}"
+          f"   token-norm err {tl2:.3e}")
+    assert torch.isfinite(feat).all()
+    assert e_hip <= 1.2 * e_ctl, "HIP bf16 arithmetic error exceeds 1.2x the torch-bf16 control"
+    assert e_hip < 3e-2 and m_hip < 8e-2 and tl2 < 3e-2          # absolute ceilings: measured 2e-2-class rel l2 (random weights)
+
+
+@pytest.mark.parametrize("fixture,name,hw,prev", CASES[:3])
+def test_vitl_bf16_free_running_within_control(golden_dir, fixture, name, hw, prev):
+    """Free-running bf16 (what bench.py times): selection decided by the bf16 scores.  Error vs the fp32 reference next to
+    the free-running control, and how many kept tokens flipped."""
+    cfg, m = build(name, "bf16")
+    inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    ref, step = golden_feat(g)
+    out = run_hip(m, inp, prev)
+    feat = out.img_feats["last_feat"]
+    c = oracle_on_gpu(name, cfg, inp, "bf16", prev)
+    e_hip, e_ctl = rel_l2(feat[:, ::step], ref), rel_l2(c["last_feat"][:, ::step], ref)
+    i_hip = [iou(out.keep_idx[s], g[f"keep_idx{s}"]) for s in range(3)]
+    i_ctl = [iou(c["keep_idx"][s], g[f"keep_idx{s}"]) for s in range(3)]
+    print(f"[{fixture} bf16 free] rel l2: hip {e_hip:.3e} control {e_ctl:.3e}   keep IoU: hip {np.round(i_hip, 4).tolist()} control {np.round(i_ctl, 4).tolist()}")
+    assert torch.isfinite(feat).all()
+    # top-k flips are chaotic (one flipped token moves every later block), so two free-running bf16 runs are only comparable as a
+    # band.  Measured on MI355X (r02): rel l2 hip / control 0.118 / 0.123 (faster), 0.120 / 0.117 (fast), 0.137 / 0.163 (first frame);
+    # worst-view stage-3 IoU 0.936 / 0.936, 0.961 / 0.942, 0.840 / 0.887.  Stage 1 is decided by six dense blocks only: near 0.99.
+    assert e_hip <= 1.2 * e_ctl + 5e-3
+    assert min(i_hip) >= min(i_ctl) - 0.06 and i_hip[0] > 0.98
+
+
+@pytest.mark.parametrize("name", ["toc3d_faster", "toc3d_fast"])
+def test_vitl_bf16_per_block_error_budget(golden_dir, name):
+    """Residual stream after every block, forced selection: HIP bf16 vs the fp32 oracle, block by block, next to the control."""
+    cfg, m = build(name, "bf16")
+    inp = synth.make_inputs(cfg, views_per_frame=6)
+    g = np.load(os.path.join(golden_dir, f"vitl_{name}.npz"))
+    forced = forced_from_golden(g)
+    snaps = {}
+    m.block_hook = lambda i, gp, carried: None if carried else snaps.__setitem__(i, gp["x"][:, ::16].clone())
+    run_hip(m, inp, True, forced)
+    m.block_hook = None
+    cap32, cap16 = {}, {}
+    oracle_on_gpu(name, cfg, inp, "fp32", True, forced, capture=cap32)
+    ref = {i: cap32[f"block{i}.out"].reshape(-1, cfg["embed_dim"])[:, ::16].clone() for i in snaps}
+    del cap32
+    oracle_on_gpu(name, cfg, inp, "bf16", True, forced, capture=cap16)
+    rows = []
+    for i in sorted(snaps):
+        c = cap16[f"block{i}.out"].reshape(-1, cfg["embed_dim"])[:, ::16]
+        rows.append((i, rel_l2(snaps[i], ref[i]), rel_l2(c, ref[i])))
+    print(f"[{name} bf16 forced] per-block rel l2 (block: hip / control): " + "  ".join(f"{i}: {a:.2e}/{b:.2e}" for i, a, b in rows))
+    # the reference golden pins the oracle's per-block values where the fixture holds them (blocks 5, 6, 11, 17)
+    for i in (5, 6, 11, 17):
+        if f"block{i}.out.c16" in g and i in ref:
+            assert rel_max(ref[i].reshape(g[f"block{i}.out.c16"].shape), torch.from_numpy(g[f"block{i}.out.c16"])) < 1e-4
+    assert len(rows) >= 15
+    for i, e_hip, e_ctl in rows:
+        assert e_hip <= 1.2 * e_ctl + 2e-4, f"block {i}: hip {e_hip:.3e} vs control {e_ctl:.3e}"
+    assert rows[-1][1] < 3e-2
+    assert all(b[1] <= 1.6 * a[1] + 1e-3 for a, b in zip(rows, rows[1:])), "error must grow smoothly along the depth (no broken block)"
+
+
+@pytest.mark.parametrize("fixture,hw", [("vitl_toc3d_faster_1600x640", (640, 1600)), ("vitl_toc3d_faster_1600x800", (800, 1600))])
+def test_vitl_1600_fp32_matches_reference(golden_dir, fixture, hw):
+    """BASELINE.json config 4 (6 x 1600x640) and the reference's own hi-res input (6 x 1600x800, ToC3D_faster_1600.py:43,177), all six
+    views, strict-parity path against the REAL reference's golden."""
+    cfg, m = build("toc3d_faster", "fp32")
+    inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    ref, step = golden_feat(g)
+    out = run_hip(m, inp, True)
+    feat = out.img_feats["last_feat"]
+    assert tuple(feat.shape) == (6, 1024, hw[0] // 16, hw[1] // 16)
+    for s in range(3):
+        assert iou(out.keep_idx[s], g[f"keep_idx{s}"]) > 0.99
+        assert (out.token_masks[s][..., 0].cpu() - torch.from_numpy(g[f"token_mask{s}"])).abs().max().item() < 5e-3
+    err = rel_max(feat[:, ::step], ref)
+    tl2 = (feat.double().norm(dim=1).cpu() - torch.from_numpy(g["last_feat.token_l2"])).abs().max().item() / g["last_feat.token_l2"].max()
+    print(f"[{fixture} fp32] rel max err {err:.3e} token-norm err {tl2:.3e}")
+    assert err < 1e-3 and tl2 < 1e-3
+
+
+def test_vitl_first_frame_fp32_matches_reference(golden_dir):
+    """prev_exists=False at full size: ScoreBasedTokenSelector.score (toc3d_utils.py:114-129) feeds the selection."""
+    cfg, m = build("toc3d_faster", "fp32")
+    inp = synth.make_inputs(cfg, views_per_frame=6)
+    g = np.load(os.path.join(golden_dir, "vitl_toc3d_faster_first.npz"))
+    ref, step = golden_feat(g)
+    out = run_hip(m, inp, False)
+    feat = out.img_feats["last_feat"]
+    for s in range(3):
+        assert iou(out.keep_idx[s], g[f"keep_idx{s}"]) > 0.99
+    err = rel_max(feat[:, ::step], ref)
+    print(f"[vitl toc3d_faster first frame fp32] rel max err {err:.3e}")
+    assert err < 1e-3
+
+
+def test_forced_selection_reproduces_free_running_on_the_parity_path(golden_dir):
+    """fp32: forcing the reference's scores must give the same features as running free (the fp32 scores agree to 1e-6)."""
+    cfg, m = build("toc3d_tiny", "fp32")
+    inp = synth.make_inputs(cfg, views_per_frame=2)
+    g = np.load(os.path.join(golden_dir, "tiny_toc3d_prev.npz"))
+    forced = [(torch.from_numpy(g[f"stage{s}.score"]).reshape(2, -1), torch.from_numpy(g[f"token_mask{s}"]).reshape(2, -1)) for s in range(3)]
+    a = run_hip(m, inp, True, forced).img_feats["last_feat"].clone()
+    b = run_hip(m, inp, True).img_feats["last_feat"].clone()
+    ref = torch.from_numpy(g["last_feat"])
+    assert rel_max(a, ref) < 1e-3 and rel_max(b, ref) < 1e-3 and rel_max(a, b) < 1e-4

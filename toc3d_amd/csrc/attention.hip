@@ -521,9 +521,9 @@ size_t attn_small_lds(int64_t stride, int L, bool chunk) {
 
 template <typename T, bool CHUNK>
 void launch_small(const AttnArgs& a, size_t lds, int64_t num_heads, int64_t nwin, hipStream_t s) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_kernel<T, CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); set = true; }
-    hipLaunchKernelGGL((attn_small_kernel<T, CHUNK>), dim3((unsigned)num_heads, (unsigned)nwin), dim3(256), lds, s, a);
+    static Toc3dLdsAttr attr;                    // per function instantiation, per device
+    attr.ensure(reinterpret_cast<const void*>(&attn_small_kernel<T, CHUNK>), 80 * 1024);
+    toc3d_launch((attn_small_kernel<T, CHUNK>), dim3((unsigned)num_heads, (unsigned)nwin), dim3(256), lds, s, a);
 }
 
 template <typename T>
@@ -541,7 +541,7 @@ void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_
     // size of this model: more, fuller workgroups beat the halved K/V staging)
     const size_t lds = (size_t)(KT + HD + 4 * 16) * Pad<T>::ld * sizeof(T) + (size_t)((a.stride + 3) & ~3) * 8 + (size_t)a.L * 16 * 4 * 4;
     dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)nwin);
-    hipLaunchKernelGGL((attn_kernel<T, 1>), grid, dim3(256), lds, s, a);
+    toc3d_launch((attn_kernel<T, 1>), grid, dim3(256), lds, s, a);
 }
 
 // window_partition as index maps (backbones/eva_utils.py:89-110): real tokens of each window in slot order.
@@ -599,7 +599,7 @@ int toc3d_window_map_dense(int64_t V, int64_t h, int64_t w, int64_t L, int32_t* 
     TOC3D_REQUIRE(rows && slots && count && npad, "toc3d_window_map_dense: null buffer");
     TOC3D_REQUIRE(V > 0 && h > 0 && w > 0 && L > 0, "toc3d_window_map_dense: bad dims");
     const int nW = (int)(V * ((h + L - 1) / L) * ((w + L - 1) / L));
-    hipLaunchKernelGGL(window_map_dense_kernel, dim3(nW), dim3(256), 0, as_stream(stream), (int)V, (int)h, (int)w, (int)L, rows, slots, count, npad);
+    toc3d_launch(window_map_dense_kernel, dim3(nW), dim3(256), 0, as_stream(stream), (int)V, (int)h, (int)w, (int)L, rows, slots, count, npad);
     TOC3D_LAUNCH_CHECK("toc3d_window_map_dense");
     return TOC3D_OK;
 }

@@ -276,16 +276,13 @@ thread_local bool g_bad_variant = false;               // variant cannot serve t
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int lds = STAGES * (BM + BN) * RB;
-    static bool attr_set = false;      // > 64 KiB of dynamic LDS: raise the per-kernel limit once
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
+    if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds);
     if (EPI == TOC3D_EPI_SWIGLU && (BN / WN) % 32 != 0) { g_bad_variant = true; return; }   // a wave must own whole (w1, w2) 32-column groups
     if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
     const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
     const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
+    toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
 }
 
 // tile / pipeline variants (toc3d_linear_ex `variant`); 0 = heuristic
@@ -485,7 +482,7 @@ int toc3d_normalize_images(const uint8_t* img, int64_t V, int64_t H, int64_t W, 
     TOC3D_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "toc3d_normalize_images: zero std");
     const int64_t total = V * Hp * (Wp / 4);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(normalize_images_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, make_norm(mean3, std3, to_rgb),
+    toc3d_launch(normalize_images_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, make_norm(mean3, std3, to_rgb),
                        out, (int)Hp, (int)Wp);
     TOC3D_LAUNCH_CHECK("toc3d_normalize_images");
     return TOC3D_OK;
@@ -502,9 +499,9 @@ int toc3d_im2col_patches_u8(int dtype, const uint8_t* img, int64_t V, int64_t H,
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     const ImgNorm n = make_norm(mean3, std3, to_rgb);
     if (dtype == TOC3D_BF16)
-        hipLaunchKernelGGL(im2col_u8_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, n, (bf16_t*)out, ldo, (int)Hp, (int)Wp, (int)patch);
+        toc3d_launch(im2col_u8_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, n, (bf16_t*)out, ldo, (int)Hp, (int)Wp, (int)patch);
     else if (dtype == TOC3D_F32)
-        hipLaunchKernelGGL(im2col_u8_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, n, (float*)out, ldo, (int)Hp, (int)Wp, (int)patch);
+        toc3d_launch(im2col_u8_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (int)V, (int)H, (int)W, n, (float*)out, ldo, (int)Hp, (int)Wp, (int)patch);
     else { toc3d_set_error("toc3d_im2col_patches_u8: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_im2col_patches_u8");
     return TOC3D_OK;
@@ -560,9 +557,9 @@ int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out
     TOC3D_REQUIRE(w && out && Np >= N && Kp >= K && N > 0 && K > 0, "toc3d_pack_weight: bad arguments");
     const int blocks = (int)((Np * Kp + 255) / 256 < 4096 ? (Np * Kp + 255) / 256 : 4096);
     if (dtype == TOC3D_BF16)
-        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), w, (int)N, (int)K, (bf16_t*)out, (int)Np, (int)Kp);
+        toc3d_launch(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), w, (int)N, (int)K, (bf16_t*)out, (int)Np, (int)Kp);
     else if (dtype == TOC3D_F32)
-        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), w, (int)N, (int)K, (float*)out, (int)Np, (int)Kp);
+        toc3d_launch(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), w, (int)N, (int)K, (float*)out, (int)Np, (int)Kp);
     else { toc3d_set_error("toc3d_pack_weight: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_pack_weight");
     return TOC3D_OK;
@@ -575,9 +572,9 @@ int toc3d_pack_swiglu(int dtype, const float* w1, const float* w2, const float* 
     const int64_t total = 2 * Hp * Kp;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == TOC3D_BF16)
-        hipLaunchKernelGGL(pack_swiglu_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), w1, w2, b1, b2, (int)Hd, (int)K, (bf16_t*)out_w, out_b, (int)Hp, (int)Kp);
+        toc3d_launch(pack_swiglu_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), w1, w2, b1, b2, (int)Hd, (int)K, (bf16_t*)out_w, out_b, (int)Hp, (int)Kp);
     else if (dtype == TOC3D_F32)
-        hipLaunchKernelGGL(pack_swiglu_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), w1, w2, b1, b2, (int)Hd, (int)K, (float*)out_w, out_b, (int)Hp, (int)Kp);
+        toc3d_launch(pack_swiglu_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), w1, w2, b1, b2, (int)Hd, (int)K, (float*)out_w, out_b, (int)Hp, (int)Kp);
     else { toc3d_set_error("toc3d_pack_swiglu: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_pack_swiglu");
     return TOC3D_OK;
@@ -593,9 +590,9 @@ int toc3d_im2col_patches(int dtype, const float* img, void* out, int64_t ldo, in
     if (total == 0) return TOC3D_OK;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == TOC3D_BF16)
-        hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (bf16_t*)out, ldo, (int)V, (int)Cin, (int)H, (int)W, (int)patch);
+        toc3d_launch(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (bf16_t*)out, ldo, (int)V, (int)Cin, (int)H, (int)W, (int)patch);
     else if (dtype == TOC3D_F32)
-        hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (float*)out, ldo, (int)V, (int)Cin, (int)H, (int)W, (int)patch);
+        toc3d_launch(im2col_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), img, (float*)out, ldo, (int)V, (int)Cin, (int)H, (int)W, (int)patch);
     else { toc3d_set_error("toc3d_im2col_patches: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_im2col_patches");
     return TOC3D_OK;

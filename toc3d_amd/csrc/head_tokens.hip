@@ -143,8 +143,8 @@ int toc3d_head_frustum_inputs(int dtype, const float* img2lidar, const float* in
     a.B = (int)B; a.N = (int)N; a.h = (int)h; a.w = (int)w; a.D = (int)D; a.stride = (int)stride; a.pad_h = (int)pad_h; a.pad_w = (int)pad_w;
     const int64_t total = B * N * h * w * D;
     dim3 grid((unsigned)((total + 255) / 256));
-    if (dtype == TOC3D_BF16) hipLaunchKernelGGL(frustum_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), a, (bf16_t*)pos_in, ld_pos, (bf16_t*)cone_act, ld_cone, cone);
-    else if (dtype == TOC3D_F32) hipLaunchKernelGGL(frustum_kernel<float>, grid, dim3(256), 0, as_stream(stream), a, (float*)pos_in, ld_pos, (float*)cone_act, ld_cone, cone);
+    if (dtype == TOC3D_BF16) toc3d_launch(frustum_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), a, (bf16_t*)pos_in, ld_pos, (bf16_t*)cone_act, ld_cone, cone);
+    else if (dtype == TOC3D_F32) toc3d_launch(frustum_kernel<float>, grid, dim3(256), 0, as_stream(stream), a, (float*)pos_in, ld_pos, (float*)cone_act, ld_cone, cone);
     else { toc3d_set_error("toc3d_head_frustum_inputs: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_head_frustum_inputs");
     return TOC3D_OK;
@@ -154,8 +154,8 @@ int toc3d_relu_inplace(int dtype, void* x, int64_t n, toc3d_stream_t stream) {
     TOC3D_REQUIRE(x && n >= 0, "toc3d_relu_inplace: bad arguments");
     if (n == 0) return TOC3D_OK;
     dim3 grid((unsigned)((n + 255) / 256));
-    if (dtype == TOC3D_BF16) hipLaunchKernelGGL(relu_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)x, n);
-    else if (dtype == TOC3D_F32) hipLaunchKernelGGL(relu_kernel<float>, grid, dim3(256), 0, as_stream(stream), (float*)x, n);
+    if (dtype == TOC3D_BF16) toc3d_launch(relu_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)x, n);
+    else if (dtype == TOC3D_F32) toc3d_launch(relu_kernel<float>, grid, dim3(256), 0, as_stream(stream), (float*)x, n);
     else { toc3d_set_error("toc3d_relu_inplace: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_relu_inplace");
     return TOC3D_OK;
@@ -164,8 +164,8 @@ int toc3d_relu_inplace(int dtype, void* x, int64_t n, toc3d_stream_t stream) {
 int toc3d_nchw_to_rows(int dtype, const float* x, void* out, int64_t ldo, int64_t V, int64_t C, int64_t hw, toc3d_stream_t stream) {
     TOC3D_REQUIRE(x && out && V > 0 && C > 0 && hw > 0 && ldo >= C && V <= 65535, "toc3d_nchw_to_rows: bad arguments");
     dim3 grid((unsigned)((hw + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)V);
-    if (dtype == TOC3D_BF16) hipLaunchKernelGGL(nchw_rows_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), x, (bf16_t*)out, ldo, (int)C, (int)hw);
-    else if (dtype == TOC3D_F32) hipLaunchKernelGGL(nchw_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), x, (float*)out, ldo, (int)C, (int)hw);
+    if (dtype == TOC3D_BF16) toc3d_launch(nchw_rows_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), x, (bf16_t*)out, ldo, (int)C, (int)hw);
+    else if (dtype == TOC3D_F32) toc3d_launch(nchw_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), x, (float*)out, ldo, (int)C, (int)hw);
     else { toc3d_set_error("toc3d_nchw_to_rows: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_nchw_to_rows");
     return TOC3D_OK;
@@ -176,8 +176,8 @@ int toc3d_mln_apply(int dtype, const float* x, const float* gamma, const float* 
     TOC3D_REQUIRE(x && gamma && beta && out && out_act && M >= 0 && E > 0 && E <= 1024 && ld_act >= E, "toc3d_mln_apply: bad arguments (E <= 1024)");
     if (M == 0) return TOC3D_OK;
     dim3 grid((unsigned)((M + 3) / 4));
-    if (dtype == TOC3D_BF16) hipLaunchKernelGGL(mln_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, (int)E, out, (bf16_t*)out_act, ld_act, (int)M);
-    else if (dtype == TOC3D_F32) hipLaunchKernelGGL(mln_kernel<float>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, (int)E, out, (float*)out_act, ld_act, (int)M);
+    if (dtype == TOC3D_BF16) toc3d_launch(mln_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, (int)E, out, (bf16_t*)out_act, ld_act, (int)M);
+    else if (dtype == TOC3D_F32) toc3d_launch(mln_kernel<float>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, (int)E, out, (float*)out_act, ld_act, (int)M);
     else { toc3d_set_error("toc3d_mln_apply: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_mln_apply");
     return TOC3D_OK;
@@ -186,7 +186,7 @@ int toc3d_mln_apply(int dtype, const float* x, const float* gamma, const float* 
 int toc3d_se_gate(const float* pos, const float* se, float* out, int64_t n, toc3d_stream_t stream) {
     TOC3D_REQUIRE(pos && se && out && n >= 0, "toc3d_se_gate: bad arguments");
     if (n == 0) return TOC3D_OK;
-    hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), pos, se, out, n);
+    toc3d_launch(se_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), pos, se, out, n);
     TOC3D_LAUNCH_CHECK("toc3d_se_gate");
     return TOC3D_OK;
 }

@@ -109,7 +109,7 @@ int toc3d_memory_pre_update(float* emb, float* ref, double* ts, float* pose, flo
     TOC3D_REQUIRE(B > 0 && memory_len > 0 && capacity >= memory_len && embed_dims > 0 && num_propagated >= 0 && num_propagated <= memory_len &&
                   (num_propagated == 0 || pseudo_reference_points), "toc3d_memory_pre_update: bad dims");
     TOC3D_REQUIRE(B <= 65535, "toc3d_memory_pre_update: batch too large");
-    hipLaunchKernelGGL(pre_update_kernel, dim3((unsigned)memory_len, (unsigned)B), dim3(64), 0, as_stream(stream), Bank{emb, ref, ts, pose, vel},
+    toc3d_launch(pre_update_kernel, dim3((unsigned)memory_len, (unsigned)B), dim3(64), 0, as_stream(stream), Bank{emb, ref, ts, pose, vel},
                        prev_exists, timestamp, ego_pose_inv, pseudo_reference_points, pc_range, (int)B, (int)capacity, (int)memory_len,
                        (int)num_propagated, (int)embed_dims, fresh);
     TOC3D_LAUNCH_CHECK("toc3d_memory_pre_update");
@@ -119,7 +119,7 @@ int toc3d_memory_pre_update(float* emb, float* ref, double* ts, float* pose, flo
 int toc3d_memory_scores(const float* cls_scores, int64_t rows, int64_t num_classes, float* score, toc3d_stream_t stream) {
     TOC3D_REQUIRE(cls_scores && score && rows >= 0 && num_classes > 0, "toc3d_memory_scores: bad arguments");
     if (rows == 0) return TOC3D_OK;
-    hipLaunchKernelGGL(score_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), cls_scores, rows, (int)num_classes, score);
+    toc3d_launch(score_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), cls_scores, rows, (int)num_classes, score);
     TOC3D_LAUNCH_CHECK("toc3d_memory_scores");
     return TOC3D_OK;
 }
@@ -135,7 +135,7 @@ int toc3d_memory_post_update(const float* emb_in, const float* ref_in, const dou
                   "toc3d_memory_post_update: in and out banks must be distinct (the update shifts every slot)");
     TOC3D_REQUIRE(B > 0 && B <= 65535 && topk > 0 && topk <= Q && memory_len > 0 && capacity == memory_len + topk && embed_dims > 0 && ld_bbox >= 5,
                   "toc3d_memory_post_update: bad dims (capacity must be memory_len + topk)");
-    hipLaunchKernelGGL(post_update_kernel, dim3((unsigned)capacity, (unsigned)B), dim3(64), 0, as_stream(stream),
+    toc3d_launch(post_update_kernel, dim3((unsigned)capacity, (unsigned)B), dim3(64), 0, as_stream(stream),
                        Bank{const_cast<float*>(emb_in), const_cast<float*>(ref_in), const_cast<double*>(ts_in), const_cast<float*>(pose_in), const_cast<float*>(vel_in)},
                        Bank{emb_out, ref_out, ts_out, pose_out, vel_out}, order, rec_ego_pose, bbox_preds, (int)ld_bbox, outs_dec, ego_pose, timestamp,
                        (int)B, (int)Q, (int)capacity, (int)topk, (int)embed_dims);

@@ -458,14 +458,14 @@ int toc3d_pack_motion_weights(const float* qe0_w, const float* qe0_b, const floa
                       {pe_bet_w, QD, QD, MW::pe_bet_w}, {q_red_w, QD, MD, MW::q_red_w}, {q_gam_w, QD, QD, MW::q_gam_w}, {q_bet_w, QD, QD, MW::q_bet_w},
                       {te_w, QD, QD, MW::te_w}};
     for (const M& m : mats)
-        hipLaunchKernelGGL(transpose_copy_kernel, dim3(64), dim3(256), 0, s, m.src, m.out_dim, m.in_dim, out + m.off);
+        toc3d_launch(transpose_copy_kernel, dim3(64), dim3(256), 0, s, m.src, m.out_dim, m.in_dim, out + m.off);
     struct Vv { const float* src; int n, off; };
     const Vv vecs[] = {{qe0_b, QD, MW::qe0_b}, {qe2_b, QD, MW::qe2_b}, {pe_red_b, QD, MW::pe_red_b}, {pe_gam_b, QD, MW::pe_gam_b},
                        {pe_bet_b, QD, MW::pe_bet_b}, {q_red_b, QD, MW::q_red_b}, {q_gam_b, QD, MW::q_gam_b}, {q_bet_b, QD, MW::q_bet_b},
                        {te_b, QD, MW::te_b}, {te_ln_w, QD, MW::te_ln_w}, {te_ln_b, QD, MW::te_ln_b}, {pc_range, 6, MW::pc_range},
                        {dimt3, 128, MW::dimt3}, {dimt1, 256, MW::dimt1}};
     for (const Vv& v : vecs)
-        hipLaunchKernelGGL(transpose_copy_kernel, dim3(1), dim3(256), 0, s, v.src, v.n, 1, out + v.off);
+        toc3d_launch(transpose_copy_kernel, dim3(1), dim3(256), 0, s, v.src, v.n, 1, out + v.off);
     TOC3D_LAUNCH_CHECK("toc3d_pack_motion_weights");
     return TOC3D_OK;
 }
@@ -477,7 +477,7 @@ int toc3d_motion_queries(const float* w, int64_t n_stages, int64_t w_stride, con
     TOC3D_REQUIRE(n_stages >= 1 && (n_stages == 1 || w_stride >= MW::total), "toc3d_motion_queries: bad n_stages / w_stride");
     if (B <= 0 || Q <= 0) return TOC3D_OK;
     const int64_t groups = (B * Q + QB - 1) / QB;
-    hipLaunchKernelGGL(motion_queries_kernel, dim3((unsigned)(n_stages * groups)), dim3(1024), 0, as_stream(stream), w, w_stride, queries, ref_points, vel,
+    toc3d_launch(motion_queries_kernel, dim3((unsigned)(n_stages * groups)), dim3(1024), 0, as_stream(stream), w, w_stride, queries, ref_points, vel,
                        timestamp, timestamp_is_f64, ego_pose, ego_pose_inv, (int)Q, (int)(B * Q), (int)groups, out);
     TOC3D_LAUNCH_CHECK("toc3d_motion_queries");
     return TOC3D_OK;
@@ -488,7 +488,7 @@ int toc3d_collapse_query_scorer(const float* mq, const float* w_in, const float*
     TOC3D_REQUIRE(mq && w_in && b_in && w_agg && b_agg && wc && bc, "toc3d_collapse_query_scorer: null buffer");
     if (B <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((C + 255) / 256), (unsigned)B);
-    hipLaunchKernelGGL(collapse_kernel, grid, dim3(256), 0, as_stream(stream), mq, w_in, b_in, w_agg, b_agg, (int)Q, (int)C, scale, wc, bc);
+    toc3d_launch(collapse_kernel, grid, dim3(256), 0, as_stream(stream), mq, w_in, b_in, w_agg, b_agg, (int)Q, (int)C, scale, wc, bc);
     TOC3D_LAUNCH_CHECK("toc3d_collapse_query_scorer");
     return TOC3D_OK;
 }
@@ -500,7 +500,7 @@ int toc3d_score_tokens(const float* x, int64_t C, const float* mask, const float
     TOC3D_REQUIRE(C % 4 == 0 && views_per_frame > 0 && V % views_per_frame == 0, "toc3d_score_tokens: bad dims");
     const int64_t M = V * T;
     if (M <= 0) return TOC3D_OK;
-    hipLaunchKernelGGL(score_tokens_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), x, (int)C, mask, wc, bc, gumbel, M, (int)T,
+    toc3d_launch(score_tokens_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), x, (int)C, mask, wc, bc, gumbel, M, (int)T,
                        (int)views_per_frame, pred, score, mask_out);
     TOC3D_LAUNCH_CHECK("toc3d_score_tokens");
     return TOC3D_OK;
@@ -513,9 +513,9 @@ int toc3d_score_head(int dtype, const void* f, int64_t ld, int64_t kdim, const f
     if (M <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((M + 3) / 4));
     if (dtype == TOC3D_BF16)
-        hipLaunchKernelGGL(score_head_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)f, ld, (int)kdim, w, b, gumbel, M, pred, score, mask_out);
+        toc3d_launch(score_head_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)f, ld, (int)kdim, w, b, gumbel, M, pred, score, mask_out);
     else if (dtype == TOC3D_F32)
-        hipLaunchKernelGGL(score_head_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)f, ld, (int)kdim, w, b, gumbel, M, pred, score, mask_out);
+        toc3d_launch(score_head_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)f, ld, (int)kdim, w, b, gumbel, M, pred, score, mask_out);
     else { toc3d_set_error("toc3d_score_head: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_score_head");
     return TOC3D_OK;
@@ -525,8 +525,8 @@ int toc3d_global_mean_half(int dtype, void* t, int64_t ld, int64_t V, int64_t T,
     TOC3D_REQUIRE(t && C % 2 == 0 && ld >= C, "toc3d_global_mean_half: bad arguments");
     if (V <= 0 || T <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((C / 2 + 63) / 64), (unsigned)V);
-    if (dtype == TOC3D_BF16) hipLaunchKernelGGL(global_mean_half_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)t, ld, (int)T, (int)C);
-    else if (dtype == TOC3D_F32) hipLaunchKernelGGL(global_mean_half_kernel<float>, grid, dim3(256), 0, as_stream(stream), (float*)t, ld, (int)T, (int)C);
+    if (dtype == TOC3D_BF16) toc3d_launch(global_mean_half_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (bf16_t*)t, ld, (int)T, (int)C);
+    else if (dtype == TOC3D_F32) toc3d_launch(global_mean_half_kernel<float>, grid, dim3(256), 0, as_stream(stream), (float*)t, ld, (int)T, (int)C);
     else { toc3d_set_error("toc3d_global_mean_half: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_global_mean_half");
     return TOC3D_OK;
@@ -539,7 +539,7 @@ int toc3d_abs_pos_bicubic(const float* pos, int64_t S, int64_t C, float* out, in
         if (e != hipSuccess) { toc3d_set_error("toc3d_abs_pos_bicubic: copy failed: %s", hipGetErrorString(e)); return TOC3D_ERR_LAUNCH; }
         return TOC3D_OK;
     }
-    hipLaunchKernelGGL(abs_pos_bicubic_kernel, dim3((unsigned)(h * w)), dim3(256), 0, as_stream(stream), pos, (int)S, (int)C, out, (int)h, (int)w);
+    toc3d_launch(abs_pos_bicubic_kernel, dim3((unsigned)(h * w)), dim3(256), 0, as_stream(stream), pos, (int)S, (int)C, out, (int)h, (int)w);
     TOC3D_LAUNCH_CHECK("toc3d_abs_pos_bicubic");
     return TOC3D_OK;
 }
@@ -549,8 +549,8 @@ int toc3d_im2col_3x3(int dtype, const float* x, void* out, int64_t ldo, int64_t 
     TOC3D_REQUIRE(x && out && ldo >= 9 * C, "toc3d_im2col_3x3: bad arguments");
     const int64_t M = V * h * w;
     if (M <= 0) return TOC3D_OK;
-    if (dtype == TOC3D_BF16) hipLaunchKernelGGL(im2col_3x3_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, as_stream(stream), x, (bf16_t*)out, ldo, (int)V, (int)h, (int)w, (int)C);
-    else if (dtype == TOC3D_F32) hipLaunchKernelGGL(im2col_3x3_kernel<float>, dim3((unsigned)M), dim3(256), 0, as_stream(stream), x, (float*)out, ldo, (int)V, (int)h, (int)w, (int)C);
+    if (dtype == TOC3D_BF16) toc3d_launch(im2col_3x3_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, as_stream(stream), x, (bf16_t*)out, ldo, (int)V, (int)h, (int)w, (int)C);
+    else if (dtype == TOC3D_F32) toc3d_launch(im2col_3x3_kernel<float>, dim3((unsigned)M), dim3(256), 0, as_stream(stream), x, (float*)out, ldo, (int)V, (int)h, (int)w, (int)C);
     else { toc3d_set_error("toc3d_im2col_3x3: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_im2col_3x3");
     return TOC3D_OK;

@@ -508,6 +508,14 @@ __global__ __launch_bounds__(256) void ln_rebase_kernel(float* __restrict__ slow
     wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, out + (int64_t)row * ldo);
 }
 
+// plain device-to-device copy as a kernel, so that it can live inside a recorded launch plan (16-byte body, byte tail)
+__global__ __launch_bounds__(256) void copy_bytes_kernel(char* __restrict__ dst, const char* __restrict__ src, int64_t n16, int64_t nbytes) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C) {
     __shared__ float tile[32][33];
     const int v = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -536,7 +544,7 @@ int toc3d_layernorm_rows(int dtype, const float* x, int64_t ldx, const int32_t* 
     if (M <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((M + 3) / 4)), block(256);
     hipStream_t s = as_stream(stream);
-#define LNR(T, MV) hipLaunchKernelGGL((ln_rows_kernel<T, MV>), grid, block, 0, s, x, ldx, row_index, row_scale, gamma, beta, eps, (T*)out, ldo, (int)M, (int)C)
+#define LNR(T, MV) toc3d_launch((ln_rows_kernel<T, MV>), grid, block, 0, s, x, ldx, row_index, row_scale, gamma, beta, eps, (T*)out, ldo, (int)M, (int)C)
     if (dtype == TOC3D_BF16) { if (C <= 1024) LNR(bf16_t, 4); else LNR(bf16_t, 8); }
     else if (dtype == TOC3D_F32) { if (C <= 1024) LNR(float, 4); else LNR(float, 8); }
     else { toc3d_set_error("toc3d_layernorm_rows: bad dtype"); return TOC3D_ERR_ARG; }
@@ -553,7 +561,7 @@ int toc3d_layernorm_act(int dtype, const void* x, int64_t ldx, const float* gamm
     if (M <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((M + 3) / 4)), block(256);
     hipStream_t s = as_stream(stream);
-#define LNA(T, MC) hipLaunchKernelGGL((ln_act_kernel<T, MC>), grid, block, 0, s, (const T*)x, ldx, gamma, beta, eps, (T*)out, ldo, (int)M, (int)n)
+#define LNA(T, MC) toc3d_launch((ln_act_kernel<T, MC>), grid, block, 0, s, (const T*)x, ldx, gamma, beta, eps, (T*)out, ldo, (int)M, (int)n)
     const int mc = (int)((ldo / 8 + 63) / 64);
     if (dtype == TOC3D_BF16) { if (mc <= 2) LNA(bf16_t, 2); else if (mc <= 6) LNA(bf16_t, 6); else LNA(bf16_t, 12); }
     else if (dtype == TOC3D_F32) { if (mc <= 2) LNA(float, 2); else if (mc <= 6) LNA(float, 6); else LNA(float, 12); }
@@ -569,8 +577,9 @@ int toc3d_rank_desc(const float* scores, int64_t B, int64_t n, int64_t* order, t
     if (B <= 0 || n == 0) return TOC3D_OK;
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)B);
     const size_t lds = (size_t)n * 8;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_desc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(rank_desc_kernel, grid, dim3(256), lds, as_stream(stream), scores, (int)n, order);
+    static Toc3dLdsAttr rank_attr;
+    if (lds > 64 * 1024) rank_attr.ensure(reinterpret_cast<const void*>(&rank_desc_kernel), 160 * 1024);
+    toc3d_launch(rank_desc_kernel, grid, dim3(256), lds, as_stream(stream), scores, (int)n, order);
     TOC3D_LAUNCH_CHECK("toc3d_rank_desc");
     return TOC3D_OK;
 }
@@ -597,8 +606,9 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
     TOC3D_REQUIRE(k >= 0 && k < N, "toc3d_window_topk: k=%lld outside [0, %lld) (keep-all is the dense Block path)", (long long)k, (long long)N);
     const int nW = (int)(V * ((h + L - 1) / L) * ((w + L - 1) / L));
     const size_t lds = (size_t)((N + 1) & ~(int64_t)1) * 8 + (size_t)N * 12 + 64;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipLaunchKernelGGL(window_topk_kernel, dim3(nW), dim3(1024), lds, as_stream(stream), scores, (int)V, (int)h, (int)w,
+    static Toc3dLdsAttr topk_attr;
+    if (lds > 64 * 1024) topk_attr.ensure(reinterpret_cast<const void*>(&window_topk_kernel), 96 * 1024);
+    toc3d_launch(window_topk_kernel, dim3(nW), dim3(1024), lds, as_stream(stream), scores, (int)V, (int)h, (int)w,
                        (int)L, (int)k, order, tok, wgt, prow, crow_tok, rep_index, rep_row, arows, aslots, acount_q, acount_k);
     TOC3D_LAUNCH_CHECK("toc3d_window_topk");
     return TOC3D_OK;
@@ -610,18 +620,20 @@ int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* t
     TOC3D_REQUIRE(x && tok && wgt && crow_tok && rep_row && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln: null buffer");
     TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
     TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW, "toc3d_gather_merge_ln: bad k / lda / rows");
+    // each of the 16 waves prefetches the index / weight of its share of the dropped tokens in its 64 lanes
+    TOC3D_REQUIRE(N - k <= 1024, "toc3d_gather_merge_ln: N - k = %lld dropped tokens per window exceed the kernel's 1024", (long long)(N - k));
     if (nW <= 0) return TOC3D_OK;
     dim3 grid((unsigned)(nW + (rows + 15) / 16)), block(1024);
     const size_t lds = (size_t)16 * C * 4;
     hipStream_t s = as_stream(stream);
     if (dtype == TOC3D_BF16) {
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_merge_ln_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); set = true; }
-        hipLaunchKernelGGL((gather_merge_ln_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (bf16_t*)a_out, lda);
+        static Toc3dLdsAttr attr;
+        attr.ensure(reinterpret_cast<const void*>(&gather_merge_ln_kernel<bf16_t, 4>), 65536);
+        toc3d_launch((gather_merge_ln_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (bf16_t*)a_out, lda);
     } else if (dtype == TOC3D_F32) {
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_merge_ln_kernel<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); set = true; }
-        hipLaunchKernelGGL((gather_merge_ln_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (float*)a_out, lda);
+        static Toc3dLdsAttr attr;
+        attr.ensure(reinterpret_cast<const void*>(&gather_merge_ln_kernel<float, 4>), 65536);
+        toc3d_launch((gather_merge_ln_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (float*)a_out, lda);
     } else { toc3d_set_error("toc3d_gather_merge_ln: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln");
     return TOC3D_OK;
@@ -635,7 +647,7 @@ int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t*
     TOC3D_REQUIRE(C > 0 && C % 4 == 0 && k >= 0 && k < N, "toc3d_scatter_update: bad dims");
     if (nW <= 0 || N <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((nW * N + 3) / 4));
-    hipLaunchKernelGGL(scatter_update_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)C, tok, prow, (int)nW, (int)N, (int)k, slow_out, rep_raw1, rep_raw2, rep_raw3, rep_raw4);
+    toc3d_launch(scatter_update_kernel, grid, dim3(256), 0, as_stream(stream), x, (int)C, tok, prow, (int)nW, (int)N, (int)k, slow_out, rep_raw1, rep_raw2, rep_raw3, rep_raw4);
     TOC3D_LAUNCH_CHECK("toc3d_scatter_update");
     return TOC3D_OK;
 }
@@ -648,7 +660,7 @@ int toc3d_rebase_layernorm_rows(int dtype, float* slow, int64_t C, const int32_t
     if (rows <= 0) return TOC3D_OK;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t s = as_stream(stream);
-#define LNB(T, MV) hipLaunchKernelGGL((ln_rebase_kernel<T, MV>), grid, block, 0, s, slow, (int)C, rep_index, tok, wgt, (int)N, (int)k, rep_raw1, rep_raw2, gamma, beta, eps, (T*)out, ldo, (int)rows)
+#define LNB(T, MV) toc3d_launch((ln_rebase_kernel<T, MV>), grid, block, 0, s, slow, (int)C, rep_index, tok, wgt, (int)N, (int)k, rep_raw1, rep_raw2, gamma, beta, eps, (T*)out, ldo, (int)rows)
     if (dtype == TOC3D_BF16) { if (C <= 1024) LNB(bf16_t, 4); else LNB(bf16_t, 8); }
     else if (dtype == TOC3D_F32) { if (C <= 1024) LNB(float, 4); else LNB(float, 8); }
     else { toc3d_set_error("toc3d_rebase_layernorm_rows: bad dtype"); return TOC3D_ERR_ARG; }
@@ -657,10 +669,22 @@ int toc3d_rebase_layernorm_rows(int dtype, float* slow, int64_t C, const int32_t
     return TOC3D_OK;
 }
 
+int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(nbytes >= 0 && (nbytes == 0 || (dst && src)), "toc3d_copy_bytes: bad arguments");
+    if (nbytes == 0) return TOC3D_OK;
+    const bool aligned = ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0;
+    const int64_t n16 = aligned ? nbytes / 16 : 0;
+    const int64_t work = n16 > 0 ? n16 : nbytes;
+    const int blocks = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+    toc3d_launch(copy_bytes_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (char*)dst, (const char*)src, n16, nbytes);
+    TOC3D_LAUNCH_CHECK("toc3d_copy_bytes");
+    return TOC3D_OK;
+}
+
 int toc3d_nhwc_to_nchw(const float* x, float* out, int64_t V, int64_t T, int64_t C, toc3d_stream_t stream) {
     TOC3D_REQUIRE(x && out && V > 0 && T > 0 && C > 0, "toc3d_nhwc_to_nchw: bad arguments");
     dim3 grid((unsigned)((T + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)V);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(stream), x, out, (int)T, (int)C);
+    toc3d_launch(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(stream), x, out, (int)T, (int)C);
     TOC3D_LAUNCH_CHECK("toc3d_nhwc_to_nchw");
     return TOC3D_OK;
 }

@@ -84,7 +84,8 @@ class HeadTokenEmbedding(nn.Module):
     @torch.no_grad()
     def forward(self, img_feats: torch.Tensor, intrinsics: torch.Tensor, lidar2img: torch.Tensor, pad_shape):
         """img_feats (B, N, C, h, w) f32 (neck level 0, ``data['img_feats']`` :626); intrinsics / lidar2img (B, N, 4, 4);
-        pad_shape = (pad_h, pad_w[, 3]) of ``img_metas[0]['pad_shape'][0]``.  Returns (memory, pos_embed), f32 (B, N*h*w, embed_dims)."""
+        pad_shape = (pad_h, pad_w[, 3]) of ``img_metas[0]['pad_shape'][0]``.  Returns (memory, pos_embed, cone): memory and pos_embed
+        f32 (B, N*h*w, embed_dims), cone f32 (B, N*h*w, 8) (:419-421) -- all three freshly allocated, none aliases a workspace."""
         if not isinstance(img_feats, torch.Tensor) or not img_feats.is_cuda:
             raise RuntimeError("toc3d_amd.HeadTokenEmbedding: inputs must be CUDA/HIP tensors -- the HIP extension is the only compute path")
         dev = img_feats.device
@@ -134,4 +135,4 @@ class HeadTokenEmbedding(nn.Module):
         linear(W["mem_a"], P["se1"], W["s1"], E, E, relu=True)
         linear(W["s1"], P["se2"], W["se"], E, E, f32_out=True)
         lib.call("toc3d_se_gate", W["pos"], W["se"], pos_embed, M * E, s)
-        return memory.view(B, N * h * w, E), pos_embed.view(B, N * h * w, E), W["cone"].view(B, N * h * w, 8)
+        return memory.view(B, N * h * w, E), pos_embed.view(B, N * h * w, E), W["cone"].clone().view(B, N * h * w, 8)

@@ -53,6 +53,13 @@ _SIGS = {
     "toc3d_memory_pre_update": "pppppppppplllllip",
     "toc3d_memory_scores": "pllpp",
     "toc3d_memory_post_update": "ppppppppppppplpppllllllp",
+    "toc3d_copy_bytes": "pplp",
+    "toc3d_plan_create": "p",
+    "toc3d_plan_destroy": "p",
+    "toc3d_plan_begin": "p",
+    "toc3d_plan_wait": "pll",
+    "toc3d_plan_end": "pi",
+    "toc3d_plan_run": "pp",
 }
 _CT = {"p": _P, "l": _I64, "i": _I, "f": _F}
 
@@ -80,6 +87,10 @@ def load():
     lib.toc3d_motion_weights_floats.restype = _I64
     lib.toc3d_window_topk_rows.restype = _I64
     lib.toc3d_window_topk_rows.argtypes = [_I64] * 5
+    lib.toc3d_plan_lane_stream.restype = _P
+    lib.toc3d_plan_lane_stream.argtypes = [_I64]
+    lib.toc3d_plan_num_launches.restype = _I64
+    lib.toc3d_plan_num_launches.argtypes = [_P]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -107,6 +118,18 @@ def call(name: str, *args):
         raise RuntimeError(f"{name} failed ({rc}): {lib.toc3d_last_error().decode()}")
 
 
+# Lane of the launch plan being recorded by this thread (toc3d_amd/plan.py); None = launch on torch's current stream.
+_rec_lane = None
+
+
 def stream_ptr():
+    """The `stream` argument of a C-ABI call: torch's current HIP stream, or -- while a launch plan is being recorded -- the
+    handle of the current lane (include/toc3d.h, toc3d_plan_lane_stream)."""
+    if _rec_lane is not None:
+        return load().toc3d_plan_lane_stream(_rec_lane)
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def recording() -> bool:
+    return _rec_lane is not None

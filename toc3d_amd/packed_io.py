@@ -58,11 +58,18 @@ def fingerprint(model) -> Dict[str, Any]:
     fp = dict(cls=type(model).__name__, precision=model.precision, embed_dim=model.embed_dim, depth=model.depth, num_heads=model.num_heads,
               hidden_dim=model.hidden_dim, patch_size=model.patch_size, window_size=model.window_size,
               global_window_size=model.global_window_size, global_attn_indexes=list(model.global_attn_indexes),
+              in_chans=model.in_chans, pretrain_use_cls_token=bool(model.pretrain_use_cls_token),
+              # everything that shapes or gives meaning to a packed buffer: the abs-pos source grid (None = use_abs_pos False), the RoPE
+              # table sides (img_size / patch for the global blocks), the scorer scale and the point-cloud range baked into the motion tables
+              pos_embed_rows=None if model.pos_embed is None else int(model.pos_embed.shape[1]),
+              rope_sides=[int(model.rope_win.freqs_cos.shape[0]), int(model.rope_glb.freqs_cos.shape[0])],
               abi=int(lib.load().toc3d_abi_version()))
-    for k in ("pruning_loc", "token_ratio", "pruning_num_queries", "accelerate_global"):
+    for k in ("pruning_loc", "token_ratio", "pruning_num_queries", "accelerate_global", "pruning_attn_scale"):
         if hasattr(model, k):
             v = getattr(model, k)
             fp[k] = list(v) if isinstance(v, (list, tuple)) else v
+    if hasattr(model, "score_predictor") and len(model.score_predictor):
+        fp["pc_range"] = [round(float(v), 6) for v in model.score_predictor[0].pc_range.detach().cpu().tolist()]
     return fp
 
 
@@ -103,13 +110,17 @@ def load_packed(model, path: str):
     P["pos"] = {tuple(int(i) for i in k.split("x")): v for k, v in P.get("pos", {}).items()}
     P["dev"] = dev
     model._packed = P
+    model._plans = {}                      # recorded launch plans point into the previous packed buffers
 
 
-def convert_checkpoint(ckpt_path: str, cfg: dict, out_path: str, prefix: str = "img_backbone.", device: str = "cuda"):
+def convert_checkpoint(ckpt_path: str, cfg: dict, out_path: str, prefix: str = "img_backbone.", device: str = "cuda",
+                       trust_pickle: bool = False):
     """``.pth`` of the reference detector (``tools/test.py:207``; keys ``img_backbone.*``) -> packed file for ``cfg``
-    (a backbone config dict, ``type`` included).  Returns the backbone it built."""
+    (a backbone config dict, ``type`` included).  Returns the backbone it built.  The checkpoint is read with
+    ``weights_only=True`` (tensors and plain containers only); ``trust_pickle=True`` opts into full unpickling for checkpoints
+    whose ``meta`` holds arbitrary objects -- only for files you trust, unpickling can run code."""
     from .registry import build_backbone
-    ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    ck = torch.load(ckpt_path, map_location="cpu", weights_only=not trust_pickle)
     sd = ck.get("state_dict", ck)
     sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)} if prefix else dict(sd)
     if not sub:
