@@ -83,7 +83,8 @@ def main():
     ap.add_argument("--config", default="toc3d_faster")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--hw", default="320x800")
-    ap.add_argument("--groups", type=int, default=2, help="concurrent view groups (independent views on separate HIP streams)")
+    ap.add_argument("--groups", type=int, default=1, help="concurrent view groups (independent views on separate lanes / HIP streams); "
+                    "measured r02: one lane replayed from a launch plan is as fast as two eagerly issued ones and steadier than two replayed ones")
     ap.add_argument("--launch", default="plan", choices=["plan", "graph", "eager"],
                     help="plan: the frame's launch sequence recorded once and replayed from C on HIP streams (toc3d_plan_run); "
                          "graph: the same recording as an explicitly built hipGraph; eager: every launch issued from Python")

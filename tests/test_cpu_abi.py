@@ -101,3 +101,85 @@ def test_launch_plan_api_validates_without_gpu():
     assert l.toc3d_plan_end(h.value, 0) == -1 and b"nothing was recorded" in l.toc3d_last_error()
     assert l.toc3d_plan_destroy(h.value) == 0 and l.toc3d_plan_destroy(h2.value) == 0
     assert l.toc3d_plan_begin(None) == -1
+
+
+def test_return_type_binds_to_the_plugin_class_when_the_plugin_is_imported():
+    """petr3d.py:159 does isinstance(out, ToC3DViTReturnType) with the plugin's class (petr3d.py:17): once that module is in
+    sys.modules the backbone returns the plugin's class, no manual re-binding."""
+    import sys
+    import types
+    from toc3d_amd import backbone as bb
+    name = "projects.mmdet3d_plugin.models.backbones.toc3d_utils"
+    assert name not in sys.modules and bb._return_type() is bb.ToC3DViTReturnType
+
+    class PluginReturnType:                                    # stands in for toc3d_utils.py:10-25 (same constructor signature)
+        def __init__(self, img_feats=None, token_masks=None, attn_scores=None, keep_idx=None, drop_idx=None, aux_outputs=None):
+            self.img_feats, self.token_masks, self.keep_idx, self.drop_idx = img_feats, token_masks, keep_idx, drop_idx
+    mod = types.ModuleType(name)
+    mod.ToC3DViTReturnType = PluginReturnType
+    sys.modules[name] = mod
+    try:
+        assert bb._return_type() is PluginReturnType
+        out = bb._return_type()({"last_feat": 1}, None, None, keep_idx=None, drop_idx=None, aux_outputs=None)
+        assert isinstance(out, PluginReturnType) and out.img_feats == {"last_feat": 1}
+    finally:
+        del sys.modules[name]
+
+
+def test_registration_on_an_mmcv_style_registry():
+    """The HAVE_MMDET branch of toc3d_amd/registry.py: with mmdet.models.builder importable, the classes are registered on ITS
+    registries under the reference's type names (force=True shadows the plugin's own registration) and built through them."""
+    import importlib
+    import sys
+    import types
+
+    class Registry:                                            # the slice of mmcv.utils.Registry the plugin relies on
+        def __init__(self, name):
+            self.name, self._module_dict = name, {}
+
+        @property
+        def module_dict(self):
+            return self._module_dict
+
+        def register_module(self, name=None, force=False, module=None):
+            def _register(cls):
+                key = name or cls.__name__
+                if not force and key in self._module_dict:
+                    raise KeyError(f"{key} is already registered in {self.name}")
+                self._module_dict[key] = cls
+                return cls
+            return _register(module) if module is not None else _register
+
+        def get(self, key):
+            return self._module_dict.get(key)
+
+        def build(self, cfg):
+            cfg = dict(cfg)
+            return self._module_dict[cfg.pop("type")](**cfg)
+
+    class RefBackbone:                                         # what the plugin registered first
+        pass
+    fake = {n: types.ModuleType(n) for n in ("mmdet", "mmdet.models", "mmdet.models.builder")}
+    fake["mmdet.models.builder"].BACKBONES, fake["mmdet.models.builder"].NECKS = Registry("backbone"), Registry("neck")
+    fake["mmdet.models.builder"].BACKBONES.register_module(name="ToC3DEVAViT", module=RefBackbone)
+    saved = {n: sys.modules.get(n) for n in fake}
+    sys.modules.update(fake)
+    from toc3d_amd import registry
+    try:
+        reg = importlib.reload(registry)
+        assert reg.HAVE_MMDET and reg.BACKBONES is fake["mmdet.models.builder"].BACKBONES
+        reg.register_all()
+        assert reg.BACKBONES.get("ToC3DEVAViT") is toc3d_amd.ToC3DEVAViT and reg.BACKBONES.get("EVA_ViT") is toc3d_amd.EVA_ViT
+        assert reg.NECKS.get("CPFPN") is toc3d_amd.CPFPN
+        m = reg.build_backbone(configs.get("toc3d_tiny"), precision="fp32")
+        assert isinstance(m, toc3d_amd.ToC3DEVAViT) and m.precision == "fp32"
+        assert isinstance(reg.build_neck(configs.CPFPN_TINY), toc3d_amd.CPFPN)
+    finally:
+        for n, v in saved.items():
+            if v is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = v
+        importlib.reload(registry)
+        registry.register_all()
+    assert not registry.HAVE_MMDET

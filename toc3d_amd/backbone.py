@@ -44,6 +44,16 @@ class ToC3DViTReturnType:
         self.aux_outputs = aux_outputs
 
 
+def _return_type():
+    """The class forward() returns.  ``Petr3D.extract_img_feat`` tests ``isinstance(out, ToC3DViTReturnType)`` against the class it
+    imported from the reference plugin (``detectors/petr3d.py:17,159``): when that plugin module has been imported in this process
+    (the detector did), its class is used, so the drop-in needs no manual re-binding; otherwise the local twin above."""
+    import sys
+    ref = sys.modules.get("projects.mmdet3d_plugin.models.backbones.toc3d_utils")
+    cls = getattr(ref, "ToC3DViTReturnType", None) if ref is not None else None
+    return cls if isinstance(cls, type) else ToC3DViTReturnType
+
+
 def _round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
@@ -349,7 +359,7 @@ class _BackboneBase(nn.Module):
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
     _flush = None               # 256 MB scratch shared by all models: evicts L2 + Infinity Cache between tuning launches
-    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 110, 114, 116, 117, 126, 145, 147, 149),
+    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 163),
                  lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
@@ -1010,5 +1020,5 @@ class ToC3DEVAViT(_BackboneBase):
             order = cl(plan["order"][s])
             keep.append(order[:, :kimg])
             drop.append(order[:, kimg:])
-        return ToC3DViTReturnType({self._out_features[0]: self._feature_view(plan)}, masks or None, None,
-                                  keep_idx=keep or None, drop_idx=drop or None, aux_outputs=None)
+        return _return_type()({self._out_features[0]: self._feature_view(plan)}, masks or None, None,
+                              keep_idx=keep or None, drop_idx=drop or None, aux_outputs=None)

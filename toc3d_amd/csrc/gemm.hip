@@ -93,6 +93,94 @@ TOC3D_DEV void tile_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// ---- epilogue of one wavefront's (MT*16) x (NT*16) accumulator block whose first row / column are row0 / col0.  The MFMA is issued
+// with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
+// .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
+// alignment / leading dims) enables the vector path. ----
+template <typename T, int EPI, int MT, int NT>
+TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, int col0, int r16, int g) {
+    if (EPI == TOC3D_EPI_SWIGLU) {
+        // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
+        T* out = reinterpret_cast<T*>(a.out);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = row0 + i * 16 + r16;
+#pragma unroll
+            for (int jp = 0; jp < NT / 2; ++jp) {
+                const int pc = col0 + jp * 32 + g * 4;    // packed col of the w1 half, first of 4
+                const int unit0 = (pc >> 5) * 16 + g * 4;
+                if (pc < a.N && row < a.M) {
+                    T hs[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x1 = acc[i][2 * jp][r] + a.bias[pc + r], x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
+                        hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu(x1) * x2 : 0.f);
+                    }
+                    T* dst = out + (int64_t)row * a.ldo + unit0;
+                    if (a.vec) store4(dst, hs);
+                    else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
+                }
+            }
+        }
+        return;
+    }
+    float bcol[NT][4];
+    int nok[NT];                                         // valid columns among the lane's 4 (0..4)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = col0 + j * 16 + g * 4;
+        nok[j] = a.N - col < 0 ? 0 : (a.N - col > 4 ? 4 : a.N - col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = row0 + i * 16 + r16;
+        if (row >= a.M) continue;
+        if (EPI == TOC3D_EPI_RESIDUAL) {
+            // the modular residual row and the representative-row test cost an integer division / a load each: once per row
+            const int rr = a.res_mod > 0 ? row % a.res_mod : row;
+            const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
+            float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
+            float* reprow = nullptr;
+            if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (nok[j] == 0) continue;
+                const int col = col0 + j * 16 + g * 4;
+                float raw[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) raw[r] = acc[i][j][r] + bcol[j][r];
+                if (a.vec && nok[j] == 4) {
+                    f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{rv[0] + raw[0], rv[1] + raw[1], rv[2] + raw[2], rv[3] + raw[3]};
+                    if (reprow) *reinterpret_cast<f32x4*>(reprow + col) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+                } else {
+                    for (int r = 0; r < nok[j]; ++r) {
+                        orow[col + r] = (resrow ? resrow[col + r] : 0.f) + raw[r];
+                        if (reprow) reprow[col + r] = raw[r];
+                    }
+                }
+            }
+        } else {
+            T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (nok[j] == 0) continue;
+                const int col = col0 + j * 16 + g * 4;
+                T o4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float raw = acc[i][j][r] + bcol[j][r];
+                    o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
+                }
+                if (a.vec && nok[j] == 4) store4(orow + col, o4);
+                else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
+            }
+        }
+    }
+}
+
 // Multi-stage pipeline: the LDS ring holds STAGES K-tiles; tile t+STAGES-1 is requested while tile t is
 // multiplied, so a K step no longer exposes an HBM/L2 round trip.  The in-flight global_load_lds are
 // tracked with a *counted* s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain them to
@@ -186,89 +274,162 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    // ---- epilogue.  The MFMA is issued with the operands swapped (W fragment as A, activation fragment as B), so a lane
-    // holds C[row = .. + r16][4 consecutive cols = .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of
-    // 2- / 4-byte scattered ones.  a.vec (host-checked alignment / leading dims) enables the vector path. ----
-    if (EPI == TOC3D_EPI_SWIGLU) {
-        // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
-        T* out = reinterpret_cast<T*>(a.out);
+    gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Phased big-tile kernel (bf16): BM x BN per 512-thread workgroup, ONE workgroup per CU, latency hidden inside the workgroup.
+//
+// The 128x128 family above is bound by the L2 -> LDS fill rate (32 KB per 2.1 MFLOP K-step) and hides
+// latency only through co-resident workgroups.  Here a K-step of a 256x256 tile brings 64 KB for 8.4 MFLOP (half the bytes per
+// FLOP), every wavefront owns a 128x64 block (half the LDS read bytes per FLOP of the 64x32 blocks above), and the K loop is
+// cut into four *phases* per 64-deep K-tile (cdna_hip_programming.md "8-phase" template, re-derived for this ring):
+//
+//   the wave's block = 2 x 2 sub-blocks (a0 | a1 rows) x (b0 | b1 columns); the LDS ring holds two K-tiles, each as four
+//   half-tiles  A0 A1 B0 B1  (A_h = the a_h rows of every wave row, B_h likewise);
+//   phase 1: read B0, A0 | stage A1[t+1] | MFMA a0.b0          phase 3: read A1 | stage A0[t+2] | MFMA a1.b1
+//   phase 2: read B1     | stage B0[t+1] | MFMA a0.b1          phase 4: read B0 | stage B1[t+2], wait | MFMA a1.b0
+//
+//   each phase = [LDS reads + one half-tile of global_load_lds] s_barrier [MFMAs] s_barrier, and the second half of the
+//   wavefronts (waves 4-7, which share the SIMDs of waves 0-3) runs ONE barrier behind the first: on every SIMD one wave is in its
+//   MFMA segment while its partner issues loads, so the matrix pipe and the memory path stay busy from a single workgroup.
+//
+// Hazards (both wave groups, the lagging one included):
+//   RAW  a half-tile is read one phase or more after the counted s_waitcnt vmcnt that retires it (phase 4, once per K-tile: only
+//        the two newest half-tiles may still be in flight) and a barrier every wave has passed;
+//   WAR  a slot is restaged two phases or more after its last read (A0: read ph1 -> restaged ph3; B1: ph2 -> ph4; A1: ph3 -> next
+//        ph1; B0: ph4 -> next ph2), i.e. behind a barrier that follows the readers' own lgkmcnt(0).
+// ---------------------------------------------------------------------------------------------------
+template <int ROWS, int TB, int NTHR>
+TOC3D_DEV void stage_half(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0, int h, char* lds_half, int wave, int lane) {
+    // half-tile h of an operand whose wave blocks are TB rows tall: LDS row lr = (wave-row w) * TB/2 + j  <->  tile row w * TB + h * TB/2 + j
+    constexpr int L = ROWS * 8 / NTHR;
+    static_assert(L * NTHR == ROWS * 8, "half-tile must be a whole number of 16-byte loads per thread");
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int row = m0 + wm * TM + i * 16 + r16;
-#pragma unroll
-            for (int jp = 0; jp < NT / 2; ++jp) {
-                const int pc = n0 + wn * TN + jp * 32 + g * 4;    // packed col of the w1 half, first of 4
-                const int unit0 = (pc >> 5) * 16 + g * 4;
-                if (pc < a.N && row < a.M) {
-                    T hs[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x1 = acc[i][2 * jp][r] + a.bias[pc + r], x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
-                        hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu(x1) * x2 : 0.f);
-                    }
-                    T* dst = out + (int64_t)row * a.ldo + unit0;
-                    if (a.vec) store4(dst, hs);
-                    else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
-                }
-            }
-        }
-        return;
+    for (int i = 0; i < L; ++i) {
+        const int c = i * NTHR + wave * 64 + lane;
+        const int lr = c >> 3, p = c & 7;
+        const int w = lr / (TB / 2), j = lr % (TB / 2);
+        int gr = row0 + w * TB + h * (TB / 2) + j;
+        gr = gr < max_row ? gr : max_row;
+        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ (lr & 7)) << 4);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_half + (i * NTHR + wave * 64) * 16), 16, 0, 0);
     }
-    float bcol[NT][4];
-    int nok[NT];                                         // valid columns among the lane's 4 (0..4)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int col = n0 + wn * TN + j * 16 + g * 4;
-        nok[j] = a.N - col < 0 ? 0 : (a.N - col > 4 ? 4 : a.N - col);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
+}
+
+template <int EPI, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(WM * WN == 8, "eight wavefronts");
+    constexpr int NTHR = 512;
+    constexpr int TM = BM / WM, TN = BN / WN;             // per-wave block
+    constexpr int HM = TM / 2, HN = TN / 2;               // sub-blocks
+    constexpr int MT2 = HM / 16, NT2 = HN / 16;           // MFMA tiles per sub-block
+    static_assert(HM % 16 == 0 && HN % 16 == 0, "sub-blocks are whole MFMA tiles");
+    constexpr int AH = (BM / 2) * 128, BH = (BN / 2) * 128;   // bytes per half-tile (128-byte rows: 64 bf16 of K)
+    constexpr int KT = 2 * AH + 2 * BH;                   // one K-tile in the ring: A0 | A1 | B0 | B1
+    constexpr int LA = (BM / 2) * 8 / NTHR, LB = (BN / 2) * 8 / NTHR;   // global_load_lds per thread per half-tile
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, g = lane >> 4;
+    const bool late = wave >= 4;                          // the group that runs one barrier behind
+
+    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    int m0, n0;
+    if (a.order == 0) {
+        const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        m0 = (tile / tiles_n) * BM;
+        n0 = (tile % tiles_n) * BN;
+    } else {
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int r0 = (xcd * tiles_m) >> 3, r1 = ((xcd + 1) * tiles_m) >> 3;
+        const int band = r1 - r0;
+        if (band <= 0 || l >= band * tiles_n) return;
+        m0 = (r0 + l % band) * BM;
+        n0 = (l / band) * BN;
     }
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
+    const int nk = a.K / 64;
+    const int a_max = a.M - 1, w_max = ((a.N + 127) / 128) * 128 - 1;
+
+    f32x4 acc[2 * MT2][2 * NT2];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = m0 + wm * TM + i * 16 + r16;
-        if (row >= a.M) continue;
-        if (EPI == TOC3D_EPI_RESIDUAL) {
-            // the modular residual row and the representative-row test cost an integer division / a load each: once per row
-            const int rr = a.res_mod > 0 ? row % a.res_mod : row;
-            const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
-            float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
-            float* reprow = nullptr;
-            if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
+    for (int i = 0; i < 2 * MT2; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (nok[j] == 0) continue;
-                const int col = n0 + wn * TN + j * 16 + g * 4;
-                float raw[4];
+        for (int j = 0; j < 2 * NT2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Frag<bf16_t> fa[MT2][2], fb[NT2][2];                  // [tile][32-wide K step]
+
+    auto slot = [&](int t, int kind, int h) -> char* { return smem + (t & 1) * KT + kind * 2 * AH + h * (kind ? BH : AH); };
+    auto stage_a = [&](int t, int h) { stage_half<BM / 2, TM, NTHR>(A, a.lda, m0, a_max, t * 64, h, slot(t, 0, h), wave, lane); };
+    auto stage_b = [&](int t, int h) { stage_half<BN / 2, TN, NTHR>(W, a.ldw, n0, w_max, t * 64, h, slot(t, 1, h), wave, lane); };
+    auto read_a = [&](int t, int h) {
+        const char* base = slot(t, 0, h);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) raw[r] = acc[i][j][r] + bcol[j][r];
-                if (a.vec && nok[j] == 4) {
-                    f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{rv[0] + raw[0], rv[1] + raw[1], rv[2] + raw[2], rv[3] + raw[3]};
-                    if (reprow) *reinterpret_cast<f32x4*>(reprow + col) = f32x4{raw[0], raw[1], raw[2], raw[3]};
-                } else {
-                    for (int r = 0; r < nok[j]; ++r) {
-                        orow[col + r] = (resrow ? resrow[col + r] : 0.f) + raw[r];
-                        if (reprow) reprow[col + r] = raw[r];
-                    }
-                }
-            }
-        } else {
-            T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
+        for (int i = 0; i < MT2; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (nok[j] == 0) continue;
-                const int col = n0 + wn * TN + j * 16 + g * 4;
-                T o4[4];
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_frag<128>(base, wm * HM + i * 16 + r16, ks, g, bf16_t());
+    };
+    auto read_b = [&](int t, int h) {
+        const char* base = slot(t, 1, h);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float raw = acc[i][j][r] + bcol[j][r];
-                    o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
-                }
-                if (a.vec && nok[j] == 4) store4(orow + col, o4);
-                else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
-            }
-        }
+        for (int j = 0; j < NT2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = lds_frag<128>(base, wn * HN + j * 16 + r16, ks, g, bf16_t());
+    };
+    auto mfma = [&](auto HA, auto HB) {
+        constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT2; ++j) mma_step(acc[ha * MT2 + i][hb * NT2 + j], fb[j][ks], fa[i][ks]);   // swapped: see gemm_epilogue
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- prologue: K-tile 0 complete, A0 / B1 of K-tile 1 on their way (what phases 3, 4 of a tile "-1" would have staged) ----
+    stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1);
+    if (nk > 1) { stage_a(1, 0); stage_b(1, 1); wait_vmcnt<LA + LB>(); }
+    else wait_vmcnt<0>();
+    tile_barrier();
+    if (late) tile_barrier();
+
+    for (int t = 0; t < nk; ++t) {
+        const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+        // phase 1
+        read_b(t, 0); read_a(t, 0);
+        if (n1) stage_a(t + 1, 1);
+        tile_barrier();
+        mfma(I0(), I0());
+        tile_barrier();
+        // phase 2
+        read_b(t, 1);
+        if (n1) stage_b(t + 1, 0);
+        tile_barrier();
+        mfma(I0(), I1());
+        tile_barrier();
+        // phase 3
+        read_a(t, 1);
+        if (n2) stage_a(t + 2, 0);
+        tile_barrier();
+        mfma(I1(), I1());
+        tile_barrier();
+        // phase 4: everything of K-tile t+1 that phase 1 reads must have landed (A0, B0; B1 / A1 are older): only A0 / B1 of K-tile t+2,
+        // staged in phase 3 and here, may stay in flight
+        read_b(t, 0);
+        if (n2) { stage_b(t + 2, 1); wait_vmcnt<LA + LB>(); }
+        else wait_vmcnt<0>();
+        tile_barrier();
+        mfma(I1(), I0());
+        tile_barrier();
     }
+    if (!late) tile_barrier();                            // every wave executes the same number of barriers
+
+    gemm_epilogue<bf16_t, EPI, 2 * MT2, 2 * NT2>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
 }
 
 thread_local bool g_bad_variant = false;               // variant cannot serve the requested epilogue
@@ -283,6 +444,17 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
     const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
     const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
     toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
+}
+
+template <int EPI, int BM, int BN, int WM, int WN>
+void launch_phased(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds = 2 * (BM + BN) * 128;              // two K-tiles of 64 bf16
+    static Toc3dLdsAttr attr;
+    attr.ensure(reinterpret_cast<const void*>(&gemm_phased_kernel<EPI, BM, BN, WM, WN>), lds);
+    if (EPI == TOC3D_EPI_SWIGLU && (BN / WN) % 32 != 0) { g_bad_variant = true; return; }
+    const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
+    const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;
+    toc3d_launch((gemm_phased_kernel<EPI, BM, BN, WM, WN>), dim3(tiles), dim3(512), lds, s, a);
 }
 
 // tile / pipeline variants (toc3d_linear_ex `variant`); 0 = heuristic
@@ -351,6 +523,11 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 48: launch_cfg<T, EPI, 128, 192, 3, 128, 2, 4, 1>(a, s); break;      // 128x192, 3-deep ring, 120 KiB
         case 49: launch_cfg<T, EPI, 192, 128, 2, 128, 2, 4, 1>(a, s); break;      // 192x128 double buffered, 96x32 per wave (serves SwiGLU), 80 KiB
         case 50: launch_cfg<T, EPI, 192, 128, 1, 128, 2, 4, 1>(a, s); break;      // 192x128 single buffer, 40 KiB
+        // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
+        case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB
+        case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
+        case 62: if (sizeof(T) == 2) launch_phased<EPI, 128, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
+        case 63: if (sizeof(T) == 2) launch_phased<EPI, 128, 128, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x32 per wave, 64 KiB: two per CU
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;
