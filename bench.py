@@ -88,7 +88,11 @@ def main():
     ap.add_argument("--launch", default="plan", choices=["plan", "graph", "eager"],
                     help="plan: the frame's launch sequence recorded once and replayed from C on HIP streams (toc3d_plan_run); "
                          "graph: the same recording as an explicitly built hipGraph; eager: every launch issued from Python")
-    ap.add_argument("--tune-cache", default=None, help="JSON file: load the GEMM variant table if present, save it after warm-up")
+    ap.add_argument("--frames-total", type=int, default=0, help="strong-scaling mode (SURVEY.md 8d C5): this many frames per step in total, "
+                    "split over the ranks like the reference's DistributedSampler (contiguous chunks); 0 = one frame per rank per step (weak scaling)")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: all-gather the neck features on the compute stream instead of overlapped on a side stream")
+    ap.add_argument("--tune-cache", default=None, help="JSON file: load the GEMM variant table if present, save it after warm-up "
+                    "(default: the table shipped in toc3d_amd/tuned/ for this config, if any)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
@@ -100,10 +104,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP extension is the only compute path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from toc3d_amd import dist as tdist
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.pin_rank_to_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # one slice of host cores per rank
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     H, W = (int(v) for v in args.hw.split("x"))
@@ -122,53 +128,58 @@ def main():
     neck.alias_outputs = True
     neck.launch_mode = args.launch
 
-    # every rank gets its own frame (seed = rank): independent units, weak scaling
-    inp_cpu = synth.make_inputs(cfg, n_frames=1, views_per_frame=6, hw=(H, W), seed=rank)
-    inp = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in inp_cpu.items()}
+    # weak scaling (default): every rank gets its own frame (seed = rank) -- independent units, one per rank per step.
+    # strong scaling (--frames-total F): F frames per step in total, rank r owns the reference sampler's contiguous chunk
+    # (datasets/samplers/distributed_sampler.py:41-44), every frame its own inputs (seed = frame id).
+    my_frames = list(tdist.frames_for_rank(args.frames_total, rank, world)) if args.frames_total else [rank]
+    frames_per_step = args.frames_total if args.frames_total else world
+    to_dev = lambda d: {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in d.items()}
+    inp_cpu = synth.make_inputs(cfg, n_frames=1, views_per_frame=6, hw=(H, W), seed=my_frames[0] if my_frames else rank)
+    inps = [to_dev(inp_cpu)] + [to_dev(synth.make_inputs(cfg, n_frames=1, views_per_frame=6, hw=(H, W), seed=f)) for f in my_frames[1:]]
+    inp = inps[0]
     V, h, w = 6, H // 16, W // 16
-    from toc3d_amd import dist as tdist
-    gathered = torch.empty(world, V, 256, h, w, dtype=torch.bfloat16, device=dev) if world > 1 else None
+    # the one exchange (BASELINE.json config 5): per-frame neck features for the head, all-gathered over RCCL on a side stream
+    # while the next frame's backbone runs (toc3d_amd/dist.py); the head would wait on the ticket where it reads them
+    gather = tdist.FeatureGather((V, 256, h, w), dev) if world > 1 and not args.sync_gather else None
+    gathered = torch.empty(world, V, 256, h, w, dtype=torch.bfloat16, device=dev) if world > 1 and args.sync_gather else None
 
-    def step():
+    def one_frame(d):
         if is_toc:
-            out = model(inp["x"], temp_queries=inp["temp_queries"], prev_exists=True, temp_ref_points=inp["temp_ref_points"],
-                        temp_vel=inp["temp_vel"], temp_timestamp=inp["temp_timestamp"], temp_ego_pose=inp["temp_ego_pose"],
-                        ego_pose_inv=inp["ego_pose_inv"], gumbel_noise=inp["gumbel"])
+            out = model(d["x"], temp_queries=d["temp_queries"], prev_exists=True, temp_ref_points=d["temp_ref_points"],
+                        temp_vel=d["temp_vel"], temp_timestamp=d["temp_timestamp"], temp_ego_pose=d["temp_ego_pose"],
+                        ego_pose_inv=d["ego_pose_inv"], gumbel_noise=d["gumbel"])
             feat = out.img_feats["last_feat"]
         else:
-            feat = model(inp["x"])["last_feat"]
+            feat = model(d["x"])["last_feat"]
         n0 = neck([feat])[0]
-        if world > 1:
-            tdist.all_gather_features(n0, gathered)          # the one exchange: per-frame neck features for the head (RCCL)
+        if world > 1 and my_frames:
+            if gather is not None:
+                gather.submit(n0)
+            else:
+                tdist.all_gather_features(n0, gathered)
+        return n0
+
+    def step():
+        n0 = None
+        for d in (inps if my_frames else []):
+            n0 = one_frame(d)
         return n0
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        tdist.barrier(dev)
 
-    # ---- warm-up (also packs weights / builds plans / autotunes the GEMM tiles), optional graph capture -----
-    if args.tune_cache and os.path.exists(args.tune_cache):
-        model.load_tuning(args.tune_cache)
-    for _ in range(max(1, args.warmup)):
-        step()
+    # ---- warm-up (also packs weights / builds plans / autotunes the GEMM tiles) + timed region --------------
+    shipped = os.path.join(ROOT, "toc3d_amd", "tuned", f"{args.config}_{H}x{W}_{args.precision}.json")
+    tune_path = args.tune_cache or (shipped if os.path.exists(shipped) else None)
+    if tune_path and os.path.exists(tune_path):
+        model.load_tuning(tune_path)
+    step()                                                   # first forward: packs, tunes shapes the table does not hold
     torch.cuda.synchronize()
     if args.tune_cache and rank == 0:
         model.save_tuning(args.tune_cache)
-    run = step
-
-    # ---- timed region ------------------------------------------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    # W untimed steps, barrier + sync, EXACTLY K timed steps (the overlapped exchange drained inside the timed region), barrier + sync,
+    # max over ranks -- toc3d_amd/dist.py:timed_steps, the same function the world-2 gloo test drives
+    elapsed = tdist.timed_steps(step, args.steps, max(0, args.warmup - 1), dev, finish=gather.drain if gather is not None else None)
 
     # ---- dominant-kernel timing: HIP events around every launch of each C-ABI op (eager, same stream) ------
     roof = None
@@ -194,6 +205,7 @@ def main():
 
         n_inst = min(args.steps, 5)
         world_saved, world = world, 1                  # no collective in the instrumented pass
+        inps_saved, inps = inps, inps[:1]              # one frame per instrumented step
         model.view_groups = 1                          # one stream: per-launch durations are not inflated by co-running kernels
         model.launch_mode = neck.launch_mode = "eager" # per-launch events need one host call per launch
         for _ in range(2):
@@ -232,7 +244,7 @@ def main():
             torch.cuda.synchronize()
         finally:
             lib.call = orig_call
-            world = world_saved
+            world, inps = world_saved, inps_saved
             model.view_groups = args.groups
             model.launch_mode = neck.launch_mode = args.launch
         detail = {}
@@ -278,22 +290,26 @@ def main():
             print(f"   {k:70s} {1e3 * v[1] / v[0]:8.1f} us x {v[0] // n_inst:3d}  = {v[1] / n_inst:6.3f} ms{tf}", file=sys.stderr)
 
     if rank == 0:
+        world_report = world
         ms = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
+        value = frames_per_step * args.steps / elapsed
         alg, iss, _ = flop_model(cfg, V, h, w)
         res = {
             "metric": "multi-view frames/sec through ViT+ToC3D backbone, 6x(800x320)" if (H, W) == (320, 800) else f"multi-view frames/sec through ViT+ToC3D backbone, 6x({W}x{H})",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak",
+            "higher_is_better": True, "scaling": "strong" if args.frames_total else "weak",
             "vs_baseline": (value / PAPER_FPS) if (args.config == "toc3d_faster" and (H, W) == (320, 800)) else None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config} EVA-02 ViT-L backbone + CPFPN neck, 6 views x 3x{H}x{W} per frame, 1 frame per rank per step, "
-                                   f"random-init weights, prev_exists=True, injected Gumbel noise",
-                       "frames_per_step": world, "launch": {"plan": "recorded launch plan replayed from C (toc3d_plan_run, HIP streams)", "graph": "recorded launch plan as an explicit hipGraph",
+            "config": {"workload": f"{args.config} EVA-02 ViT-L backbone + CPFPN neck, 6 views x 3x{H}x{W} per frame, "
+                                   + (f"{args.frames_total} frames per step split over the ranks, " if args.frames_total else "1 frame per rank per step, ")
+                                   + "random-init weights, prev_exists=True, injected Gumbel noise",
+                       "frames_per_step": frames_per_step,
+                       "feature_exchange": None if world_report == 1 else ("all-gather on the compute stream" if args.sync_gather else "all-gather overlapped on a side stream"),
+                       "launch": {"plan": "recorded launch plan replayed from C (toc3d_plan_run, HIP streams)", "graph": "recorded launch plan as an explicit hipGraph",
                                   "eager": "eager (Python issues every launch)"}[args.launch],
                        "view_groups": args.groups,
                        "baseline_note": "vs_baseline divides by the paper's 4.78 backbone-frames/s (fp32, GPU model unstated, BASELINE.md section 1)"},
-            "whole_path_tflops": (alg / (ms * 1e-3)) / 1e12,
+            "whole_path_tflops": (alg * frames_per_step / world_report / (ms * 1e-3)) / 1e12,      # per GPU
             "paper_protocol": None if roof is None or block_loop_ms is None else {
                 "block_loop_ms": block_loop_ms, "block_loop_frames_per_s": 1e3 / block_loop_ms,
                 "note": "block loop only, single stream, event-timed (the span the paper's 209 ms covers); the headline value also "

@@ -55,6 +55,90 @@ def test_world2_gloo_allgather_and_timing():
         assert t == 2.0                                                                        # max over ranks
 
 
+def _bench_worker(rank, world, port, frames_total, q):
+    """bench.py's N > 1 step / barrier / timing logic (toc3d_amd.dist.timed_steps + FeatureGather) with a stub model."""
+    import time
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = list(tdist.frames_for_rank(frames_total, rank, world)) if frames_total else [rank]
+    gather = tdist.FeatureGather((6, 4, 2, 3), "cpu", dtype=torch.float32, depth=2)
+    log = []
+
+    def step():
+        for f in mine:
+            time.sleep(0.01 * (1 + rank))                                  # stub backbone: rank 1 is the slow one
+            feat = torch.full((6, 4, 2, 3), float(f))
+            t = gather.submit(feat)                                        # exchange of frame f overlaps the next frame's "backbone"
+            if t >= 1:
+                log.append(gather.wait(t - 1)[:, 0, 0, 0, 0].tolist())     # consumer reads the previous frame's exchange
+
+    elapsed = tdist.timed_steps(step, steps=3, warmup=1, device="cpu", finish=gather.drain)
+    last = gather.out[(gather.n - 1) % 2][:, 0, 0, 0, 0].tolist()
+    q.put((rank, mine, elapsed, log[-1], last, gather.n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world2(target, *args):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_world2_timed_steps_weak_scaling_with_overlapped_gather():
+    res = _run_world2(_bench_worker, 0)
+    (r0, m0, t0, log0, last0, n0), (r1, m1, t1, log1, last1, n1) = res
+    assert m0 == [0] and m1 == [1] and n0 == n1 == 4                       # 1 warm-up + 3 timed steps, one exchange each
+    assert t0 == t1                                                        # max over ranks, identical on every rank
+    assert t0 >= 3 * 0.02                                                  # ... and set by the slow rank (20 ms per step)
+    assert log0 == log1 == [0.0, 1.0] and last0 == last1 == [0.0, 1.0]     # every rank sees both ranks' frames, in rank order
+
+
+def test_world2_timed_steps_strong_scaling_chunks():
+    res = _run_world2(_bench_worker, 4)                                    # 4 frames per step over 2 ranks: [0, 1] and [2, 3]
+    (r0, m0, t0, log0, last0, n0), (r1, m1, t1, log1, last1, n1) = res
+    assert m0 == [0, 1] and m1 == [2, 3] and n0 == n1 == 8
+    assert t0 == t1 and t0 >= 3 * 2 * 0.02
+    assert last0 == last1 == [1.0, 3.0]                                    # the step's last exchange: each rank's second frame
+    assert log0 == log1 == [0.0, 2.0]                                      # the one before: each rank's first frame of the last step
+
+
+def test_feature_gather_single_process_ring():
+    g = tdist.FeatureGather((2, 3), "cpu", dtype=torch.float32, depth=2)
+    t0 = g.submit(torch.full((2, 3), 1.0))
+    t1 = g.submit(torch.full((2, 3), 2.0))
+    assert g.wait(t0)[0, 0, 0].item() == 1.0 and g.wait(t1)[0, 0, 0].item() == 2.0
+    t2 = g.submit(torch.full((2, 3), 3.0))                                 # reuses slot 0
+    assert g.wait(t2)[0, 0, 0].item() == 3.0
+    import pytest
+    with pytest.raises(AssertionError):
+        g.wait(t0)                                                         # older than the ring
+    g.drain()
+
+
+def test_pin_rank_to_cores_partitions_the_allowed_set():
+    if not hasattr(os, "sched_getaffinity"):
+        return
+    before = os.sched_getaffinity(0)
+    try:
+        if len(before) >= 2:
+            a = tdist.pin_rank_to_cores(0, 2)
+            os.sched_setaffinity(0, before)
+            b = tdist.pin_rank_to_cores(1, 2)
+            assert a and b and not (set(a) & set(b)) and set(a) | set(b) <= set(before)
+        assert tdist.pin_rank_to_cores(0, 1) is None
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 def test_single_process_allgather_is_a_copy():
     f = torch.randn(6, 8, 2, 3)
     g = tdist.all_gather_features(f, dtype=torch.float32)
