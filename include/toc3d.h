@@ -323,6 +323,10 @@ int toc3d_se_gate(const float* pos, const float* se, float* out, int64_t n, toc3
 
 /* Plain device-to-device copy as a kernel (recordable into a launch plan, unlike hipMemcpyAsync). */
 int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t stream);
+/* Up to 16 small device-to-device copies in ONE launch (every launch costs ~5 us of device time, and a frame has nine per-frame input
+ * tensors to stage: temp_queries ... ego_pose_inv of detectors/petr3d.py:115-134 plus the three Gumbel tensors).  dst / src / nbytes are
+ * HOST arrays of n entries (read during the call); device pointers need no alignment (16-byte body when both are aligned). */
+int toc3d_copy_segments(int64_t n, void* const* dst, const void* const* src, const int64_t* nbytes, toc3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Launch plans: the per-frame host loop (the block loop of ToC3DEVAViT.forward, backbones/toc3d_eva_vit.py:263-291, and of

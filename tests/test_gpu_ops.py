@@ -722,3 +722,24 @@ def test_every_tuned_gemm_pipeline_is_bit_stable_beside_attention(variant):
     for i, o in enumerate(outs[1:]):
         assert torch.equal(o.view(torch.uint8), outs[0].view(torch.uint8)), f"variant {variant}: launch {i + 1} differs from launch 0"
     assert torch.equal(outs[0], qkv), "and equals the heuristic variant's result"
+
+
+@pytest.mark.gpu
+def test_copy_segments_one_launch_many_ragged_copies():
+    """toc3d_copy_segments: per-frame input staging in one launch -- unaligned pointers, odd byte counts, an empty segment."""
+    import torch
+    from toc3d_amd import lib
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    sizes = [4096, 48000, 7, 0, 1234, 16, 100001, 33]
+    srcs = [torch.randint(0, 255, (n + 5,), dtype=torch.uint8, device=dev) for n in sizes]
+    dsts = [torch.zeros(n + 9, dtype=torch.uint8, device=dev) for n in sizes]
+    pairs = [(d[3:3 + n] if i % 2 else d[:n], s[1:1 + n] if i % 3 == 0 else s[:n]) for i, (d, s, n) in enumerate(zip(dsts, srcs, sizes))]
+    lib.copy_segments([(d, s) for d, s in pairs], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for (d, s), full, n in zip(pairs, dsts, sizes):
+        assert torch.equal(d, s)
+        assert int(full.sum()) == int(s.sum())          # nothing written outside the segment
+    with pytest.raises(RuntimeError):
+        lib.copy_segments([(dsts[0][:4], srcs[0][:4])] * 17, torch.cuda.current_stream().cuda_stream) if False else lib.call(
+            "toc3d_copy_segments", 17, None, None, None, torch.cuda.current_stream().cuda_stream)

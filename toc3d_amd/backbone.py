@@ -925,14 +925,14 @@ class ToC3DEVAViT(_BackboneBase):
 
         # ---- per-frame inputs -> the plan's staging buffers (tiny copies on the caller's stream, in front of the frame) -----------
         ts_key = "ts32"
+        staged = []                                              # (dst, src) pairs, staged with ONE launch (every launch has a ~5 us floor)
         if prev and ns:
             assert temp_queries is not None and ego_pose_inv is not None, "prev_exists=True needs the memory-bank tensors"
 
             def put(dst, t, dtype=torch.float32):
                 t = t.to(device=dev, dtype=dtype).contiguous()
                 assert t.numel() == dst.numel(), (tuple(t.shape), tuple(dst.shape))
-                lib.call("toc3d_copy_bytes", dst, t, dst.numel() * dst.element_size(), s0)
-                return t                                         # stays referenced until the copy is enqueued (same stream: safe to free)
+                staged.append((dst, t))                          # t stays referenced until the copy is enqueued (same stream: safe to free)
             put(sg["tq"], temp_queries), put(sg["rp"], temp_ref_points), put(sg["vel"], temp_vel)
             put(sg["pose"], temp_ego_pose), put(sg["inv"], ego_pose_inv)
             if temp_timestamp.dtype == torch.float64:            # the memory bank's f64 epoch timestamps
@@ -945,8 +945,8 @@ class ToC3DEVAViT(_BackboneBase):
                 # F.gumbel_softmax's own sampling (-log of Exp(1) draws), toc3d_utils.py:147
                 sg["gumbel"][st].exponential_().log_().neg_()
             else:
-                gsrc = gumbel_noise[st].to(device=dev, dtype=torch.float32).reshape(V * T, 2).contiguous()
-                lib.call("toc3d_copy_bytes", sg["gumbel"][st], gsrc, gsrc.numel() * 4, s0)
+                staged.append((sg["gumbel"][st], gumbel_noise[st].to(device=dev, dtype=torch.float32).reshape(V * T, 2).contiguous()))
+        lib.copy_segments(staged, s0)
         forced = None
         if forced_scores is not None:
             forced = [(f[0].to(device=dev, dtype=torch.float32).reshape(V * T), f[1].to(device=dev, dtype=torch.float32).reshape(V * T))

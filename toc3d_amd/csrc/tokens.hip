@@ -516,6 +516,23 @@ __global__ __launch_bounds__(256) void copy_bytes_kernel(char* __restrict__ dst,
     for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) dst[i] = src[i];
 }
 
+// several small device-to-device copies in ONE launch (the per-frame inputs of the recorded plan: every launch has a ~5 us floor)
+constexpr int COPY_MAX_SEGS = 16;
+struct CopySegs { char* dst[COPY_MAX_SEGS]; const char* src[COPY_MAX_SEGS]; int64_t nbytes[COPY_MAX_SEGS]; };
+
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs c) {
+    const int sg = blockIdx.y;
+    char* dst = c.dst[sg];
+    const char* src = c.src[sg];
+    const int64_t nbytes = c.nbytes[sg];
+    const bool al = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+    const int64_t n16 = al ? nbytes / 16 : 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C) {
     __shared__ float tile[32][33];
     const int v = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -678,6 +695,24 @@ int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t 
     const int blocks = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
     toc3d_launch(copy_bytes_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (char*)dst, (const char*)src, n16, nbytes);
     TOC3D_LAUNCH_CHECK("toc3d_copy_bytes");
+    return TOC3D_OK;
+}
+
+int toc3d_copy_segments(int64_t n, void* const* dst, const void* const* src, const int64_t* nbytes, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(n >= 0 && n <= COPY_MAX_SEGS && (n == 0 || (dst && src && nbytes)), "toc3d_copy_segments: 0 <= n <= %d segments, host arrays of n entries", COPY_MAX_SEGS);
+    if (n == 0) return TOC3D_OK;
+    CopySegs c;
+    int64_t most = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        TOC3D_REQUIRE(nbytes[i] >= 0 && (nbytes[i] == 0 || (dst[i] && src[i])), "toc3d_copy_segments: bad segment %lld", (long long)i);
+        c.dst[i] = (char*)dst[i]; c.src[i] = (const char*)src[i]; c.nbytes[i] = nbytes[i];
+        most = nbytes[i] > most ? nbytes[i] : most;
+    }
+    if (most == 0) return TOC3D_OK;
+    const int64_t per = (most / 16 + 255) / 256;
+    const int bx = (int)(per < 1 ? 1 : (per > 64 ? 64 : per));
+    toc3d_launch(copy_segments_kernel, dim3(bx, (unsigned)n), dim3(256), 0, as_stream(stream), c);
+    TOC3D_LAUNCH_CHECK("toc3d_copy_segments");
     return TOC3D_OK;
 }
 

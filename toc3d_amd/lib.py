@@ -54,6 +54,7 @@ _SIGS = {
     "toc3d_memory_scores": "pllpp",
     "toc3d_memory_post_update": "ppppppppppppplpppllllllp",
     "toc3d_copy_bytes": "pplp",
+    "toc3d_copy_segments": "lpppp",
     "toc3d_plan_create": "p",
     "toc3d_plan_destroy": "p",
     "toc3d_plan_begin": "p",
@@ -116,6 +117,17 @@ def call(name: str, *args):
     rc = getattr(lib, name)(*[_conv(a) for a in args])
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.toc3d_last_error().decode()}")
+
+
+def copy_segments(pairs, stream):
+    """[(dst tensor, src tensor), ...] (same byte sizes) staged with one toc3d_copy_segments launch per 16 pairs."""
+    for i in range(0, len(pairs), 16):
+        chunk = pairs[i:i + 16]
+        n = len(chunk)
+        d = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in chunk])
+        s = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t in chunk])
+        b = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t, _ in chunk])
+        call("toc3d_copy_segments", n, d, s, b, stream)
 
 
 # Lane of the launch plan being recorded by this thread (toc3d_amd/plan.py); None = launch on torch's current stream.
