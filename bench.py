@@ -193,7 +193,7 @@ def main():
             e0.record()
             orig_call(name, *a)
             e1.record()
-            if name == "toc3d_linear_ex":
+            if name in ("toc3d_linear_ex", "toc3d_linear_fused"):
                 tag = f"[epi{a[1]} v{a[2]} M={a[15]} N={a[16]} K={a[17]}]"
             elif name == "toc3d_linear":
                 tag = f"[epi{a[1]} M={a[14]} N={a[15]} K={a[16]}]"
@@ -223,7 +223,7 @@ def main():
             orig_call(name, *a)
             if name in ("toc3d_im2col_patches", "toc3d_im2col_patches_u8"):
                 state["stem"] = True
-            elif state["stem"] and name == "toc3d_linear_ex":
+            elif state["stem"] and name in ("toc3d_linear_ex", "toc3d_linear_fused"):
                 state["stem"] = False
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()

@@ -46,6 +46,8 @@ extern "C" {
 #define TOC3D_EPI_RESIDUAL 1  /* out(f32)  = residual + (A.W^T + bias)        (+ optional raw capture) */
 #define TOC3D_EPI_SWIGLU 2    /* out(act)  = silu(A.W1^T + b1) * (A.W2^T + b2), W packed interleaved   */
 #define TOC3D_EPI_GELU 3      /* out(act)  = gelu_erf(A.W^T + bias)                                    */
+#define TOC3D_EPI_SWIGLU_STATS 4  /* SWIGLU + per-row (sum, sum of squares) of the written hidden units  (toc3d_linear_fused) */
+#define TOC3D_EPI_RESIDUAL_LN 5   /* RESIDUAL with a LayerNorm of the A rows folded into the epilogue    (toc3d_linear_fused) */
 
 typedef void* toc3d_stream_t;
 
@@ -89,6 +91,28 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
                     float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                     toc3d_stream_t stream);
 
+
+/* SwiGLU.ffn_ln folded across the w1|w2 -> w3 boundary (backbones/eva_vit.py:47-49: x = ffn_ln(act(w1 x) * w2 x); x = w3 x), bf16 only.
+ *   w3(LN(h))[n] = rstd * (h . W'[n] - mean * c1[n]) + c2[n],   W' = gamma (.) w3 (packed in the act dtype), c1[n] = sum_j W'[n, j],
+ *   c2[n] = sum_j beta[j] w3[n, j] + b3[n]   (toc3d_pack_weight_lnfold), mean / rstd over the n_valid hidden units of the row.
+ * So the LayerNorm pass over h (read + write of M x Hp activations per block, one launch) disappears:
+ *   EPI_SWIGLU_STATS  = EPI_SWIGLU that also leaves per-row partial (sum h, sum h^2) of the *rounded* hidden units in row_stats:
+ *                       int32 header [4] (header[0] = slots per row actually written) followed by f32 [M, stats_cap, 2]; one slot per
+ *                       128 packed columns, every slot summed in one fixed tree whatever the tile variant (variants whose N-tile is not a
+ *                       multiple of 128 cannot serve it: TOC3D_ERR_UNSUPPORTED), so results do not depend on the variant;
+ *                       stats_cap >= ceil(N / 128).
+ *   EPI_RESIDUAL_LN   = EPI_RESIDUAL on A = h with W = W', bias = c2, col_sums = c1, ln_n = number of valid hidden units, ln_eps;
+ *                       reads row_stats (fixed summation order: independent of its own tile variant too).
+ * Every other argument as toc3d_linear_ex; epilogues 0-3 ignore the five extra arguments. */
+int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
+                       const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                       float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                       float* row_stats, int64_t stats_cap, const float* col_sums, int64_t ln_n, float ln_eps,
+                       toc3d_stream_t stream);
+/* w3 f32 [N, K], ffn_ln gamma / beta f32 [K], b3 f32 [N] -> W' act [Np, Kp] (zero padded), c1 f32 [N] (sums of the ROUNDED W' rows, so
+ * that the mean term cancels exactly what the GEMM accumulated), c2 f32 [N]. */
+int toc3d_pack_weight_lnfold(int dtype, const float* w3, const float* gamma, const float* beta, const float* b3, int64_t N, int64_t K,
+                             void* out_w, int64_t Np, int64_t Kp, float* c1, float* c2, toc3d_stream_t stream);
 
 /* f32 [N, K] state-dict weight -> act [Np, Kp], zero padded (Np multiple of 128, Kp multiple of 64). */
 int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out, int64_t Np, int64_t Kp, toc3d_stream_t stream);

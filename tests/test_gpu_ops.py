@@ -743,3 +743,76 @@ def test_copy_segments_one_launch_many_ragged_copies():
     with pytest.raises(RuntimeError):
         lib.copy_segments([(dsts[0][:4], srcs[0][:4])] * 17, torch.cuda.current_stream().cuda_stream) if False else lib.call(
             "toc3d_copy_segments", 17, None, None, None, torch.cuda.current_stream().cuda_stream)
+
+
+def test_ffn_ln_folded_across_the_gemm_boundary():
+    """SwiGLU.ffn_ln folded (EPI_SWIGLU_STATS -> EPI_RESIDUAL_LN, eva_vit.py:47-49) against the explicit sequence
+    (EPI_SWIGLU -> toc3d_layernorm_act -> EPI_RESIDUAL) and an f64 reference on the same rounded hidden units; the row
+    statistics and both outputs must not depend on the tile variant."""
+    dt, tdt = lib.BF16, torch.bfloat16
+    M, K, Hd, Hp, C = 777, 512, 300, 320, 384
+    eps = 1e-6
+    A = rnd(M, K, seed=1)
+    a_d = as_act(A, tdt)
+    w12 = torch.empty(2 * Hp, K, dtype=tdt, device=DEV)
+    b12 = torch.empty(2 * Hp, device=DEV)
+    lib.call("toc3d_pack_swiglu", dt, rnd(Hd, K, seed=5, scale=K ** -0.5).to(DEV), rnd(Hd, K, seed=6, scale=K ** -0.5).to(DEV), rnd(Hd, seed=7).to(DEV),
+             rnd(Hd, seed=8).to(DEV), Hd, K, w12, b12, Hp, K, S())
+    gamma, beta = (1.0 + 0.3 * rnd(Hd, seed=9)).to(DEV), (0.2 * rnd(Hd, seed=10)).to(DEV)
+    W3, b3 = rnd(C, Hd, seed=11, scale=Hd ** -0.5).to(DEV), rnd(C, seed=12).to(DEV)
+    res = rnd(M, C, seed=13).to(DEV)
+    rep_index = torch.full((M,), -1, dtype=torch.int32, device=DEV)
+    rep_index[::50] = torch.arange(len(range(0, M, 50)), dtype=torch.int32, device=DEV)
+    nrep = int((rep_index >= 0).sum())
+    # explicit sequence
+    hid0 = torch.zeros(M, Hp, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear_ex", dt, lib.EPI_SWIGLU, 16, a_d, K, w12, K, b12, hid0, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, S())
+    hln = torch.zeros(M, Hp, dtype=tdt, device=DEV)
+    lib.call("toc3d_layernorm_act", dt, hid0, Hp, gamma, beta, eps, hln, Hp, M, Hd, S())
+    out0 = res.clone()
+    lib.call("toc3d_linear_ex", dt, lib.EPI_RESIDUAL, 16, hln, Hp, pack(W3.cpu(), dt, tdt), Hp, b3, out0, C, out0, C, 0, None, None, M, C, Hp, 0, S())
+    # f64 reference on the rounded hidden units
+    h = hid0[:, :Hd].double()
+    ln = (h - h.mean(1, keepdim=True)) / torch.sqrt(h.var(1, unbiased=False, keepdim=True) + eps) * gamma.double() + beta.double()
+    delta_ref = ln @ W3.double().T + b3.double()
+    ref = res.double() + delta_ref
+    # folded
+    w3f = torch.empty(ru(C, 128), Hp, dtype=tdt, device=DEV)
+    c1, c2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    lib.call("toc3d_pack_weight_lnfold", dt, W3.contiguous(), gamma, beta, b3, C, Hd, w3f, w3f.shape[0], Hp, c1, c2, S())
+    assert relerr(c1, (gamma * W3).to(tdt).double().sum(1)) < 1e-5 and relerr(c2, (W3.double() * beta.double()).sum(1) + b3.double()) < 1e-5
+    cap = 6
+    ref_stats = ref_out = ref_rep = None
+    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 116, 117, 126, 149):
+        stats = torch.zeros(4 + M * cap * 2, device=DEV)
+        hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
+        lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd,
+                 stats, cap, None, 0, 0.0, S())
+        assert torch.equal(hid, hid0), f"variant {v}: hidden units differ from EPI_SWIGLU"
+        nslots = int(stats[:1].view(torch.int32).item())
+        assert nslots == (2 * Hp + 127) // 128
+        st = stats[4:].view(M, cap, 2)[:, :nslots]
+        if ref_stats is None:
+            ref_stats = st.clone()
+            assert relerr(st[..., 0].sum(1), hid0.double().sum(1)) < 1e-5 and relerr(st[..., 1].sum(1), (hid0.double() ** 2).sum(1)) < 1e-5
+        assert torch.equal(st, ref_stats), f"variant {v}: row statistics depend on the tile variant"
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 114, 116, 117, 126, 145):
+        out = res.clone()
+        rep = torch.zeros(nrep, C, device=DEV)
+        lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,
+                 stats, cap, c1, Hd, eps, S())
+        if ref_out is None:
+            ref_out, ref_rep = out.clone(), rep.clone()
+            e_fold, e_seq = relerr(out, ref), relerr(out0, ref)
+            print(f"[ffn_ln fold] rel err vs f64: folded {e_fold:.3e}, explicit LayerNorm pass {e_seq:.3e}")
+            assert e_fold < 4e-3 and e_fold < 1.5 * e_seq + 1e-4
+            assert relerr(rep, delta_ref[rep_index.cpu() >= 0]) < 6e-3            # representative rows capture the raw branch output
+        assert torch.equal(out, ref_out) and torch.equal(rep, ref_rep), f"variant {v}: folded epilogue depends on the tile variant"
+    for v, epi in ((47, lib.EPI_SWIGLU_STATS), (9, lib.EPI_SWIGLU_STATS), (60, lib.EPI_SWIGLU_STATS), (60, lib.EPI_RESIDUAL_LN)):
+        with pytest.raises(RuntimeError, match="cannot serve"):
+            if epi == lib.EPI_SWIGLU_STATS:
+                lib.call("toc3d_linear_fused", dt, epi, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, 0.0, S())
+            else:
+                lib.call("toc3d_linear_fused", dt, epi, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, None, None, M, C, Hp, 0, stats, cap, c1, Hd, eps, S())
+    with pytest.raises(RuntimeError, match="bf16 only"):
+        lib.call("toc3d_linear_fused", lib.F32, lib.EPI_SWIGLU_STATS, 16, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, 0.0, S())

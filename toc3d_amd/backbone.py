@@ -207,6 +207,9 @@ class _BackboneBase(nn.Module):
         self.alias_outputs = False      # True: returned tensors alias the reused workspace (benchmarks)
         self.view_groups = 1            # > 1: split the views into groups that run concurrently on separate lanes (HIP streams)
         self.carry_compact = precision == "bf16" and os.environ.get("TOC3D_CARRY", "1") != "0"   # see _accel_block
+        # bf16 path: SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused): no LayerNorm pass over
+        # the hidden activations.  The strict-parity fp32 path keeps the reference's sequence (eva_vit.py:47-49).
+        self.fold_ffn_ln = precision == "bf16" and os.environ.get("TOC3D_FOLD_LN", "1") != "0"
         # "plan": the frame's launch sequence is recorded once per (input shape, config) and replayed from C with one call per frame
         # (toc3d_plan_run, HIP streams + events); "graph": the same recording as an explicitly built hipGraph; "eager": every launch
         # issued from Python (what the first forward of a shape always does: it autotunes, and it is what gets recorded next).
@@ -275,7 +278,15 @@ class _BackboneBase(nn.Module):
             lib.call("toc3d_pack_swiglu", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias),
                      self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
             p["w12"], p["b12"] = w12, b12
-            p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
+            if self.fold_ffn_ln:
+                N3, K3 = m.w3.weight.shape
+                w3f = torch.empty(_round_up(N3, 128), Hp, dtype=self._tdt, device=dev)
+                p["c1"], p["c2"] = torch.empty(N3, device=dev), torch.empty(N3, device=dev)
+                lib.call("toc3d_pack_weight_lnfold", self._dt, self._f32(m.w3.weight), self._f32(m.ffn_ln.weight), self._f32(m.ffn_ln.bias),
+                         self._f32(m.w3.bias), N3, K3, w3f, w3f.shape[0], Hp, p["c1"], p["c2"], lib.stream_ptr())
+                p["w3"] = w3f                                     # gamma-scaled; c1 / c2 carry the mean and beta / bias terms
+            else:
+                p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
             for n, mod in (("ln1", blk.norm1), ("ln2", blk.norm2), ("lnf", m.ffn_ln)):
                 p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
             p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
@@ -354,6 +365,9 @@ class _BackboneBase(nn.Module):
                     hln=torch.zeros(R, Hp, dtype=tdt, device=dev),
                     col=torch.zeros(M, _round_up(Kc, 64), dtype=tdt, device=dev),
                     Kc=Kc)
+        if self.fold_ffn_ln:                                      # per-row partial (sum, sum^2) slots of the hidden units: header + [R, cap, 2]
+            plan["stats_cap"] = _round_up(-(-2 * Hp // 128), 2)
+            plan["stats"] = torch.zeros(4 + R * plan["stats_cap"] * 2, dtype=torch.float32, device=dev)
         plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
         return plan
 
@@ -362,7 +376,7 @@ class _BackboneBase(nn.Module):
     _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 163),
                  lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
-    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid):
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=(None, 0, None, 0, 0.0)):
         """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
         real operands the first time the shape is seen (never during hipGraph capture: shapes are warmed up eagerly).
         All variants accumulate K in the same order, so the choice does not change results."""
@@ -373,16 +387,20 @@ class _BackboneBase(nn.Module):
             var = 0
             if lib.recording():
                 # a shape first seen while recording (the eager warm-up forward normally tunes every shape): heuristic tile, no timing
-                lib.call("toc3d_linear_ex", self._dt, epi, 0, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, s)
+                lib.call("toc3d_linear_fused", self._dt, epi, 0, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
                 return
             if self.autotune and not torch.cuda.is_current_stream_capturing():
                 o = out
-                if epi == lib.EPI_RESIDUAL:                 # in-place residual add: tune into scratch
+                if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN):   # in-place residual add: tune into scratch
                     o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
                 rep_s = torch.empty_like(rep_out) if rep_out is not None else None
                 cands = self._VARIANTS[self._dt]
-                if epi == lib.EPI_SWIGLU:
+                if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS):
                     cands = [v for v in cands if v not in (33, 45, 145)]   # wave slabs that are not whole (w1, w2) 32-column groups
+                if epi == lib.EPI_SWIGLU_STATS:                            # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
+                    cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47, 60, 63)]
+                if epi == lib.EPI_RESIDUAL_LN:
+                    cands = [v for v in cands if v % 100 not in (60, 63)]
                 # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
                 # L2 / Infinity Cache): time single launches behind a cache-sized memset, not a warm back-to-back loop, or the
                 # tuner prefers shallow pipelines that lose in place (tools/ubench/n1024_all_variants.py).
@@ -390,14 +408,14 @@ class _BackboneBase(nn.Module):
                     _BackboneBase._flush = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=out.device)
 
                 def cold_time(v, reps):
-                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, s)
-                    lib.call("toc3d_linear_ex", *args)
+                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, *fused, s)
+                    lib.call("toc3d_linear_fused", *args)
                     ts = []
                     for _ in range(reps):
                         _BackboneBase._flush.zero_()
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        lib.call("toc3d_linear_ex", *args)
+                        lib.call("toc3d_linear_fused", *args)
                         e1.record()
                         e1.synchronize()
                         ts.append(e0.elapsed_time(e1))
@@ -407,7 +425,7 @@ class _BackboneBase(nn.Module):
                 short = sorted((cold_time(v, 3), v) for v in cands)[:4]
                 var = min((cold_time(v, 9), v) for _, v in short)[1]
             self._tuned[key] = var
-        lib.call("toc3d_linear_ex", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, s)
+        lib.call("toc3d_linear_fused", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
 
     def save_packed(self, path):
         """Write the packed device weights (what the kernels consume) to a safetensors file; see ``packed_io``."""
@@ -470,6 +488,14 @@ class _BackboneBase(nn.Module):
         Hp = plan["hid"].shape[1]
         dt = self._dt
         lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
+        if self.fold_ffn_ln:
+            # ffn_ln folded: the SwiGLU GEMM leaves per-row (sum, sum^2) slots, the w3 GEMM (gamma-scaled weights) normalises in its epilogue
+            st, cap = plan["stats"], plan["stats_cap"]
+            self._linear(lib.EPI_SWIGLU_STATS, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
+                         fused=(st, cap, None, 0, 0.0))
+            self._linear(lib.EPI_RESIDUAL_LN, plan["hid"], Hp, bp["w3"], bp["w3"].shape[1], bp["c2"], res, C, res, C, 0,
+                         rep_out, rep_index, rows, C, Hp, 0, fused=(st, cap, bp["c1"], Hd, self.LN_EPS))
+            return
         self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)
         lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
         self._linear(lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,

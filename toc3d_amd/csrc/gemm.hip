@@ -33,7 +33,13 @@ struct GemmArgs {
     int M, N, K, n_valid;
     int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
     int vec;                                             // epilogue may use 4-element vector accesses (alignment checked on the host)
+    // LayerNorm folded across a GEMM boundary (TOC3D_EPI_SWIGLU_STATS writes, TOC3D_EPI_RESIDUAL_LN reads; include/toc3d.h)
+    float* stats; int stats_cap;                         // int32 header [4] + f32 [M, stats_cap, 2]
+    const float* c1; float ln_inv_n, ln_eps;
 };
+
+constexpr bool epi_is_swiglu(int epi) { return epi == TOC3D_EPI_SWIGLU || epi == TOC3D_EPI_SWIGLU_STATS; }
+constexpr bool epi_is_residual(int epi) { return epi == TOC3D_EPI_RESIDUAL || epi == TOC3D_EPI_RESIDUAL_LN; }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -97,9 +103,12 @@ TOC3D_DEV void tile_barrier() {
 // with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
 // .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
 // alignment / leading dims) enables the vector path. ----
+// EPI_SWIGLU_STATS: gs / gq [MT][NT / 2] receive, per row tile i and 32-column group jp, this lane's share of (sum h, sum h^2) over the
+// ROUNDED hidden units it wrote (zero for rows / columns outside the matrix); the caller completes the sums.
 template <typename T, int EPI, int MT, int NT>
-TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, int col0, int r16, int g) {
-    if (EPI == TOC3D_EPI_SWIGLU) {
+TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, int col0, int r16, int g, float (*gs)[NT / 2 > 0 ? NT / 2 : 1] = nullptr,
+                             float (*gq)[NT / 2 > 0 ? NT / 2 : 1] = nullptr, const f32x2* lnrow = nullptr) {
+    if (epi_is_swiglu(EPI)) {
         // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
         T* out = reinterpret_cast<T*>(a.out);
 #pragma unroll
@@ -109,35 +118,48 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
             for (int jp = 0; jp < NT / 2; ++jp) {
                 const int pc = col0 + jp * 32 + g * 4;    // packed col of the w1 half, first of 4
                 const int unit0 = (pc >> 5) * 16 + g * 4;
+                float ssum = 0.f, sq = 0.f;
                 if (pc < a.N && row < a.M) {
                     T hs[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x1 = acc[i][2 * jp][r] + a.bias[pc + r], x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
                         hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu(x1) * x2 : 0.f);
+                        if (EPI == TOC3D_EPI_SWIGLU_STATS) {
+                            const float hv = from_act(hs[r]);       // what the next GEMM multiplies: the rounded value
+                            ssum += hv;
+                            sq = __builtin_fmaf(hv, hv, sq);
+                        }
                     }
                     T* dst = out + (int64_t)row * a.ldo + unit0;
                     if (a.vec) store4(dst, hs);
                     else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
                 }
+                if (EPI == TOC3D_EPI_SWIGLU_STATS) { gs[i][jp] = ssum; gq[i][jp] = sq; }
             }
         }
         return;
     }
     float bcol[NT][4];
+    float ccol[EPI == TOC3D_EPI_RESIDUAL_LN ? NT : 1][4];    // c1: column sums of the gamma-scaled weights
     int nok[NT];                                         // valid columns among the lane's 4 (0..4)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int col = col0 + j * 16 + g * 4;
         nok[j] = a.N - col < 0 ? 0 : (a.N - col > 4 ? 4 : a.N - col);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
+            if (EPI == TOC3D_EPI_RESIDUAL_LN) ccol[j][r] = r < nok[j] ? a.c1[col + r] : 0.f;
+        }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int row = row0 + i * 16 + r16;
         if (row >= a.M) continue;
-        if (EPI == TOC3D_EPI_RESIDUAL) {
+        float mu = 0.f, rs = 1.f;                        // EPI_RESIDUAL_LN: (mean, rstd) of this A row, prepared in LDS by the kernel
+        if (EPI == TOC3D_EPI_RESIDUAL_LN) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
+        if (epi_is_residual(EPI)) {
             // the modular residual row and the representative-row test cost an integer division / a load each: once per row
             const int rr = a.res_mod > 0 ? row % a.res_mod : row;
             const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
@@ -150,7 +172,10 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                 const int col = col0 + j * 16 + g * 4;
                 float raw[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) raw[r] = acc[i][j][r] + bcol[j][r];
+                for (int r = 0; r < 4; ++r) {
+                    if (EPI == TOC3D_EPI_RESIDUAL_LN) raw[r] = rs * (acc[i][j][r] - mu * ccol[j][r]) + bcol[j][r];
+                    else raw[r] = acc[i][j][r] + bcol[j][r];
+                }
                 if (a.vec && nok[j] == 4) {
                     f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(orow + col) = f32x4{rv[0] + raw[0], rv[1] + raw[1], rv[2] + raw[2], rv[3] + raw[3]};
@@ -274,7 +299,64 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
+    if constexpr (EPI == TOC3D_EPI_SWIGLU_STATS) {
+        // Row statistics of the written hidden units for the LayerNorm folded into the next GEMM (include/toc3d.h).  One slot per 128 packed
+        // columns, built in ONE fixed tree for every tile variant: lane -> 4 values in order; 32-column group = butterfly over the 4 lane
+        // groups; slot = (g0 + g1) + (g2 + g3) of its four groups, combined through LDS whatever wave computed them.
+        static_assert(BN % 128 == 0 && NT % 2 == 0, "EPI_SWIGLU_STATS needs N-tiles of whole 128-column slots");
+        constexpr int NG = NT / 2;                      // 32-column groups per wave
+        float gs[MT][NG], gq[MT][NG];
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq);
+        tile_barrier();                                  // every wave is done with the operand tiles: LDS becomes the reduction scratch
+        f32x2* red = reinterpret_cast<f32x2*>(smem);     // [GPT][BM]
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jp = 0; jp < NG; ++jp) {
+                const float s1 = g4_sum(gs[i][jp]), s2 = g4_sum(gq[i][jp]);
+                if (g == 0) red[(wn * NG + jp) * BM + wm * TM + i * 16 + r16] = f32x2{s1, s2};
+            }
+        tile_barrier();
+        f32x2* data = reinterpret_cast<f32x2*>(a.stats + 4);
+        for (int w = tid; w < BM * (BN / 128); w += NTHR) {
+            const int r = w % BM, sl = w / BM;
+            const int row = m0 + r;
+            if (row >= a.M) continue;
+            const f32x2 v0 = red[(4 * sl) * BM + r], v1 = red[(4 * sl + 1) * BM + r], v2 = red[(4 * sl + 2) * BM + r], v3 = red[(4 * sl + 3) * BM + r];
+            data[(int64_t)row * a.stats_cap + n0 / 128 + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
+        }
+        if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + 127) / 128;
+    } else if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) {
+        // Folded LayerNorm of the A rows: (mean, rstd) per tile row from the partial sums the producing GEMM left, into LDS.  Four threads per
+        // row; thread part p sums slots p, p + 4, ... in sequence, the parts meet in two butterfly steps; f64.  The order is fixed, so the
+        // bits do not depend on the tile variant that runs this epilogue.
+        tile_barrier();                                  // operand tiles are dead: LDS becomes the row table
+        f32x2* lnrow = reinterpret_cast<f32x2*>(smem);   // [BM]
+        const int nslots = *reinterpret_cast<const int*>(a.stats);
+        const f32x2* base = reinterpret_cast<const f32x2*>(a.stats + 4);
+        for (int w = tid; w < BM * 4; w += NTHR) {
+            const int r = w >> 2, part = w & 3;
+            int row = m0 + r;
+            row = row < a.M ? row : a.M - 1;
+            const f32x2* sp = base + (int64_t)row * a.stats_cap;
+            double s1 = 0.0, s2 = 0.0;
+            for (int sl = part; sl < nslots; sl += 4) {
+                const f32x2 v = sp[sl];
+                s1 += (double)v[0];
+                s2 += (double)v[1];
+            }
+            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+            const double mean = s1 * (double)a.ln_inv_n;
+            double var = s2 * (double)a.ln_inv_n - mean * mean;      // biased variance (F.layer_norm)
+            var = var > 0.0 ? var : 0.0;
+            if (part == 0) lnrow[r] = f32x2{(float)mean, 1.0f / sqrtf((float)var + a.ln_eps)};
+        }
+        tile_barrier();
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM);
+    } else {
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -436,25 +518,34 @@ thread_local bool g_bad_variant = false;               // variant cannot serve t
 
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = STAGES * (BM + BN) * RB;
-    static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
-    if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds);
-    if (EPI == TOC3D_EPI_SWIGLU && (BN / WN) % 32 != 0) { g_bad_variant = true; return; }   // a wave must own whole (w1, w2) 32-column groups
-    if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
-    const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
-    const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
-    toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
+    // a wave must own whole (w1, w2) 32-column groups; the folded-LayerNorm statistics need N-tiles of whole 128-column slots; the fold is bf16 only
+    constexpr bool unsupported = (epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (EPI == TOC3D_EPI_SWIGLU_STATS && BN % 128 != 0) ||
+                                 (EPI >= TOC3D_EPI_SWIGLU_STATS && sizeof(T) != 2);
+    if constexpr (unsupported) {
+        g_bad_variant = true;
+    } else {
+        constexpr int lds = STAGES * (BM + BN) * RB;
+        static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
+        if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds);
+        if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
+        const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
+        const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
+        toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
+    }
 }
 
 template <int EPI, int BM, int BN, int WM, int WN>
 void launch_phased(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = 2 * (BM + BN) * 128;              // two K-tiles of 64 bf16
-    static Toc3dLdsAttr attr;
-    attr.ensure(reinterpret_cast<const void*>(&gemm_phased_kernel<EPI, BM, BN, WM, WN>), lds);
-    if (EPI == TOC3D_EPI_SWIGLU && (BN / WN) % 32 != 0) { g_bad_variant = true; return; }
-    const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
-    const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;
-    toc3d_launch((gemm_phased_kernel<EPI, BM, BN, WM, WN>), dim3(tiles), dim3(512), lds, s, a);
+    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || EPI >= TOC3D_EPI_SWIGLU_STATS) {   // the phased kernel does not carry the folded-LayerNorm epilogues
+        g_bad_variant = true;
+    } else {
+        constexpr int lds = 2 * (BM + BN) * 128;              // two K-tiles of 64 bf16
+        static Toc3dLdsAttr attr;
+        attr.ensure(reinterpret_cast<const void*>(&gemm_phased_kernel<EPI, BM, BN, WM, WN>), lds);
+        const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
+        const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;
+        toc3d_launch((gemm_phased_kernel<EPI, BM, BN, WM, WN>), dim3(tiles), dim3(512), lds, s, a);
+    }
 }
 
 // tile / pipeline variants (toc3d_linear_ex `variant`); 0 = heuristic
@@ -540,6 +631,8 @@ int launch_gemm(int epi, int variant, const GemmArgs& a, hipStream_t s) {
         case TOC3D_EPI_RESIDUAL: return launch_epi<T, TOC3D_EPI_RESIDUAL>(variant, a, s);
         case TOC3D_EPI_SWIGLU: return launch_epi<T, TOC3D_EPI_SWIGLU>(variant, a, s);
         case TOC3D_EPI_GELU: return launch_epi<T, TOC3D_EPI_GELU>(variant, a, s);
+        case TOC3D_EPI_SWIGLU_STATS: return launch_epi<T, TOC3D_EPI_SWIGLU_STATS>(variant, a, s);
+        case TOC3D_EPI_RESIDUAL_LN: return launch_epi<T, TOC3D_EPI_RESIDUAL_LN>(variant, a, s);
         default: return TOC3D_ERR_ARG;
     }
 }
@@ -571,6 +664,34 @@ __global__ void pack_swiglu_kernel(const float* __restrict__ w1, const float* __
         out_w[i] = to_act<T>(v);
         if (k == 0) out_b[pr] = unit < Hd ? (second ? b2 : b1)[unit] : 0.f;
     }
+}
+
+// gamma-scaled w3 + the two column vectors of the folded ffn_ln (include/toc3d.h, toc3d_pack_weight_lnfold): one workgroup per output
+// row n; c1 sums the ROUNDED scaled weights, c2 = beta . w3[n] + b3[n]; fixed-order tree reduction.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_lnfold_kernel(const float* __restrict__ w3, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ b3, int N, int K, T* __restrict__ out, int Kp,
+                                                          float* __restrict__ c1, float* __restrict__ c2) {
+    __shared__ float r1[256], r2[256];
+    const int n = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = threadIdx.x; k < Kp; k += 256) {
+        T v = to_act<T>(0.f);
+        if (n < N && k < K) {
+            const float w = w3[(int64_t)n * K + k];
+            v = to_act<T>(gamma[k] * w);
+            s1 += from_act(v);
+            s2 = __builtin_fmaf(beta[k], w, s2);
+        }
+        out[(int64_t)n * Kp + k] = v;
+    }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && n < N) { c1[n] = r1[0]; c2[n] = r2[0] + b3[n]; }
 }
 
 // im2col for the k = s = patch conv: row m = (v, pr, pc), col kk = (ch, py, px) -- matches the
@@ -684,10 +805,11 @@ int toc3d_im2col_patches_u8(int dtype, const uint8_t* img, int64_t V, int64_t H,
     return TOC3D_OK;
 }
 
-int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                    void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                    float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                    toc3d_stream_t stream) {
+int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                       void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                       float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                       float* row_stats, int64_t stats_cap, const float* col_sums, int64_t ln_n, float ln_eps,
+                       toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && K > 0, "toc3d_linear: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -697,29 +819,45 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
     TOC3D_REQUIRE((lda * (dtype == TOC3D_BF16 ? 2 : 4)) % 16 == 0 && (ldw * (dtype == TOC3D_BF16 ? 2 : 4)) % 16 == 0,
                   "toc3d_linear: rows must be 16-byte aligned");
     TOC3D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "toc3d_linear: A/W must be 16-byte aligned");
-    if (epilogue == TOC3D_EPI_SWIGLU) {
+    if (epilogue >= TOC3D_EPI_SWIGLU_STATS) {
+        TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear: the folded-LayerNorm epilogues are bf16 only");
+        TOC3D_REQUIRE(row_stats && ((uintptr_t)row_stats % 16) == 0 && stats_cap > 0, "toc3d_linear: epilogue %d needs a 16-byte aligned row_stats buffer", epilogue);
+    }
+    if (epilogue == TOC3D_EPI_SWIGLU_STATS) TOC3D_REQUIRE(stats_cap >= (N + 127) / 128, "toc3d_linear: stats_cap %lld < ceil(N / 128)", (long long)stats_cap);
+    if (epilogue == TOC3D_EPI_RESIDUAL_LN) TOC3D_REQUIRE(bias && col_sums && ln_n > 0, "toc3d_linear: EPI_RESIDUAL_LN needs bias (c2), col_sums (c1) and ln_n");
+    if (epilogue == TOC3D_EPI_SWIGLU || epilogue == TOC3D_EPI_SWIGLU_STATS) {
         TOC3D_REQUIRE(bias && N % 32 == 0 && n_valid > 0 && n_valid <= N / 2, "toc3d_linear: swiglu needs bias, N%%32==0, n_valid");
         TOC3D_REQUIRE(ldo >= N / 2, "toc3d_linear: swiglu ldo < N/2");
     } else {
         TOC3D_REQUIRE(ldo >= N, "toc3d_linear: ldo < N");
     }
-    if (epilogue == TOC3D_EPI_RESIDUAL) {
+    if (epilogue == TOC3D_EPI_RESIDUAL || epilogue == TOC3D_EPI_RESIDUAL_LN) {
         TOC3D_REQUIRE(!residual || ldr >= N, "toc3d_linear: ldr < N");
         TOC3D_REQUIRE(!rep_index || rep_out, "toc3d_linear: rep_index set without rep_out");
     }
     if (M == 0) return TOC3D_OK;
     // 4-wide epilogue accesses: every row start and column group must be 16-byte aligned in its own element size
-    const int64_t osz = epilogue == TOC3D_EPI_RESIDUAL ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
+    const int64_t osz = (epilogue == TOC3D_EPI_RESIDUAL || epilogue == TOC3D_EPI_RESIDUAL_LN) ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
     const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * osz) == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
                      (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0));
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
-               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0};
+               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0,
+               row_stats, (int)stats_cap, col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps};
     g_bad_variant = false;
     int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
-    if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab < 32)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
+    if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab not a multiple of 32, or N-tile not a multiple of 128 for the statistics)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
     return TOC3D_OK;
+}
+
+int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                    void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                    float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                    toc3d_stream_t stream) {
+    TOC3D_REQUIRE(epilogue < TOC3D_EPI_SWIGLU_STATS, "toc3d_linear_ex: epilogue %d takes the extra arguments of toc3d_linear_fused", epilogue);
+    return toc3d_linear_fused(dtype, epilogue, variant, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index,
+                              M, N, K, n_valid, nullptr, 0, nullptr, 0, 0.f, stream);
 }
 
 int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -739,6 +877,18 @@ int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out
         toc3d_launch(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), w, (int)N, (int)K, (float*)out, (int)Np, (int)Kp);
     else { toc3d_set_error("toc3d_pack_weight: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_pack_weight");
+    return TOC3D_OK;
+}
+
+int toc3d_pack_weight_lnfold(int dtype, const float* w3, const float* gamma, const float* beta, const float* b3, int64_t N, int64_t K,
+                             void* out_w, int64_t Np, int64_t Kp, float* c1, float* c2, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(w3 && gamma && beta && b3 && out_w && c1 && c2 && Np >= N && Kp >= K && N > 0 && K > 0, "toc3d_pack_weight_lnfold: bad arguments");
+    if (dtype == TOC3D_BF16)
+        toc3d_launch(pack_lnfold_kernel<bf16_t>, dim3((unsigned)Np), dim3(256), 0, as_stream(stream), w3, gamma, beta, b3, (int)N, (int)K, (bf16_t*)out_w, (int)Kp, c1, c2);
+    else if (dtype == TOC3D_F32)
+        toc3d_launch(pack_lnfold_kernel<float>, dim3((unsigned)Np), dim3(256), 0, as_stream(stream), w3, gamma, beta, b3, (int)N, (int)K, (float*)out_w, (int)Kp, c1, c2);
+    else { toc3d_set_error("toc3d_pack_weight_lnfold: bad dtype"); return TOC3D_ERR_ARG; }
+    TOC3D_LAUNCH_CHECK("toc3d_pack_weight_lnfold");
     return TOC3D_OK;
 }
 

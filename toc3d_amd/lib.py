@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libtoc3d_gfx950.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU = 0, 1, 2, 3
+EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN = 0, 1, 2, 3, 4, 5
 
 _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
@@ -22,6 +22,8 @@ _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 _SIGS = {
     "toc3d_linear": "iiplplpplpllppllllp",
     "toc3d_linear_ex": "iiiplplpplpllppllllp",
+    "toc3d_linear_fused": "iiiplplpplpllppllllplplfp".replace(" ", ""),
+    "toc3d_pack_weight_lnfold": "ippppllpllppp",
     "toc3d_pack_weight": "ipllpllp",
     "toc3d_pack_swiglu": "ippppllppllp",
     "toc3d_im2col_patches": "ippllllllp",

@@ -63,6 +63,7 @@ def fingerprint(model) -> Dict[str, Any]:
               # table sides (img_size / patch for the global blocks), the scorer scale and the point-cloud range baked into the motion tables
               pos_embed_rows=None if model.pos_embed is None else int(model.pos_embed.shape[1]),
               rope_sides=[int(model.rope_win.freqs_cos.shape[0]), int(model.rope_glb.freqs_cos.shape[0])],
+              fold_ffn_ln=bool(getattr(model, "fold_ffn_ln", False)),      # w3 packed gamma-scaled + c1 / c2 instead of w3 / b3
               abi=int(lib.load().toc3d_abi_version()))
     for k in ("pruning_loc", "token_ratio", "pruning_num_queries", "accelerate_global", "pruning_attn_scale"):
         if hasattr(model, k):

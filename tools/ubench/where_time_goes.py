@@ -66,7 +66,7 @@ for name in ("toc3d_window_attention", "toc3d_layernorm_act", "toc3d_layernorm_r
     measure(f"skip {name}", skip=(name,))
 measure("skip every row kernel (ln_act, ln_rows, gather, scatter, rebase)",
         skip=("toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_scatter_update", "toc3d_rebase_layernorm_rows"))
-measure("skip all GEMMs", skip=("toc3d_linear_ex", "toc3d_linear"))
+measure("skip all GEMMs", skip=("toc3d_linear_ex", "toc3d_linear", "toc3d_linear_fused"))
 measure("skip everything but GEMMs", skip=("toc3d_window_attention", "toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_scatter_update",
                                             "toc3d_rebase_layernorm_rows", "toc3d_motion_queries", "toc3d_collapse_query_scorer", "toc3d_window_topk", "toc3d_rank_desc",
                                             "toc3d_score_tokens"))
