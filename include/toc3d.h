@@ -83,7 +83,8 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
  * (bf16), 32 = 256x128 3-deep, 33 = 128x64 on 8 wavefronts 4-deep; 34-37 = 16-wavefront 256x128 / 256x256 / 128x256 tiles;
  * 38/39 = 128x128 on 8 wavefronts with 32-wide K tiles 2-/3-deep, 40-42 = 128x256 / 256x128 single buffer and K32 rings;
  * 43-48 = 128x192 and 128x96 tiles (43/44 single buffer, 45/46 double buffer, 47 = 128x192 with 32x96 per wavefront so that
- * it serves SWIGLU, 48 = 3-deep); 49/50 = 192x128 double / single buffer.  A variant whose per-wavefront column slab is not a
+ * it serves SWIGLU, 48 = 3-deep); 49/50 = 192x128 double / single buffer; 51 = variant 16 compiled for 64 registers (four workgroups per CU);
+ * 60-63 = phased 256x256 / 256x128 / 128x256 / 128x128 tiles (bf16, one or two workgroups per CU, four phases per K-tile).  A variant whose per-wavefront column slab is not a
  * multiple of 32 cannot serve EPI_SWIGLU (error TOC3D_ERR_UNSUPPORTED).  variant + 100 = the same tile with the per-XCD band
  * order (each XCD keeps its A row band in L2 and walks the W panels once).  Every variant accumulates K in the same order: outputs are bit-identical across variants. */
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
@@ -347,6 +348,11 @@ int toc3d_se_gate(const float* pos, const float* se, float* out, int64_t n, toc3
 
 /* Plain device-to-device copy as a kernel (recordable into a launch plan, unlike hipMemcpyAsync). */
 int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t stream);
+/* Read n <= 8 buffers (HOST arrays ptrs / nbytes of n entries; device pointers 16-byte aligned, read-only for the duration) with `workgroups`
+ * workgroups per buffer (0 = 16) and discard the values: a software prefetch of the NEXT block's packed weights into the Infinity Cache,
+ * issued on a side stream / plan lane beside the current block (the 0.6 GB of bf16 weights cycle through a 256 MB cache once per frame, so
+ * every GEMM otherwise starts on HBM misses).  No output. */
+int toc3d_prefetch(int64_t n, const void* const* ptrs, const int64_t* nbytes, int64_t workgroups, toc3d_stream_t stream);
 /* Up to 16 small device-to-device copies in ONE launch (every launch costs ~5 us of device time, and a frame has nine per-frame input
  * tensors to stage: temp_queries ... ego_pose_inv of detectors/petr3d.py:115-134 plus the three Gumbel tensors).  dst / src / nbytes are
  * HOST arrays of n entries (read during the call); device pointers need no alignment (16-byte body when both are aligned). */

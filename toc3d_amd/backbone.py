@@ -210,6 +210,8 @@ class _BackboneBase(nn.Module):
         # bf16 path: SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused): no LayerNorm pass over
         # the hidden activations.  The strict-parity fp32 path keeps the reference's sequence (eva_vit.py:47-49).
         self.fold_ffn_ln = precision == "bf16" and os.environ.get("TOC3D_FOLD_LN", "1") != "0"
+        # software prefetch of the next block's packed weights on a side lane (toc3d_prefetch): workgroups per weight matrix, 0 = off
+        self.prefetch_weights = int(os.environ.get("TOC3D_PREFETCH", "0"))
         # "plan": the frame's launch sequence is recorded once per (input shape, config) and replayed from C with one call per frame
         # (toc3d_plan_run, HIP streams + events); "graph": the same recording as an explicitly built hipGraph; "eager": every launch
         # issued from Python (what the first forward of a shape always does: it autotunes, and it is what gets recorded next).
@@ -373,7 +375,7 @@ class _BackboneBase(nn.Module):
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
     _flush = None               # 256 MB scratch shared by all models: evicts L2 + Infinity Cache between tuning launches
-    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 163),
+    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 163),
                  lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=(None, 0, None, 0, 0.0)):
@@ -480,6 +482,16 @@ class _BackboneBase(nn.Module):
     def _run_frame(self, master, n_lanes, frame_fn, variant=None):
         """One frame in the configured launch mode (toc3d_amd/plan.py: eager / recorded plan / explicit hipGraph)."""
         run_frame(master.setdefault("launch", {}).setdefault(variant, {}), self.launch_mode, n_lanes, frame_fn, self._stream_pool)
+
+    def _prefetch_block(self, ex, lane, pace_lane, P, i):
+        """Beside block i - 1 .. i: pull block i's four GEMM weight matrices (25 MB in bf16) towards the chip.  ``lane`` starts each
+        prefetch behind everything issued so far on ``pace_lane`` (= the end of the previous block), so it runs one block ahead."""
+        if not self.prefetch_weights or i >= self.depth:
+            return
+        bp = P["blocks"][i]
+        ex.wait(lane, pace_lane)
+        with ex.lane(lane):
+            lib.prefetch([bp["wqkv"], bp["wproj"], bp["w12"], bp["w3"]], self.prefetch_weights, lib.stream_ptr())
 
     def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
         """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
@@ -988,7 +1000,7 @@ class ToC3DEVAViT(_BackboneBase):
             self._stem_im2col(gp, x[gp["v0"]:gp["v0"] + gp["nv"]])
 
         # ---- the frame: lanes 0..G-1 = view groups, G..2G-1 = their side lanes, 2G = query-side scorer prep -----------------------
-        prep_lane = 2 * G
+        prep_lane, pf_lane = 2 * G, 2 * G + 1
 
         def frame(ex):
             for gp in groups:
@@ -1008,6 +1020,7 @@ class ToC3DEVAViT(_BackboneBase):
                 cin = pending
                 cout = self._accelerated(i) and self._carries(i) and not cin
                 pending = cout
+                self._prefetch_block(ex, pf_lane, 0, P, i + 1)    # block i + 1's weights travel while block i computes
                 for g, gp in enumerate(groups):
                     with ex.lane(g):
                         if i in self.pruning_loc:
@@ -1030,13 +1043,13 @@ class ToC3DEVAViT(_BackboneBase):
                         for st_ in range(ns):
                             lib.call("toc3d_copy_bytes", plan["mask"][st_][v0 * T:(v0 + nv) * T], gp["mask"][st_], nv * T * 4, lib.stream_ptr())
                             lib.call("toc3d_copy_bytes", plan["order"][st_][v0:v0 + nv], gp["order"][st_], nv * T * 8, lib.stream_ptr())
-            for l in range(1, 2 * G + 1):
+            for l in range(1, 2 * G + 2):
                 ex.wait(0, l)
 
         if forced is not None or self.block_hook is not None:
-            frame(EagerExec(2 * G + 1, self._stream_pool))
+            frame(EagerExec(2 * G + 2, self._stream_pool))
         else:
-            self._run_frame(plan, 2 * G + 1, frame, variant=(prev, ts_key))
+            self._run_frame(plan, 2 * G + 2, frame, variant=(prev, ts_key))
         h, w = plan["h"], plan["w"]
         cl = (lambda t: t) if self.alias_outputs else (lambda t: t.clone())
         masks = [cl(plan["mask"][s]).view(V, h, w, 1) for s in range(ns)]

@@ -5,9 +5,9 @@
 //
 // One workgroup (4 waves) = one (window, head, 64-query tile); wave w owns 16 query rows.  Keys/values of the
 // window stream through LDS in tiles of 64 (K row-major with RoPE already applied, V transposed so the P.V
-// B-fragment is 8 consecutive keys), online softmax in f32 registers; P goes C-layout -> LDS -> A-fragment
-// inside its own wave (no workgroup barrier).  The window never exceeds 400 + 1 keys, so K/V re-reads by the
-// window's other query tiles are L2 hits.
+// B-fragment is contiguous keys), online softmax in f32 registers; the scores are computed transposed (S^T = K Q^T)
+// so that P stays in registers and feeds P.V directly (see attn_small_kernel).  The window never exceeds 400 + 1
+// keys, so K/V re-reads by the window's other query tiles are L2 hits.
 //
 // Dense blocks zero-pad *after* LayerNorm (eva_vit.py:249-254): a padded slot is a key with k = 0 (k_proj has
 // no bias, eva_vit.py:98) and v = v_bias, identical for every pad, so the npad virtual keys are folded in
@@ -90,6 +90,28 @@ TOC3D_DEV void rope8_lds(float (&x)[8], const float* cosRC, const float* sinRC, 
 // block d', lane column r16 is head dim r16*4 + d': each lane owns 4 consecutive output dims (one 8 / 16-byte store).
 TOC3D_DEV int vt_row(int d) { return (d & 3) * 16 + (d >> 2); }
 
+template <typename T> TOC3D_DEV float softmax_exp(float x);
+template <> TOC3D_DEV float softmax_exp<bf16_t>(float x) { return __expf(x); }
+template <> TOC3D_DEV float softmax_exp<float>(float x) { return expf(x); }      // strict-parity path: the precise routine
+
+TOC3D_DEV Frag<bf16_t> frag_from_halves(const bf16_t* p0, const bf16_t* p1) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p0), b = *reinterpret_cast<const bf16x4*>(p1);
+    Frag<bf16_t> f;
+    f.v = bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return f;
+}
+TOC3D_DEV Frag<float> frag_from_halves(const float* p0, const float* p1) {
+    Frag<float> f;
+    f.lo = *reinterpret_cast<const f32x4*>(p0);
+    f.hi = *reinterpret_cast<const f32x4*>(p1);
+    return f;
+}
+TOC3D_DEV float g4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
 template <typename T, int QM>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     constexpr int LD = Pad<T>::ld;
@@ -97,8 +119,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);          // [KT keys][LD]
     T* Vt = Ks + KT * LD;                        // [HD dims][LD]   (keys along the row)
-    T* Ps = Vt + HD * LD;                        // [4 waves][16*QM q][LD]
-    int32_t* s_rows = reinterpret_cast<int32_t*>(Ps + 4 * 16 * QM * LD);   // [stride] key rows of this window
+    int32_t* s_rows = reinterpret_cast<int32_t*>(Vt + HD * LD);            // [stride] key rows of this window
     const int istride = (int)((a.stride + 3) & ~3);                        // keeps the tables behind the lists 16-byte aligned
     int32_t* s_slots = s_rows + istride;                                   // [stride] RoPE slots as (row << 16 | col)
     float* s_cos = reinterpret_cast<float*>(s_slots + istride);            // [2][L][16] compact axial tables
@@ -170,17 +191,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     fetch(0);
 
     f32x4 o[QM][4];
-    float m[QM][4], l[QM][4];
+    float m[QM], l[QM];                          // running max / partial sum of query r16 (+ mi*16) -- one query per lane, see below
 #pragma unroll
-    for (int mi = 0; mi < QM; ++mi)
+    for (int mi = 0; mi < QM; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            o[mi][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            m[mi][r] = NEG_BIG;
-            l[mi][r] = 0.f;
-        }
+        for (int d = 0; d < 4; ++d) o[mi][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m[mi] = NEG_BIG;
+        l[mi] = 0.f;
+    }
 
-    T* Pw = Ps + wave * 16 * QM * LD;
     const int nkt = (nkeys + KT - 1) / KT;
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                         // previous K/V tile fully consumed
@@ -205,68 +224,56 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         if (kt + 1 < nkt) fetch(kt + 1);         // in flight during the MFMA phase below
         if (!wave_active) continue;              // wave-uniform; barriers stay outside
 
-        // ---- S = Q K^T : 16*QM q x 64 keys (each K fragment feeds QM MFMAs) ----
-        f32x4 sc[QM][4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int mi = 0; mi < QM; ++mi) sc[mi][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const Frag<T> kf = read_frag(Ks + (t * 16 + r16) * LD + s * 32 + g * 8);
-#pragma unroll
-                for (int mi = 0; mi < QM; ++mi) mma_step(sc[mi][t], qf[mi][s], kf);
-            }
-        }
+        // ---- S^T = K Q^T (K fragment as the A operand): lane holds S[q = r16][key = t*16 + g*4 + r], i.e. scores of ONE query; P then
+        // feeds P.V straight from these registers (slot numbering in the comment of attn_small_kernel below) -- no LDS round trip ----
 #pragma unroll
         for (int mi = 0; mi < QM; ++mi) {
-            // lane holds S[q = g*4 + r][key = t*16 + r16]; mask keys past the window
+            f32x4 sc[4];
+            float mx = NEG_BIG;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const bool kok = kt * KT + t * 16 + r16 < nkeys;
+                sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sc[mi][t][r] = kok ? sc[mi][t][r] : NEG_BIG;
+                for (int s = 0; s < 2; ++s) mma_step(sc[t], read_frag(Ks + (t * 16 + r16) * LD + s * 32 + g * 8), qf[mi][s]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sc[t][r] = kt * KT + t * 16 + g * 4 + r < nkeys ? sc[t][r] : NEG_BIG;      // mask keys past the window
+                    mx = fmaxf(mx, sc[t][r]);
+                }
             }
-            // ---- online softmax (per q row r; the row lives in the 16 lanes sharing g) ----
+            // ---- online softmax of query r16: the 4 lane groups hold disjoint keys of the same query ----
+            mx = g4_max(mx);
+            const float mn = fmaxf(m[mi], mx);
+            const float alpha = softmax_exp<T>(m[mi] - mn);
+            float ps = 0.f;
+            Frag<T> pf[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pv[j] = softmax_exp<T>(sc[2 * c + (j >> 2)][j & 3] - mn);
+                    ps += pv[j];
+                }
+                pf[c] = make_frag(pv, T());
+            }
+            l[mi] = l[mi] * alpha + ps;              // per-lane partial; the 4 lane groups are summed at the end
+            m[mi] = mn;
+            // the accumulator rows are queries g*4 + r: their factor lives in lane g*4 + r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float mx = fmaxf(fmaxf(sc[mi][0][r], sc[mi][1][r]), fmaxf(sc[mi][2][r], sc[mi][3][r]));
-                mx = row16_max(mx);
-                const float mn = fmaxf(m[mi][r], mx);
-                const float alpha = __expf(m[mi][r] - mn);
-                float ps = 0.f;
+                const float aq = __shfl(alpha, g * 4 + r, 64);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float p = __expf(sc[mi][t][r] - mn);
-                    sc[mi][t][r] = p;
-                    ps += p;
+                for (int d = 0; d < 4; ++d) o[mi][d][r] *= aq;
+            }
+            // ---- O += P V : A = P[q][key slot], B = V[key slot][d] read from Vt[d][key] with the same slot numbering ----
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const T* vrow = Vt + (d * 16 + r16) * LD + c * 32 + g * 4;
+                    mma_step(o[mi][d], pf[c], frag_from_halves(vrow, vrow + 16));
                 }
-                l[mi][r] = l[mi][r] * alpha + ps;   // per-lane partial; reduced over the 16 lanes at the end
-                m[mi][r] = mn;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) o[mi][d][r] *= alpha;
-            }
-            // ---- P: C layout -> LDS -> A fragments (own wave only) ----
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Pw[(mi * 16 + g * 4 + r) * LD + t * 16 + r16] = to_act<T>(sc[mi][t][r]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- O += P V : A = P[q][key], B = V[key][d] read from Vt[d][key] (each V fragment feeds QM MFMAs) ----
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            Frag<T> pf[QM];
-#pragma unroll
-            for (int mi = 0; mi < QM; ++mi) pf[mi] = read_frag(Pw + (mi * 16 + r16) * LD + s * 32 + g * 8);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const Frag<T> vf = read_frag(Vt + (d * 16 + r16) * LD + s * 32 + g * 8);
-#pragma unroll
-                for (int mi = 0; mi < QM; ++mi) mma_step(o[mi][d], pf[mi], vf);
-            }
         }
     }
     if (!wave_active) return;
@@ -274,18 +281,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     // ---- epilogue: fold in the virtual zero-padded keys, normalise, store ----
     const int np = a.npad ? a.npad[win] : 0;
 #pragma unroll
-    for (int mi = 0; mi < QM; ++mi)
+    for (int mi = 0; mi < QM; ++mi) {
+        float lr = g4_sum(l[mi]);
+        float alpha = 1.f, padw = 0.f;
+        if (np > 0) {
+            const float mn = fmaxf(m[mi], 0.f);
+            alpha = softmax_exp<T>(m[mi] - mn);
+            padw = (float)np * softmax_exp<T>(-mn);
+            lr = lr * alpha + padw;
+        }
+        const float inv = 1.f / lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float lr = row16_sum(l[mi][r]);
-            float alpha = 1.f, padw = 0.f;
-            if (np > 0) {
-                const float mn = fmaxf(m[mi][r], 0.f);
-                alpha = __expf(m[mi][r] - mn);
-                padw = (float)np * __expf(-mn);
-                lr = lr * alpha + padw;
-            }
-            const float inv = 1.f / lr;
+            const float inv_q = __shfl(inv, g * 4 + r, 64), alpha_q = __shfl(alpha, g * 4 + r, 64), padw_q = __shfl(padw, g * 4 + r, 64);
             const int qi = q0 + mi * 16 + g * 4 + r;
             if (qi < n) {
                 const int64_t orow = rows[qi];
@@ -293,38 +301,45 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 T o4[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {                   // V^T row d*16 + r16 holds head dim r16*4 + d (vt_row)
-                    float v = o[mi][d][r] * alpha;
-                    if (np > 0) v += padw * a.v_bias[head * HD + r16 * 4 + d];
-                    o4[d] = to_act<T>(v * inv);
+                    float v = o[mi][d][r] * alpha_q;
+                    if (np > 0) v += padw_q * a.v_bias[head * HD + r16 * 4 + d];
+                    o4[d] = to_act<T>(v * inv_q);
                 }
                 store4(dst, o4);
             }
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Small windows (<= 208 keys: every accelerated block of the shipped configs): one workgroup per (window, head) keeps
-// the whole K (RoPE applied) and V^T of that head in LDS, so nothing is staged twice and the softmax is single-pass
-// (no running max / rescale).  Wave w walks the 16-query MFMA tiles w, w+4, ...
+// Windows of up to 208 keys (every accelerated block of the shipped configs; dense windows too when they fit): one workgroup per
+// (window, head) keeps the whole K (RoPE applied) and V^T of that head in LDS, so nothing is staged twice and the softmax is
+// single-pass (no running max / rescale).  Wave w walks the 16-query MFMA tiles w, w+4, ...
+//
+// The scores are computed TRANSPOSED, S^T = K . Q^T (K fragment as the MFMA A operand, Q as B): a lane then holds scores of ONE
+// query (q = lane & 15) for the keys t*16 + (lane >> 4)*4 + 0..3 of every 16-key tile t.  Two tiles give the lane 8 probabilities of
+// its query -- exactly an A-operand fragment of P . V if the 32 key slots of that MFMA step are numbered
+//     slot (g, j < 4) = key c*32 + g*4 + j,      slot (g, j >= 4) = key c*32 + 16 + g*4 + (j - 4)
+// and the V^T fragment is read with the same numbering (two 4-element reads instead of one 8-element read).  P never leaves the
+// registers: no LDS round trip of 2-byte scattered stores, no per-tile wave barriers, and no P buffer in LDS (more workgroups per CU).
+// Row max / sum live in one lane per query (+ a butterfly over the 4 lane groups); the normalisation of an output row
+// q = (lane >> 4)*4 + r fetches 1/sum from lane q.
+// Dense blocks (npad): the analytic zero-pad keys of the header comment enter the single pass as max(m, 0), sum += npad * exp(-m).
 // ---------------------------------------------------------------------------------------------------
-constexpr int SMALL_MAX_SUB = 13;                // 13 * 16 = 208 keys
-
-template <typename T, bool CHUNK>
+template <typename T, int MAXSUB>
 __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     constexpr int LD = Pad<T>::ld;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int head = blockIdx.x, win = blockIdx.y;
     const int n = a.count[win];
+    if (n == 0) return;
     const int nkeys = a.count_k ? a.count_k[win] : n;
     const int nsub = (nkeys + 15) >> 4;          // 16-key MFMA tiles
     const int NK32 = ((nkeys + 31) >> 5) << 5;   // keys padded to the 32-wide P.V step
-    const int LDP = NK32 + 16 / (int)sizeof(T);  // row stride of V^T and P (elements), keeps 16-byte alignment
+    const int LDP = NK32 + 16 / (int)sizeof(T);  // row stride of V^T (elements), keeps 16-byte alignment
     T* Ks = reinterpret_cast<T*>(smem);          // [nsub*16][LD]
     T* Vt = Ks + nsub * 16 * LD;                 // [HD][LDP]
-    constexpr int PLD = 32 + 16 / (int)sizeof(T); // P chunk tile row stride (elements)
-    const int PS = CHUNK ? PLD : LDP;            // P row stride: one 32-key chunk at a time, or the whole key range
-    T* Ps = Vt + HD * LDP;                       // [4 waves][16][PS]
-    int32_t* s_rows = reinterpret_cast<int32_t*>(Ps + 4 * 16 * PS);
+    int32_t* s_rows = reinterpret_cast<int32_t*>(Vt + HD * LDP);
     const int istride = (int)((a.stride + 3) & ~3);
     int32_t* s_slots = s_rows + istride;
     float* s_cos = reinterpret_cast<float*>(s_slots + istride);
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
 
     // ---- staging with every global load of the workgroup in flight at once (the kernel is latency-bound: its inputs
     // were written by a GEMM on other XCDs, so nothing hits this XCD's L2) ----
-    constexpr int MAXC = (SMALL_MAX_SUB * 16 + 16) * 8 / 256;   // (key, 8-dim chunk) pairs per thread: 7
+    constexpr int MAXC = (MAXSUB * 16 + 16) * 8 / 256;           // (key, 8-dim chunk) pairs per thread
     int crow[MAXC], cslot[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {                             // 1. index loads
@@ -358,11 +373,25 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
             vraw[i] = read_frag(src + 2 * a.C + head * HD + dc * 8);
         }
     }
-    for (int j = tid; j < nkeys; j += 256) {                     // 3. key list + compact RoPE tables -> LDS
-        const int sl = slots[j];
-        s_rows[j] = rows[j];
-        s_slots[j] = ((sl / L) << 16) | (sl % L);
+    // raw Q rows of all tiles this wave owns are requested in the same round trip (their rows come from the same list)
+    const int nmt = (n + 15) >> 4;
+    constexpr int MAXT = (MAXSUB + 3) / 4;
+    Frag<T> qraw[MAXT][2];
+    int qslot[MAXT];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+        const int qi = (wave + 4 * u) * 16 + r16;
+        const bool ok = qi < n;
+        const int qrow = ok ? rows[qi] : -1;
+        qslot[u] = ok ? slots[qi] : 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+            if (wave + 4 * u < nmt) {
+                const T* src = qrow >= 0 ? qkv + (int64_t)qrow * a.ldqkv : qkv;
+                qraw[u][s2] = read_frag(src + head * HD + s2 * 32 + g * 8);
+            }
     }
+    for (int j = tid; j < n; j += 256) s_rows[j] = rows[j];      // 3. output rows + compact RoPE tables -> LDS
     for (int i = tid; i < L * 16; i += 256) {
         const int c = i >> 4, f = i & 15;
         s_cos[i] = a.cosT[(int64_t)(c * L) * HD + 2 * f];
@@ -391,29 +420,16 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    T* Pw = Ps + wave * 16 * PS;
-    const int nmt = (n + 15) >> 4;
-    // raw Q rows of all tiles this wave owns (<= 4) are requested up front
-    constexpr int MAXT = (SMALL_MAX_SUB + 1 + 3) / 4;
-    Frag<T> qraw[MAXT][2];
-#pragma unroll
-    for (int u = 0; u < MAXT; ++u) {
-        const int qi = (wave + 4 * u) * 16 + r16;
-        const int qrow = qi < n ? s_rows[qi] : 0;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-            if (wave + 4 * u < nmt) qraw[u][s2] = read_frag(qkv + (int64_t)qrow * a.ldqkv + head * HD + s2 * 32 + g * 8);
-    }
+    const int np = a.npad ? a.npad[win] : 0;
 #pragma unroll
     for (int u = 0; u < MAXT; ++u) {
         const int mt = wave + 4 * u;
         if (mt >= nmt) break;
-        // Q fragment of this 16-row tile (RoPE + scale in f32)
+        // Q fragment of this 16-row tile (RoPE + scale in f32); B operand: column = query r16
         Frag<T> qf[2];
         {
-            const int qi = mt * 16 + r16;
-            const bool ok = qi < n;
-            const int qrc = ok ? s_slots[qi] : 0;
+            const bool ok = mt * 16 + r16 < n;
+            const int qrc = ((qslot[u] / L) << 16) | (qslot[u] % L);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int d0 = s2 * 32 + g * 8;
@@ -425,121 +441,106 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
                 qf[s2] = make_frag(x, T());
             }
         }
-        // S = Q K^T over all keys; lane holds S[q = g*4 + r][key = t*16 + r16]
-        f32x4 sc[SMALL_MAX_SUB];
-        float mx[4] = {NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};
+        // S^T = K Q^T over all keys; lane holds S[q = r16][key = t*16 + g*4 + r]
+        f32x4 sc[MAXSUB];
+        float mx = np > 0 ? 0.f : NEG_BIG;
 #pragma unroll
-        for (int t = 0; t < SMALL_MAX_SUB; ++t) {
+        for (int t = 0; t < MAXSUB; ++t) {
             sc[t] = f32x4{NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};
             if (t < nsub) {
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) mma_step(acc, qf[s2], read_frag(Ks + (t * 16 + r16) * LD + s2 * 32 + g * 8));
-                const bool kok = t * 16 + r16 < nkeys;
+                for (int s2 = 0; s2 < 2; ++s2) mma_step(acc, read_frag(Ks + (t * 16 + r16) * LD + s2 * 32 + g * 8), qf[s2]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    sc[t][r] = kok ? acc[r] : NEG_BIG;
-                    mx[r] = fmaxf(mx[r], sc[t][r]);
+                    sc[t][r] = t * 16 + g * 4 + r < nkeys ? acc[r] : NEG_BIG;
+                    mx = fmaxf(mx, sc[t][r]);
                 }
             }
         }
-        float sum[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { mx[r] = row16_max(mx[r]); sum[r] = 0.f; }
-        // O = P V.  P = exp(S - max) goes through wave-private LDS (C layout -> A-operand layout).  CHUNK: one [16][32] tile at
-        // a time, so the P buffer costs 5 KB instead of 21 KB per workgroup (3 workgroups / CU up to 144 keys) -- for launches
-        // with more workgroups than 2 per CU; otherwise the whole P row block at once (shorter dependent chain per wave).
+        mx = g4_max(mx);
+        // O = P V with P = exp(S - max) taken straight from the score registers (slot numbering of the header comment)
         f32x4 o[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (CHUNK) {
+        float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c < (SMALL_MAX_SUB + 1) / 2; ++c) {
-                if (c * 32 < NK32) {
+        for (int c = 0; c < (MAXSUB + 1) / 2; ++c) {
+            if (c * 32 < NK32) {
+                float pv[8];
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int t = 2 * c + tt;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float pv = 0.f;
-                            if (t < SMALL_MAX_SUB && t < nsub) { pv = __expf(sc[t < SMALL_MAX_SUB ? t : 0][r] - mx[r]); sum[r] += pv; }
-                            Pw[(g * 4 + r) * PLD + tt * 16 + r16] = to_act<T>(pv);
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const Frag<T> pf = read_frag(Pw + r16 * PLD + g * 8);
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) mma_step(o[d], pf, read_frag(Vt + (d * 16 + r16) * LDP + c * 32 + g * 8));
-                    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order: the next chunk's writes follow this read)
-                }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < SMALL_MAX_SUB + 1; ++t) {      // columns past nsub*16 up to NK32 are zeroed
-                if (t * 16 < NK32) {
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * c + tt;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float pv = 0.f;
-                        if (t < SMALL_MAX_SUB && t < nsub) { pv = __expf(sc[t < SMALL_MAX_SUB ? t : 0][r] - mx[r]); sum[r] += pv; }
-                        Pw[(g * 4 + r) * LDP + t * 16 + r16] = to_act<T>(pv);
+                        float e = 0.f;
+                        if (t < MAXSUB && t < nsub) e = softmax_exp<T>(sc[t < MAXSUB ? t : 0][r] - mx);
+                        pv[tt * 4 + r] = e;
                     }
                 }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int ks = 0; ks < NK32; ks += 32) {
-                const Frag<T> pf = read_frag(Pw + r16 * LDP + ks + g * 8);
+                const Frag<T> pf = make_frag(pv, T());
 #pragma unroll
-                for (int d = 0; d < 4; ++d) mma_step(o[d], pf, read_frag(Vt + (d * 16 + r16) * LDP + ks + g * 8));
+                for (int j = 0; j < 8; ++j) sum += pv[j];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const T* vrow = Vt + (d * 16 + r16) * LDP + c * 32 + g * 4;
+                    mma_step(o[d], pf, frag_from_halves(vrow, vrow + 16));
+                }
             }
         }
+        sum = g4_sum(sum);
+        float padw = 0.f;
+        if (np > 0) { padw = (float)np * softmax_exp<T>(-mx); sum += padw; }
+        const float inv = 1.f / sum;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float inv = 1.f / row16_sum(sum[r]);
             const int qi = mt * 16 + g * 4 + r;
+            const float inv_q = __shfl(inv, g * 4 + r, 64), padw_q = __shfl(padw, g * 4 + r, 64);   // lane q holds query q's row state
             if (qi < n) {
                 T* dst = reinterpret_cast<T*>(a.out) + (int64_t)s_rows[qi] * a.ldo + head * HD + r16 * 4;
                 T o4[4];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) o4[d] = to_act<T>(o[d][r] * inv);     // V^T row d*16 + r16 holds head dim r16*4 + d
+                for (int d = 0; d < 4; ++d) {                   // V^T row d*16 + r16 holds head dim r16*4 + d (vt_row)
+                    float v = o[d][r];
+                    if (np > 0) v += padw_q * a.v_bias[head * HD + r16 * 4 + d];
+                    o4[d] = to_act<T>(v * inv_q);
+                }
                 store4(dst, o4);
             }
         }
-        __builtin_amdgcn_wave_barrier();          // P of this tile fully consumed before the next tile overwrites it
     }
 }
 
 template <typename T>
-size_t attn_small_lds(int64_t stride, int L, bool chunk) {
+size_t attn_small_lds(int64_t stride, int L) {
     const int64_t nsub = (stride + 15) / 16, nk32 = (stride + 31) / 32 * 32, ldp = nk32 + 16 / (int)sizeof(T);
-    const int64_t ps = chunk ? 32 + 16 / (int)sizeof(T) : ldp;
-    return (size_t)(nsub * 16 * Pad<T>::ld + HD * ldp + 64 * ps) * sizeof(T) + (size_t)((stride + 3) & ~3) * 8 + (size_t)L * 16 * 16;
+    return (size_t)(nsub * 16 * Pad<T>::ld + HD * ldp) * sizeof(T) + (size_t)((stride + 3) & ~3) * 8 + (size_t)L * 16 * 16;
 }
 
-template <typename T, bool CHUNK>
+template <typename T, int MAXSUB>
 void launch_small(const AttnArgs& a, size_t lds, int64_t num_heads, int64_t nwin, hipStream_t s) {
     static Toc3dLdsAttr attr;                    // per function instantiation, per device
-    attr.ensure(reinterpret_cast<const void*>(&attn_small_kernel<T, CHUNK>), 80 * 1024);
-    toc3d_launch((attn_small_kernel<T, CHUNK>), dim3((unsigned)num_heads, (unsigned)nwin), dim3(256), lds, s, a);
+    attr.ensure(reinterpret_cast<const void*>(&attn_small_kernel<T, MAXSUB>), 96 * 1024);
+    toc3d_launch((attn_small_kernel<T, MAXSUB>), dim3((unsigned)num_heads, (unsigned)nwin), dim3(256), lds, s, a);
 }
 
 template <typename T>
 void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
-    // accelerated blocks (no analytic zero pads, <= 208 keys incl. virtual ones): whole-window-resident kernel, one workgroup
-    // per (window, head), when its LDS footprint lets at least two of them share a CU.  With more workgroups than two per
-    // CU the chunked-P form (smaller footprint -> a third workgroup per CU) wins; with fewer, the plain form (measured).
-    if (!a.npad && a.stride <= SMALL_MAX_SUB * 16) {
-        const size_t full = attn_small_lds<T>(a.stride, a.L, false), chunk = attn_small_lds<T>(a.stride, a.L, true);
-        const bool crowded = nwin * num_heads > 2 * 256;
-        if (crowded && chunk <= 53 * 1024 && full > 53 * 1024) { launch_small<T, true>(a, chunk, num_heads, nwin, s); return; }
-        if (full <= 80 * 1024) { launch_small<T, false>(a, full, num_heads, nwin, s); return; }
+    // windows of up to 208 keys (virtual kept-pad keys included; every accelerated block of the shipped configs): the whole-window-resident
+    // kernel, one workgroup per (window, head), instantiated for 144 / 176 / 208 keys (score registers per lane).  Measured r02: the dense
+    // 16x16 windows (256 keys, 48 windows x 16 heads) run 49 us here against 45 us on the flash kernel below (more, smaller workgroups).
+    if (a.stride <= 208) {
+        const size_t lds = attn_small_lds<T>(a.stride, a.L);
+        if (lds <= 96 * 1024) {
+            if (a.stride <= 144) launch_small<T, 9>(a, lds, num_heads, nwin, s);
+            else if (a.stride <= 176) launch_small<T, 11>(a, lds, num_heads, nwin, s);
+            else launch_small<T, 13>(a, lds, num_heads, nwin, s);
+            return;
+        }
     }
-    // dense / large windows: flash-style kernel, 64-query workgroups (measured faster than 128-query ones on every window
+    // larger windows: flash-style kernel, 64-query workgroups (measured faster than 128-query ones on every window
     // size of this model: more, fuller workgroups beat the halved K/V staging)
-    const size_t lds = (size_t)(KT + HD + 4 * 16) * Pad<T>::ld * sizeof(T) + (size_t)((a.stride + 3) & ~3) * 8 + (size_t)a.L * 16 * 4 * 4;
+    const size_t lds = (size_t)(KT + HD) * Pad<T>::ld * sizeof(T) + (size_t)((a.stride + 3) & ~3) * 8 + (size_t)a.L * 16 * 4 * 4;
     dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)nwin);
     toc3d_launch((attn_kernel<T, 1>), grid, dim3(256), lds, s, a);
 }

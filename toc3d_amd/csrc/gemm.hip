@@ -99,6 +99,13 @@ TOC3D_DEV void tile_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// Barrier that also publishes this wave's LDS stores (the raw barrier above does not wait for them) -- but NOT its global stores: a
+// __syncthreads() here would hold every wave until its epilogue stores are acknowledged (s_waitcnt vmcnt(0)), microseconds per workgroup.
+TOC3D_DEV void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tile_barrier();
+}
+
 // ---- epilogue of one wavefront's (MT*16) x (NT*16) accumulator block whose first row / column are row0 / col0.  The MFMA is issued
 // with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
 // .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
@@ -277,61 +284,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                 for (int j = 0; j < NT; ++j) mma_step(acc[i][j], fb[j], fa[i]);   // swapped: C^T tile layout, see the epilogue
         }
     };
-    if (STAGES == 1) {
-        // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
-        for (int kt = 0; kt < nk; ++kt) {
-            request(kt);
-            wait_vmcnt<0>();
-            tile_barrier();                              // every wave's pieces of tile kt have landed
-            multiply(kt);
-            tile_barrier();                              // every wave is done reading: the buffer may be overwritten
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < STAGES - 1; ++t)
-            if (t < nk) request(t);
-        for (int kt = 0; kt < nk; ++kt) {
-            if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
-            else wait_vmcnt<0>();                                                                   // pipeline tail
-            tile_barrier();
-            if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);
-            multiply(kt);
-        }
-    }
-
-    if constexpr (EPI == TOC3D_EPI_SWIGLU_STATS) {
-        // Row statistics of the written hidden units for the LayerNorm folded into the next GEMM (include/toc3d.h).  One slot per 128 packed
-        // columns, built in ONE fixed tree for every tile variant: lane -> 4 values in order; 32-column group = butterfly over the 4 lane
-        // groups; slot = (g0 + g1) + (g2 + g3) of its four groups, combined through LDS whatever wave computed them.
-        static_assert(BN % 128 == 0 && NT % 2 == 0, "EPI_SWIGLU_STATS needs N-tiles of whole 128-column slots");
-        constexpr int NG = NT / 2;                      // 32-column groups per wave
-        float gs[MT][NG], gq[MT][NG];
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq);
-        tile_barrier();                                  // every wave is done with the operand tiles: LDS becomes the reduction scratch
-        f32x2* red = reinterpret_cast<f32x2*>(smem);     // [GPT][BM]
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int jp = 0; jp < NG; ++jp) {
-                const float s1 = g4_sum(gs[i][jp]), s2 = g4_sum(gq[i][jp]);
-                if (g == 0) red[(wn * NG + jp) * BM + wm * TM + i * 16 + r16] = f32x2{s1, s2};
-            }
-        tile_barrier();
-        f32x2* data = reinterpret_cast<f32x2*>(a.stats + 4);
-        for (int w = tid; w < BM * (BN / 128); w += NTHR) {
-            const int r = w % BM, sl = w / BM;
-            const int row = m0 + r;
-            if (row >= a.M) continue;
-            const f32x2 v0 = red[(4 * sl) * BM + r], v1 = red[(4 * sl + 1) * BM + r], v2 = red[(4 * sl + 2) * BM + r], v3 = red[(4 * sl + 3) * BM + r];
-            data[(int64_t)row * a.stats_cap + n0 / 128 + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
-        }
-        if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + 127) / 128;
-    } else if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) {
-        // Folded LayerNorm of the A rows: (mean, rstd) per tile row from the partial sums the producing GEMM left, into LDS.  Four threads per
-        // row; thread part p sums slots p, p + 4, ... in sequence, the parts meet in two butterfly steps; f64.  The order is fixed, so the
-        // bits do not depend on the tile variant that runs this epilogue.
-        tile_barrier();                                  // operand tiles are dead: LDS becomes the row table
-        f32x2* lnrow = reinterpret_cast<f32x2*>(smem);   // [BM]
+    // EPI_RESIDUAL_LN -- folded LayerNorm of the A rows: (mean, rstd) per tile row from the partial sums the producing GEMM left (include/toc3d.h),
+    // into a row table behind the operand stages.  Done at kernel start, right after the first operand tiles were requested, so its one
+    // global round trip overlaps theirs.  Four threads per row; thread part p sums slots p, p + 4, ... in sequence, the parts meet in two
+    // butterfly steps; f64.  The order is fixed: the bits do not depend on the tile variant that runs this kernel.
+    f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
+    auto ln_rows_prepare = [&]() {
         const int nslots = *reinterpret_cast<const int*>(a.stats);
         const f32x2* base = reinterpret_cast<const f32x2*>(a.stats + 4);
         for (int w = tid; w < BM * 4; w += NTHR) {
@@ -352,7 +310,60 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             var = var > 0.0 ? var : 0.0;
             if (part == 0) lnrow[r] = f32x2{(float)mean, 1.0f / sqrtf((float)var + a.ln_eps)};
         }
-        tile_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // table rows written before this wave reaches the K loop's first barrier
+    };
+    if (STAGES == 1) {
+        // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
+        for (int kt = 0; kt < nk; ++kt) {
+            request(kt);
+            if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) { if (kt == 0) ln_rows_prepare(); }
+            wait_vmcnt<0>();
+            tile_barrier();                              // every wave's pieces of tile kt have landed
+            multiply(kt);
+            tile_barrier();                              // every wave is done reading: the buffer may be overwritten
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) request(t);
+        if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) ln_rows_prepare();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
+            else wait_vmcnt<0>();                                                                   // pipeline tail
+            tile_barrier();
+            if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);
+            multiply(kt);
+        }
+    }
+
+    if constexpr (EPI == TOC3D_EPI_SWIGLU_STATS) {
+        // Row statistics of the written hidden units for the LayerNorm folded into the next GEMM (include/toc3d.h).  One slot per 128 packed
+        // columns, built in ONE fixed tree for every tile variant: lane -> 4 values in order; 32-column group = butterfly over the 4 lane
+        // groups; slot = (g0 + g1) + (g2 + g3) of its four groups, combined through LDS whatever wave computed them.
+        static_assert(BN % 128 == 0 && NT % 2 == 0, "EPI_SWIGLU_STATS needs N-tiles of whole 128-column slots");
+        constexpr int NG = NT / 2;                      // 32-column groups per wave
+        float gs[MT][NG], gq[MT][NG];
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq);
+        tile_barrier();                                  // every wave is done with the operand tiles (their reads fed MFMAs): LDS becomes the reduction scratch
+        f32x2* red = reinterpret_cast<f32x2*>(smem);     // [GPT][BM]
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jp = 0; jp < NG; ++jp) {
+                const float s1 = g4_sum(gs[i][jp]), s2 = g4_sum(gq[i][jp]);
+                if (g == 0) red[(wn * NG + jp) * BM + wm * TM + i * 16 + r16] = f32x2{s1, s2};
+            }
+        lds_barrier();
+        f32x2* data = reinterpret_cast<f32x2*>(a.stats + 4);
+        for (int w = tid; w < BM * (BN / 128); w += NTHR) {
+            const int r = w % BM, sl = w / BM;
+            const int row = m0 + r;
+            if (row >= a.M) continue;
+            const f32x2 v0 = red[(4 * sl) * BM + r], v1 = red[(4 * sl + 1) * BM + r], v2 = red[(4 * sl + 2) * BM + r], v3 = red[(4 * sl + 3) * BM + r];
+            data[(int64_t)row * a.stats_cap + n0 / 128 + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
+        }
+        if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + 127) / 128;
+    } else if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) {
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM);
     } else {
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
@@ -524,7 +535,7 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
     if constexpr (unsupported) {
         g_bad_variant = true;
     } else {
-        constexpr int lds = STAGES * (BM + BN) * RB;
+        constexpr int lds = STAGES * (BM + BN) * RB + (EPI == TOC3D_EPI_RESIDUAL_LN ? BM * 8 : 0);   // + the (mean, rstd) row table
         static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
         if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds);
         if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
@@ -614,6 +625,7 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 48: launch_cfg<T, EPI, 128, 192, 3, 128, 2, 4, 1>(a, s); break;      // 128x192, 3-deep ring, 120 KiB
         case 49: launch_cfg<T, EPI, 192, 128, 2, 128, 2, 4, 1>(a, s); break;      // 192x128 double buffered, 96x32 per wave (serves SwiGLU), 80 KiB
         case 50: launch_cfg<T, EPI, 192, 128, 1, 128, 2, 4, 1>(a, s); break;      // 192x128 single buffer, 40 KiB
+        case 51: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 8 : 1)>(a, s); break;   // variant 16 held to 64 registers (bf16): FOUR workgroups per CU -- the loop is bound by operand bytes in flight per CU
         // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
         case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB
         case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB

@@ -516,6 +516,27 @@ __global__ __launch_bounds__(256) void copy_bytes_kernel(char* __restrict__ dst,
     for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) dst[i] = src[i];
 }
 
+// Pull a read-only buffer (the next block's packed weights) towards the chip ahead of its use: plain 16-byte loads whose values are
+// kept alive but never stored.  The lines land in the Infinity Cache (and the L2 of the XCD the workgroup runs on); the GEMM that follows
+// then starts on cache hits instead of HBM misses.  Few workgroups on purpose: this runs beside the block chain on a side lane.
+constexpr int PREFETCH_MAX_SEGS = 8;
+struct PrefetchSegs { const f32x4* ptr[PREFETCH_MAX_SEGS]; int64_t n16[PREFETCH_MAX_SEGS]; };
+
+__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchSegs sg, float* __restrict__ sink) {
+    const f32x4* __restrict__ p = sg.ptr[blockIdx.y];
+    const int64_t n16 = sg.n16[blockIdx.y];
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {              // four independent loads in flight per thread
+        const f32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc += (a + b) + (c + d);
+    }
+    for (; i < n16; i += stride) acc += p[i];
+    // never true for finite data that is not all-NaN; keeps the loads observable without writing anything
+    if (acc[0] != acc[0] && acc[1] != acc[1] && acc[2] != acc[2] && acc[3] != acc[3] && sink) sink[0] = acc[0];
+}
+
 // several small device-to-device copies in ONE launch (the per-frame inputs of the recorded plan: every launch has a ~5 us floor)
 constexpr int COPY_MAX_SEGS = 16;
 struct CopySegs { char* dst[COPY_MAX_SEGS]; const char* src[COPY_MAX_SEGS]; int64_t nbytes[COPY_MAX_SEGS]; };
@@ -695,6 +716,22 @@ int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t 
     const int blocks = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
     toc3d_launch(copy_bytes_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (char*)dst, (const char*)src, n16, nbytes);
     TOC3D_LAUNCH_CHECK("toc3d_copy_bytes");
+    return TOC3D_OK;
+}
+
+int toc3d_prefetch(int64_t n, const void* const* ptrs, const int64_t* nbytes, int64_t workgroups, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(n >= 0 && n <= PREFETCH_MAX_SEGS && (n == 0 || (ptrs && nbytes)), "toc3d_prefetch: 0 <= n <= %d buffers, host arrays of n entries", PREFETCH_MAX_SEGS);
+    if (n == 0) return TOC3D_OK;
+    PrefetchSegs sg;
+    for (int64_t i = 0; i < n; ++i) {
+        TOC3D_REQUIRE(nbytes[i] >= 0 && (nbytes[i] == 0 || ptrs[i]) && ((uintptr_t)ptrs[i] % 16) == 0, "toc3d_prefetch: buffer %lld must be 16-byte aligned", (long long)i);
+        sg.ptr[i] = (const f32x4*)ptrs[i];
+        sg.n16[i] = nbytes[i] / 16;
+    }
+    int64_t wg = workgroups > 0 ? workgroups : 16;
+    wg = wg > 256 ? 256 : wg;
+    toc3d_launch(prefetch_kernel, dim3((unsigned)wg, (unsigned)n), dim3(256), 0, as_stream(stream), sg, (float*)nullptr);
+    TOC3D_LAUNCH_CHECK("toc3d_prefetch");
     return TOC3D_OK;
 }
 

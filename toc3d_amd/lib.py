@@ -57,6 +57,7 @@ _SIGS = {
     "toc3d_memory_post_update": "ppppppppppppplpppllllllp",
     "toc3d_copy_bytes": "pplp",
     "toc3d_copy_segments": "lpppp",
+    "toc3d_prefetch": "lpplp",
     "toc3d_plan_create": "p",
     "toc3d_plan_destroy": "p",
     "toc3d_plan_begin": "p",
@@ -130,6 +131,14 @@ def copy_segments(pairs, stream):
         s = (ctypes.c_void_p * n)(*[t.data_ptr() for _, t in chunk])
         b = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t, _ in chunk])
         call("toc3d_copy_segments", n, d, s, b, stream)
+
+
+def prefetch(tensors, workgroups, stream):
+    """One toc3d_prefetch launch over up to 8 (contiguous) device tensors."""
+    n = len(tensors)
+    p = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    b = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in tensors])
+    call("toc3d_prefetch", n, p, b, workgroups, stream)
 
 
 # Lane of the launch plan being recorded by this thread (toc3d_amd/plan.py); None = launch on torch's current stream.
