@@ -156,6 +156,66 @@ def _init_weights(m):
 # ------------------------------------------------------------------------------------------------
 # shared engine: weight packing + per-shape plan + the launch sequence
 # ------------------------------------------------------------------------------------------------
+_flush = None                   # 256 MB scratch shared by all models: evicts L2 + Infinity Cache between tuning launches
+
+
+_VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 163),
+             lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
+
+def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=(None, 0, None, 0, 0.0)):
+    """toc3d_linear_fused with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
+    real operands the first time the shape is seen (never while a launch plan is being recorded: shapes are warmed up eagerly).
+    ``self`` = the owner of the table: anything with ``_tuned`` (dict), ``autotune`` (bool) and ``_dt`` (the backbones, the neck).
+    All variants accumulate K in the same order, so the choice does not change results."""
+    global _flush
+    key = (epi, M, N, K)
+    var = self._tuned.get(key)
+    s = lib.stream_ptr()
+    if var is None:
+        var = 0
+        if lib.recording():
+            # a shape first seen while recording (the eager warm-up forward normally tunes every shape): heuristic tile, no timing
+            lib.call("toc3d_linear_fused", self._dt, epi, 0, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
+            return
+        if self.autotune and not torch.cuda.is_current_stream_capturing():
+            o = out
+            if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN):   # in-place residual add: tune into scratch
+                o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
+            rep_s = torch.empty_like(rep_out) if rep_out is not None else None
+            cands = _VARIANTS[self._dt]
+            if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS):
+                cands = [v for v in cands if v not in (33, 45, 145)]   # wave slabs that are not whole (w1, w2) 32-column groups
+            if epi == lib.EPI_SWIGLU_STATS:                            # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
+                cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47, 60, 63)]
+            if epi == lib.EPI_RESIDUAL_LN:
+                cands = [v for v in cands if v % 100 not in (60, 63)]
+            # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
+            # L2 / Infinity Cache): time single launches behind a cache-sized memset, not a warm back-to-back loop, or the
+            # tuner prefers shallow pipelines that lose in place (tools/ubench/n1024_all_variants.py).
+            if _flush is None or _flush.device != out.device:
+                _flush = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=out.device)
+
+            def cold_time(v, reps):
+                args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, *fused, s)
+                lib.call("toc3d_linear_fused", *args)
+                ts = []
+                for _ in range(reps):
+                    _flush.zero_()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    lib.call("toc3d_linear_fused", *args)
+                    e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return min(ts)
+            # two passes: a quick one over every candidate, then the four best again with more samples (single cold launches
+            # are noisy, and a wrong pick costs 10-20 % on that shape for the lifetime of the model)
+            short = sorted((cold_time(v, 3), v) for v in cands)[:4]
+            var = min((cold_time(v, 9), v) for _, v in short)[1]
+        self._tuned[key] = var
+    lib.call("toc3d_linear_fused", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
+
+
 class _BackboneBase(nn.Module):
     LN_EPS = 1e-6            # norm_layer=partial(nn.LayerNorm, eps=1e-6), toc3d_eva_vit.py:38
     SCORER_LN_EPS = 1e-5     # nn.LayerNorm default inside the scorers
@@ -374,60 +434,8 @@ class _BackboneBase(nn.Module):
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
-    _flush = None               # 256 MB scratch shared by all models: evicts L2 + Infinity Cache between tuning launches
-    _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 163),
-                 lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
-
     def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=(None, 0, None, 0, 0.0)):
-        """toc3d_linear_ex with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
-        real operands the first time the shape is seen (never during hipGraph capture: shapes are warmed up eagerly).
-        All variants accumulate K in the same order, so the choice does not change results."""
-        key = (epi, M, N, K)
-        var = self._tuned.get(key)
-        s = lib.stream_ptr()
-        if var is None:
-            var = 0
-            if lib.recording():
-                # a shape first seen while recording (the eager warm-up forward normally tunes every shape): heuristic tile, no timing
-                lib.call("toc3d_linear_fused", self._dt, epi, 0, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
-                return
-            if self.autotune and not torch.cuda.is_current_stream_capturing():
-                o = out
-                if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN):   # in-place residual add: tune into scratch
-                    o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
-                rep_s = torch.empty_like(rep_out) if rep_out is not None else None
-                cands = self._VARIANTS[self._dt]
-                if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS):
-                    cands = [v for v in cands if v not in (33, 45, 145)]   # wave slabs that are not whole (w1, w2) 32-column groups
-                if epi == lib.EPI_SWIGLU_STATS:                            # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
-                    cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47, 60, 63)]
-                if epi == lib.EPI_RESIDUAL_LN:
-                    cands = [v for v in cands if v % 100 not in (60, 63)]
-                # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
-                # L2 / Infinity Cache): time single launches behind a cache-sized memset, not a warm back-to-back loop, or the
-                # tuner prefers shallow pipelines that lose in place (tools/ubench/n1024_all_variants.py).
-                if _BackboneBase._flush is None or _BackboneBase._flush.device != out.device:
-                    _BackboneBase._flush = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=out.device)
-
-                def cold_time(v, reps):
-                    args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, *fused, s)
-                    lib.call("toc3d_linear_fused", *args)
-                    ts = []
-                    for _ in range(reps):
-                        _BackboneBase._flush.zero_()
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        lib.call("toc3d_linear_fused", *args)
-                        e1.record()
-                        e1.synchronize()
-                        ts.append(e0.elapsed_time(e1))
-                    return min(ts)
-                # two passes: a quick one over every candidate, then the four best again with more samples (single cold launches
-                # are noisy, and a wrong pick costs 10-20 % on that shape for the lifetime of the model)
-                short = sorted((cold_time(v, 3), v) for v in cands)[:4]
-                var = min((cold_time(v, 9), v) for _, v in short)[1]
-            self._tuned[key] = var
-        lib.call("toc3d_linear_fused", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
+        tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused)
 
     def save_packed(self, path):
         """Write the packed device weights (what the kernels consume) to a safetensors file; see ``packed_io``."""

@@ -106,6 +106,8 @@ TOC3D_DEV Frag<float> frag_from_halves(const float* p0, const float* p1) {
     f.hi = *reinterpret_cast<const f32x4*>(p1);
     return f;
 }
+TOC3D_DEV bf16_t frag_elem(const Frag<bf16_t>& f, int j) { return f.v[j]; }
+TOC3D_DEV float frag_elem(const Frag<float>& f, int j) { return j < 4 ? f.lo[j] : f.hi[j - 4]; }
 TOC3D_DEV float g4_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     v = fmaxf(v, __shfl_xor(v, 32, 64));
@@ -207,18 +209,20 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         for (int it = 0; it < 2; ++it) {
             const int c = tid + it * 256;
             const int key = c >> 3, dc = c & 7;
-            const bool ok = kt * KT + key < nkeys;
-            float kx[8], vx[8];
-            frag_to_float(pre[it].k, kx);
-            frag_to_float(pre[it].v, vx);
-            rope8_lds(kx, s_cos, s_sin, L, ok ? s_slots[kt * KT + key] : 0, dc);     // rotate_half pairs (eva_utils.py:318-322,379)
-            if (!ok) {
+            T* vdst = Vt + (dc * 2) * LD + key;                  // vt_row(dc*8 + j) = (j & 3)*16 + dc*2 + (j >> 2)
+            if (kt * KT + key < nkeys) {
+                float kx[8];
+                frag_to_float(pre[it].k, kx);
+                rope8_lds(kx, s_cos, s_sin, L, s_slots[kt * KT + key], dc);          // rotate_half pairs (eva_utils.py:318-322,379)
+                store8(Ks + key * LD + dc * 8, kx);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { kx[j] = 0.f; vx[j] = 0.f; }
+                for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LD] = frag_elem(pre[it].v, j);   // V moves as stored: no conversion
+            } else {
+                const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                store8(Ks + key * LD + dc * 8, z);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LD] = to_act<T>(0.f);
             }
-            store8(Ks + key * LD + dc * 8, kx);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Vt[vt_row(dc * 8 + j) * LD + key] = to_act<T>(vx[j]);
         }
         __syncthreads();
         if (kt + 1 < nkt) fetch(kt + 1);         // in flight during the MFMA phase below
@@ -235,11 +239,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) mma_step(sc[t], read_frag(Ks + (t * 16 + r16) * LD + s * 32 + g * 8), qf[mi][s]);
+                if (kt * KT + t * 16 + 16 > nkeys) {              // mask keys past the window: only a tile that straddles the end (wave-uniform)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    sc[t][r] = kt * KT + t * 16 + g * 4 + r < nkeys ? sc[t][r] : NEG_BIG;      // mask keys past the window
-                    mx = fmaxf(mx, sc[t][r]);
+                    for (int r = 0; r < 4; ++r) sc[t][r] = kt * KT + t * 16 + g * 4 + r < nkeys ? sc[t][r] : NEG_BIG;
                 }
+                mx = fmaxf(mx, fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3])));
             }
             // ---- online softmax of query r16: the 4 lane groups hold disjoint keys of the same query ----
             mx = g4_max(mx);
@@ -355,13 +359,11 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     // ---- staging with every global load of the workgroup in flight at once (the kernel is latency-bound: its inputs
     // were written by a GEMM on other XCDs, so nothing hits this XCD's L2) ----
     constexpr int MAXC = (MAXSUB * 16 + 16) * 8 / 256;           // (key, 8-dim chunk) pairs per thread
-    int crow[MAXC], cslot[MAXC];
+    int crow[MAXC];
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {                             // 1. index loads
         const int key = (tid + i * 256) >> 3;
-        const bool ok = key < nkeys;
-        crow[i] = ok ? rows[key] : 0;
-        cslot[i] = ok ? slots[key] : 0;
+        crow[i] = key < nkeys ? rows[key] : 0;
     }
     Frag<T> kraw[MAXC], vraw[MAXC];
 #pragma unroll
@@ -377,13 +379,10 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     const int nmt = (n + 15) >> 4;
     constexpr int MAXT = (MAXSUB + 3) / 4;
     Frag<T> qraw[MAXT][2];
-    int qslot[MAXT];
 #pragma unroll
     for (int u = 0; u < MAXT; ++u) {
         const int qi = (wave + 4 * u) * 16 + r16;
-        const bool ok = qi < n;
-        const int qrow = ok ? rows[qi] : -1;
-        qslot[u] = ok ? slots[qi] : 0;
+        const int qrow = qi < n ? rows[qi] : -1;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
             if (wave + 4 * u < nmt) {
@@ -391,7 +390,11 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
                 qraw[u][s2] = read_frag(src + head * HD + s2 * 32 + g * 8);
             }
     }
-    for (int j = tid; j < n; j += 256) s_rows[j] = rows[j];      // 3. output rows + compact RoPE tables -> LDS
+    for (int j = tid; j < nkeys; j += 256) {                     // 3. output rows, RoPE coordinates (one division per key, not per chunk)
+        const int sl = slots[j];                                 //    and the compact RoPE tables -> LDS
+        s_rows[j] = rows[j];
+        s_slots[j] = ((sl / L) << 16) | (sl % L);
+    }
     for (int i = tid; i < L * 16; i += 256) {
         const int c = i >> 4, f = i & 15;
         s_cos[i] = a.cosT[(int64_t)(c * L) * HD + 2 * f];
@@ -405,17 +408,20 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
         const int c = tid + i * 256;
         if (c < NK32 * 8) {
             const int key = c >> 3, dc = c & 7;
-            float kx[8], vx[8];
-            frag_to_float(kraw[i], kx);
-            frag_to_float(vraw[i], vx);
-            rope8_lds(kx, s_cos, s_sin, L, ((cslot[i] / L) << 16) | (cslot[i] % L), dc);
-            if (key >= nkeys) {
+            T* vdst = Vt + (dc * 2) * LDP + key;                 // vt_row(dc*8 + j) = (j & 3)*16 + dc*2 + (j >> 2)
+            if (key < nkeys) {
+                float kx[8];
+                frag_to_float(kraw[i], kx);
+                rope8_lds(kx, s_cos, s_sin, L, s_slots[key], dc);
+                store8(Ks + key * LD + dc * 8, kx);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { kx[j] = 0.f; vx[j] = 0.f; }
+                for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LDP] = frag_elem(vraw[i], j);   // V moves as stored: no conversion
+            } else {
+                const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (key < nsub * 16) store8(Ks + key * LD + dc * 8, z);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LDP] = to_act<T>(0.f);
             }
-            if (key < nsub * 16) store8(Ks + key * LD + dc * 8, kx);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Vt[vt_row(dc * 8 + j) * LDP + key] = to_act<T>(vx[j]);
         }
     }
     __syncthreads();
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
         Frag<T> qf[2];
         {
             const bool ok = mt * 16 + r16 < n;
-            const int qrc = ((qslot[u] / L) << 16) | (qslot[u] % L);
+            const int qrc = ok ? s_slots[mt * 16 + r16] : 0;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int d0 = s2 * 32 + g * 8;
@@ -451,11 +457,12 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) mma_step(acc, read_frag(Ks + (t * 16 + r16) * LD + s2 * 32 + g * 8), qf[s2]);
+                if (t * 16 + 16 > nkeys) {                        // only the last tile can straddle the end of the key list (wave-uniform)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    sc[t][r] = t * 16 + g * 4 + r < nkeys ? acc[r] : NEG_BIG;
-                    mx = fmaxf(mx, sc[t][r]);
+                    for (int r = 0; r < 4; ++r) acc[r] = t * 16 + g * 4 + r < nkeys ? acc[r] : NEG_BIG;
                 }
+                sc[t] = acc;
+                mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
             }
         }
         mx = g4_max(mx);

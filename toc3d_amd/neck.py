@@ -15,7 +15,7 @@ import torch.nn as nn
 import os
 
 from . import lib
-from .backbone import _round_up
+from .backbone import _round_up, tuned_linear
 from .plan import MODES, run_frame
 
 
@@ -46,10 +46,16 @@ class CPFPN(nn.Module):
                 nn.init.zeros_(m.bias)
         self._packed = None
         self._ws = {}
+        self._tuned = {}                # (epilogue, M, N, K) -> GEMM tile variant (toc3d_amd.backbone.tuned_linear); bench.py shares the backbone's table
+        self.autotune = True
         self.alias_outputs = False      # True: the returned level-0 tensor is the reused workspace (benchmarks, fused pipelines)
         self.launch_mode = os.environ.get("TOC3D_LAUNCH", "plan")       # see toc3d_amd/plan.py
         assert self.launch_mode in MODES
         self._stream_pool = []
+
+    @property
+    def _dt(self):
+        return lib.BF16 if self.precision == "bf16" else lib.F32
 
     def load_state_dict(self, *a, **k):
         self._packed = None
@@ -114,9 +120,10 @@ class CPFPN(nn.Module):
             else:
                 a = ws["a"]
                 lib.call("toc3d_pack_weight", dt, nhwc, M, Cin, a, M, Kl, s)           # f32 -> act conversion with K padding
-            lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, None, M, Co, Kl, 0, s)
+            # both convolutions as GEMMs with a per-shape autotuned tile (N = 256 leaves 94 tiles of 128x128 for 256 CUs: the default tile is the wrong one)
+            tuned_linear(self, lib.EPI_RESIDUAL, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, None, M, Co, Kl, 0)
             lib.call("toc3d_im2col_3x3", dt, ws["lat"], ws["col"], Kf, V, h, w, Co, s)
-            lib.call("toc3d_linear", dt, lib.EPI_RESIDUAL, ws["col"], Kf, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, None, M, Co, Kf, 0, s)
+            tuned_linear(self, lib.EPI_RESIDUAL, ws["col"], Kf, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, None, M, Co, Kf, 0)
             lib.call("toc3d_nhwc_to_nchw", ws["o0"], ws["out0"], V, h * w, Co, s)
 
         # The launch sequence names the input buffer: it can be recorded (and replayed with one C call) only for an input that sits

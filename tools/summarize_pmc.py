@@ -14,6 +14,24 @@ from collections import defaultdict
 
 
 def short(name):
+    # rocprofv3 leaves the anonymous-namespace templates mangled: _ZN12_GLOBAL__N_111gemm_kernelIDF16bLi4ELi128E...
+    m = re.search(r"gemm_kernelI(DF16b|f)((?:Li\d+E)+)", name)
+    if m:
+        v = re.findall(r"Li(\d+)E", m[2])
+        return f"gemm<{'bf16' if m[1] == 'DF16b' else 'f32'},epi{v[0]},{v[1]}x{v[2]},stages{v[3]},rb{v[4]},waves{v[5]}x{v[6]},occ{v[7]}>"
+    m = re.search(r"gemm_phased_kernelI((?:Li\d+E)+)", name)
+    if m:
+        v = re.findall(r"Li(\d+)E", m[1])
+        return f"gemm_phased<epi{v[0]},{v[1]}x{v[2]},waves{v[3]}x{v[4]}>"
+    m = re.search(r"attn_small_kernelI(DF16b|f)Li(\d+)E", name)
+    if m:
+        return f"attn_small<{'bf16' if m[1] == 'DF16b' else 'f32'},maxsub{m[2]}>"
+    m = re.search(r"attn_kernelI(DF16b|f)", name)
+    if m:
+        return f"attn_flash<{'bf16' if m[1] == 'DF16b' else 'f32'}>"
+    m = re.search(r"_GLOBAL__N_1\d+([a-z_0-9]+_kernel)", name)
+    if m:
+        return m[1]
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"gemm_kernel<([^,]+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", n)
     if m:

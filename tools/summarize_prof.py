@@ -8,13 +8,14 @@ from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(root, "gpurun_out")
+out = os.path.join(root, sys.argv[2]) if len(sys.argv) > 2 else os.path.join(root, "gpurun_out")     # directory holding kt/ fs/ wsz/
+cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 10 --warmup 3 --groups 1 --no-cpu-baseline --no-breakdown --tune-cache tune.json"
 
 
 def family(name):
-    for key in ("gemm_kernel", "attn_small_kernel", "attn_kernel", "ln_rows_kernel", "ln_act_kernel", "ln_rebase_kernel", "gather_merge_ln_kernel", "scatter_update_kernel",
+    for key in ("gemm_phased_kernel", "gemm_kernel", "attn_small_kernel", "attn_kernel", "ln_rows_kernel", "ln_act_kernel", "ln_rebase_kernel", "gather_merge_ln_kernel", "scatter_update_kernel",
                 "window_topk_kernel", "rank_desc_kernel", "motion_queries_kernel", "collapse_kernel", "score_tokens_kernel", "im2col", "nhwc_to_nchw",
-                "abs_pos", "pack_", "window_map_dense", "score_head", "global_mean_half"):
+                "abs_pos", "pack_", "window_map_dense", "score_head", "global_mean_half", "copy_segments", "copy_bytes", "prefetch"):
         if key in name:
             return key
     return "other (torch / runtime): " + re.sub(r"\(.*", "", name)[:60]
@@ -28,23 +29,23 @@ for r in rows:
     f[1] += float(r["TotalDurationNs"])
 tot = sum(v[1] for v in fam.values())
 with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"), "w") as fo:
-    fo.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --groups 1 --no-cpu-baseline --no-breakdown --tune-cache tune.json\n")
-    fo.write("# (13 steps in the trace; per-family totals, then the per-instantiation rows of the GEMM)\n")
+    fo.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}\n")
+    fo.write("# (every step of the run is in the trace; per-family totals, then the per-instantiation rows of the GEMM)\n")
     fo.write("family,calls,total_us,avg_us,percent\n")
     for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         fo.write(f"\"{k}\",{v[0]},{v[1] / 1e3:.1f},{v[1] / v[0] / 1e3:.2f},{100 * v[1] / tot:.2f}\n")
     fo.write("\nname,calls,total_us,avg_us\n")
     for r in rows:
-        if "gemm_kernel" in r["Name"]:
+        if "gemm_kernel" in r["Name"] or "gemm_phased_kernel" in r["Name"]:
             fo.write(f"\"{r['Name'][:160]}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.1f},{float(r['AverageNs']) / 1e3:.2f}\n")
-g = fam["gemm_kernel"]
+g = [fam["gemm_kernel"][0] + fam["gemm_phased_kernel"][0], fam["gemm_kernel"][1] + fam["gemm_phased_kernel"][1]]
 print(f"GEMM: {g[0]} launches, avg {g[1] / g[0] / 1e3:.2f} us, {100 * g[1] / tot:.1f}% of kernel time")
 
 
 def pmc(dirname, prefix, counter):
     n, s = 0, 0.0
     for r in csv.DictReader(open(os.path.join(out, dirname, f"{prefix}_counter_collection.csv"))):
-        if "gemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if ("gemm_kernel" in r["Kernel_Name"] or "gemm_phased_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             n += 1
             s += float(r["Counter_Value"])
     return n, s / max(n, 1)
@@ -57,7 +58,6 @@ js = {"kernel": "gemm_kernel<*> (all toc3d_linear launches of the step)", "launc
       "correction": "gfx950 rocprofv3: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> read bytes = 2 x FETCH_SIZE "
                     "(MI355X_MICROARCH.md, HBM); WRITE_SIZE uncalibrated, used as is",
       "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
-      "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (then WRITE_SIZE in a separate pass) -- python bench.py --steps 10 --warmup 3 "
-                 "--groups 1 --no-cpu-baseline --no-breakdown --tune-cache tune.json"}
+      "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (then WRITE_SIZE in a separate pass) -- " + cmd}
 json.dump(js, open(os.path.join(root, "profiles", f"{tag}_gemm_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(js)[:400])
