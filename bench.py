@@ -201,7 +201,7 @@ def main():
                 tag = f"[epi{a[1]} v{a[2]} M={a[15]} N={a[16]} K={a[17]}]"
             elif name == "toc3d_linear":
                 tag = f"[epi{a[1]} M={a[14]} N={a[15]} K={a[16]}]"
-            elif name == "toc3d_window_attention":
+            elif name.startswith("toc3d_window_attention"):
                 tag = f"[stride={a[11]} nwin={a[12]} maxq={a[13]}]"
             else:
                 tag = ""
@@ -269,7 +269,7 @@ def main():
             mnk = re.search(r"epi(\d+) .*M=(\d+) N=(\d+) K=(\d+)", tag) if name.startswith("toc3d_linear") else None
             if mnk:
                 e, M_, N_, K_ = (int(v) for v in mnk.groups())
-                out_b = 2 * M_ * N_ * 4 if e in (1, 5) else (M_ * (N_ // 2) * esz if e in (2, 4) else M_ * N_ * esz)
+                out_b = 2 * M_ * N_ * 4 + (M_ * N_ * esz if e == 6 else 0) if e in (1, 5, 6) else (M_ * (N_ // 2) * esz if e in (2, 4, 7) else M_ * N_ * esz)
                 gemm_bytes += (M_ * K_ + N_ * K_) * esz + N_ * 4 + out_b
         gemm_ms = sum(v[1] for k, v in breakdown.items() if k.startswith("toc3d_linear"))
         gemm_n = sum(v[0] for k, v in breakdown.items() if k.startswith("toc3d_linear"))

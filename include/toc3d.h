@@ -48,6 +48,9 @@ extern "C" {
 #define TOC3D_EPI_GELU 3      /* out(act)  = gelu_erf(A.W^T + bias)                                    */
 #define TOC3D_EPI_SWIGLU_STATS 4  /* SWIGLU + per-row (sum, sum of squares) of the written hidden units  (toc3d_linear_fused) */
 #define TOC3D_EPI_RESIDUAL_LN 5   /* RESIDUAL with a LayerNorm of the A rows folded into the epilogue    (toc3d_linear_fused) */
+#define TOC3D_EPI_RESIDUAL_STATS 6    /* RESIDUAL + act-dtype copy of the output rows + their per-row statistics (toc3d_linear_fused) */
+#define TOC3D_EPI_SWIGLU_STATS_LN 7   /* SWIGLU_STATS with a LayerNorm of the A rows folded into the epilogue   (toc3d_linear_fused) */
+#define TOC3D_EPI_CONV3X3 8           /* out(f32) = conv3x3(NHWC act tensor) + bias as an implicit GEMM          (toc3d_conv3x3_nhwc) */
 
 typedef void* toc3d_stream_t;
 
@@ -97,19 +100,30 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
  *   w3(LN(h))[n] = rstd * (h . W'[n] - mean * c1[n]) + c2[n],   W' = gamma (.) w3 (packed in the act dtype), c1[n] = sum_j W'[n, j],
  *   c2[n] = sum_j beta[j] w3[n, j] + b3[n]   (toc3d_pack_weight_lnfold), mean / rstd over the n_valid hidden units of the row.
  * So the LayerNorm pass over h (read + write of M x Hp activations per block, one launch) disappears:
- *   EPI_SWIGLU_STATS  = EPI_SWIGLU that also leaves per-row partial (sum h, sum h^2) of the *rounded* hidden units in row_stats:
+ *   EPI_SWIGLU_STATS  = EPI_SWIGLU that also leaves per-row partial (sum h, sum h^2) of the *rounded* hidden units in stats_out:
  *                       int32 header [4] (header[0] = slots per row actually written) followed by f32 [M, stats_cap, 2]; one slot per
  *                       128 packed columns, every slot summed in one fixed tree whatever the tile variant (variants whose N-tile is not a
  *                       multiple of 128 cannot serve it: TOC3D_ERR_UNSUPPORTED), so results do not depend on the variant;
- *                       stats_cap >= ceil(N / 128).
+ *                       stats_out_cap >= ceil(N / 128).
  *   EPI_RESIDUAL_LN   = EPI_RESIDUAL on A = h with W = W', bias = c2, col_sums = c1, ln_n = number of valid hidden units, ln_eps;
- *                       reads row_stats (fixed summation order: independent of its own tile variant too).
- * Every other argument as toc3d_linear_ex; epilogues 0-3 ignore the five extra arguments. */
+ *                       reads stats_in (fixed summation order: independent of its own tile variant too).
+ * The same identity removes norm2 (eva_vit.py:263, toc3d_eva_vit.py:381): the attention projection's residual epilogue leaves the updated
+ * residual-stream rows in the act dtype plus their statistics, and the w1|w2 GEMM applies the LayerNorm to its accumulators:
+ *   EPI_RESIDUAL_STATS   = EPI_RESIDUAL + out_act [M, ld_act] (act-dtype copy of the f32 output rows) + stats_out with one slot per 64 output
+ *                          columns (N-tiles must be multiples of 64); stats_out_cap >= ceil(N / 64).
+ *   EPI_SWIGLU_STATS_LN  = EPI_SWIGLU_STATS on A = out_act with W = gamma-scaled interleaved weights, bias = c2, col_sums = c1 in packed column
+ *                          order (toc3d_pack_swiglu_lnfold); reads stats_in, writes stats_out (different buffers).
+ * stats_out / stats_in: int32 header [4] + f32 [M, cap, 2] each; ln_n = width of the normalised rows (valid hidden units for EPI_RESIDUAL_LN,
+ * K for EPI_SWIGLU_STATS_LN).  Every other argument as toc3d_linear_ex; epilogues 0-3 ignore the nine extra arguments. */
 int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
                        const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                       float* row_stats, int64_t stats_cap, const float* col_sums, int64_t ln_n, float ln_eps,
-                       toc3d_stream_t stream);
+                       float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap,
+                       const float* col_sums, int64_t ln_n, float ln_eps, void* out_act, int64_t ld_act, toc3d_stream_t stream);
+/* mlp.w1 / mlp.w2 interleaved as toc3d_pack_swiglu, scaled by norm2's gamma per input channel; c1 [2*Hp] = row sums of the ROUNDED scaled
+ * weights, c2 [2*Hp] = beta . w + b, both in packed row order. */
+int toc3d_pack_swiglu_lnfold(int dtype, const float* w1, const float* w2, const float* b1, const float* b2, const float* gamma, const float* beta,
+                             int64_t Hd, int64_t K, void* out_w, float* c1, float* c2, int64_t Hp, int64_t Kp, toc3d_stream_t stream);
 /* w3 f32 [N, K], ffn_ln gamma / beta f32 [K], b3 f32 [N] -> W' act [Np, Kp] (zero padded), c1 f32 [N] (sums of the ROUNDED W' rows, so
  * that the mean term cancels exactly what the GEMM accumulated), c2 f32 [N]. */
 int toc3d_pack_weight_lnfold(int dtype, const float* w3, const float* gamma, const float* beta, const float* b3, int64_t N, int64_t K,
@@ -190,6 +204,16 @@ int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out,
                            const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
                            const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
                            toc3d_stream_t stream);
+/* The same launch with a weight prefetch riding on it: up to 4 read-only device buffers (HOST arrays prefetch_ptrs / prefetch_bytes of
+ * n_prefetch entries, 16-byte aligned) are streamed through the caches by `prefetch_workgroups` extra workgroups (0 = 64) of the attention
+ * grid and discarded -- the packed weights of the GEMMs that follow (this block's proj / w1|w2 / w3, the next block's q|k|v).  The attention
+ * kernels are latency-bound and leave HBM idle; the weights were last touched a frame ago.  Results are identical to toc3d_window_attention. */
+int toc3d_window_attention_pf(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
+                              const int32_t* slots, const int32_t* count, const int32_t* count_k, const int32_t* npad,
+                              const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
+                              const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
+                              int64_t n_prefetch, const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int64_t prefetch_workgroups,
+                              toc3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Token selection.
@@ -299,6 +323,13 @@ int toc3d_score_head(int dtype, const void* f, int64_t ld, int64_t kdim, const f
  *   rows [V*h*w, 9*C] act with column order (ky, kx, c); the weight is packed to match by the host.
  */
 int toc3d_nhwc_to_nchw(const float* x, float* out, int64_t V, int64_t T, int64_t C, toc3d_stream_t stream);
+/* CPFPN's 3x3 conv (pad 1, necks/cp_fpn.py:124-133) as an IMPLICIT GEMM: x act [V, h, w, C] (NHWC, C a multiple of 64), W act packed
+ * [ceil128(Cout), 9*C] in (ky, kx, c) column order (the layout toc3d_im2col_3x3 produces rows for), bias f32 [Cout] or NULL ->
+ * out f32 [V*h*w, ldo].  The GEMM's operand loader gathers the nine neighbours of every pixel itself (out-of-image taps read `zeros`, a
+ * device buffer of >= 128 zero bytes), so the [V*h*w, 9*C] im2col matrix is never written or read; same K order as toc3d_im2col_3x3 +
+ * toc3d_linear, hence the same bits.  `variant` as toc3d_linear_ex (phased variants excluded). */
+int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const void* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
+                       int64_t V, int64_t h, int64_t w, int64_t Cout, const void* zeros, toc3d_stream_t stream);
 int toc3d_im2col_3x3(int dtype, const float* x, void* out, int64_t ldo, int64_t V, int64_t h, int64_t w, int64_t C,
                      toc3d_stream_t stream);
 

@@ -516,3 +516,54 @@ def test_head_token_embedding_full_size_matches_oracle():
         rm, rp = HO.token_embeddings(sd, cfg, inp["feats"], inp["intrinsics"], inp["lidar2img"], 320, 800)
     assert tuple(memory.shape) == (1, 6000, 256)
     assert rel_max(memory, rm) < 2e-4 and rel_max(pos, rp) < 2e-4
+
+
+def test_folded_layernorms_and_riding_prefetch_against_the_explicit_sequence():
+    """bf16 dense backbone (no discrete decisions): ffn_ln folded into the w1|w2 / w3 GEMMs (default), norm2 folded into the projection /
+    w1|w2 GEMMs as well (opt-in), against the explicit LayerNorm launches; all within bf16 rounding of each other and of the fp32 oracle.
+    The weight prefetch riding on the attention launches must not change a bit."""
+    cfg = configs.get("eva_dense")
+    sd = synth.make_state_dict(cfg)
+    inp = synth.make_inputs(cfg, views_per_frame=1)
+    x = inp["x"].to(DEV)
+    with torch.no_grad():
+        ref = O.forward_eva(sd, cfg, inp["x"])["last_feat"]
+    feats = {}
+    for tag, ffn, n2, pf in (("explicit", False, False, 0), ("ffn_ln folded", True, False, 0), ("ffn_ln + norm2 folded", True, True, 0),
+                             ("ffn_ln folded + prefetch", True, False, 48)):
+        m = toc3d_amd.build_backbone(dict(cfg, precision="bf16"))
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        m.fold_ffn_ln, m.fold_norm2, m.prefetch_weights, m.autotune = ffn, n2, pf, False
+        for _ in range(3):                                       # eager warm-up, recorded plan, replay
+            f = m(x)["last_feat"].clone()
+        feats[tag] = f
+        print(f"[{tag}] rel l2 vs fp32 oracle {rel_l2(f, ref):.3e}")
+        del m
+    e0 = rel_l2(feats["explicit"], ref)
+    for tag in ("ffn_ln folded", "ffn_ln + norm2 folded"):
+        assert rel_l2(feats[tag], ref) < 1.2 * e0 + 2e-3, tag
+        assert rel_l2(feats[tag], feats["explicit"]) < 3e-2, tag
+    assert torch.equal(feats["ffn_ln folded + prefetch"], feats["ffn_ln folded"])
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 2e-2)])
+def test_full_size_neck_matches_oracle(precision, tol):
+    """CPFPN at the shipped size (1024 -> 256 channels, 6 x 20 x 50 tokens; ToC3D_faster.py:70-74): 1x1 lateral GEMM + the implicit-GEMM 3x3
+    conv against the oracle's F.conv2d composition (necks/cp_fpn.py:156-208), NCHW input (copy path) and the backbone's NHWC buffer layout."""
+    nsd = synth.neck_state_dict(configs.CPFPN_CFG)
+    neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision=precision))
+    neck.load_state_dict(nsd)
+    neck = neck.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn(6, 1024, 20, 50, generator=g)
+    with torch.no_grad():
+        r0, r1 = O.cpfpn(nsd, feat)
+    n0, n1 = neck([feat.to(DEV)])
+    e0, e1 = rel_max(n0, r0), rel_max(n1, r1)
+    print(f"[full-size neck {precision}] rel max err level0 {e0:.3e} level1 {e1:.3e}")
+    assert tuple(n0.shape) == (6, 256, 20, 50) and tuple(n1.shape) == (6, 256, 10, 25) and e0 < tol and e1 < tol
+    nhwc = feat.permute(0, 2, 3, 1).contiguous().to(DEV)              # what the backbone hands over: an NCHW view of an NHWC buffer
+    for _ in range(3):                                                 # eager, recorded, replayed
+        m0, _ = neck([nhwc.permute(0, 3, 1, 2)])
+    assert torch.equal(m0, n0)

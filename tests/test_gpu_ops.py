@@ -787,7 +787,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
         stats = torch.zeros(4 + M * cap * 2, device=DEV)
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd,
-                 stats, cap, None, 0, 0.0, S())
+                 stats, cap, None, 0, None, 0, 0.0, None, 0, S())
         assert torch.equal(hid, hid0), f"variant {v}: hidden units differ from EPI_SWIGLU"
         nslots = int(stats[:1].view(torch.int32).item())
         assert nslots == (2 * Hp + 127) // 128
@@ -800,7 +800,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
         out = res.clone()
         rep = torch.zeros(nrep, C, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,
-                 stats, cap, c1, Hd, eps, S())
+                 None, 0, stats, cap, c1, Hd, eps, None, 0, S())
         if ref_out is None:
             ref_out, ref_rep = out.clone(), rep.clone()
             e_fold, e_seq = relerr(out, ref), relerr(out0, ref)
@@ -811,8 +811,107 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
     for v, epi in ((47, lib.EPI_SWIGLU_STATS), (9, lib.EPI_SWIGLU_STATS), (60, lib.EPI_SWIGLU_STATS), (60, lib.EPI_RESIDUAL_LN)):
         with pytest.raises(RuntimeError, match="cannot serve"):
             if epi == lib.EPI_SWIGLU_STATS:
-                lib.call("toc3d_linear_fused", dt, epi, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, 0.0, S())
+                lib.call("toc3d_linear_fused", dt, epi, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, None, 0, 0.0, None, 0, S())
             else:
-                lib.call("toc3d_linear_fused", dt, epi, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, None, None, M, C, Hp, 0, stats, cap, c1, Hd, eps, S())
+                lib.call("toc3d_linear_fused", dt, epi, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, None, None, M, C, Hp, 0, None, 0, stats, cap, c1, Hd, eps, None, 0, S())
     with pytest.raises(RuntimeError, match="bf16 only"):
-        lib.call("toc3d_linear_fused", lib.F32, lib.EPI_SWIGLU_STATS, 16, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, 0.0, S())
+        lib.call("toc3d_linear_fused", lib.F32, lib.EPI_SWIGLU_STATS, 16, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, None, 0, 0.0, None, 0, S())
+
+
+def test_norm2_folded_across_the_projection_boundary():
+    """norm2 folded (EPI_RESIDUAL_STATS -> EPI_SWIGLU_STATS_LN, eva_vit.py:263) against the explicit sequence (EPI_RESIDUAL ->
+    toc3d_layernorm_rows -> EPI_SWIGLU_STATS) and an f64 reference; bf16 copy, statistics and hidden units independent of the tile variant."""
+    dt, tdt = lib.BF16, torch.bfloat16
+    M, C, Hd, Hp = 777, 384, 300, 320
+    eps = 1e-6
+    att = as_act(rnd(M, C, seed=1), tdt)
+    Wp, bp = rnd(C, C, seed=2, scale=C ** -0.5), rnd(C, seed=3).to(DEV)
+    wproj = pack(Wp, dt, tdt)
+    x0 = (3.0 * rnd(M, C, seed=4) + 0.7).to(DEV)                      # residual stream with a non-zero mean
+    g2, b2 = (1.0 + 0.3 * rnd(C, seed=5)).to(DEV), (0.2 * rnd(C, seed=6)).to(DEV)
+    w1, w2 = rnd(Hd, C, seed=7, scale=C ** -0.5).to(DEV), rnd(Hd, C, seed=8, scale=C ** -0.5).to(DEV)
+    bb1, bb2 = rnd(Hd, seed=9).to(DEV), rnd(Hd, seed=10).to(DEV)
+    rep_index = torch.full((M,), -1, dtype=torch.int32, device=DEV)
+    rep_index[::40] = torch.arange(len(range(0, M, 40)), dtype=torch.int32, device=DEV)
+    nrep = int((rep_index >= 0).sum())
+    # explicit sequence
+    x_ref = x0.clone()
+    rep0 = torch.zeros(nrep, C, device=DEV)
+    lib.call("toc3d_linear_ex", dt, lib.EPI_RESIDUAL, 16, att, C, wproj, C, bp, x_ref, C, x_ref, C, 0, rep0, rep_index, M, C, C, 0, S())
+    a_ln = torch.zeros(M, C, dtype=tdt, device=DEV)
+    lib.call("toc3d_layernorm_rows", dt, x_ref, C, None, None, g2, b2, eps, a_ln, C, M, C, S())
+    w12 = torch.empty(2 * Hp, C, dtype=tdt, device=DEV)
+    b12 = torch.empty(2 * Hp, device=DEV)
+    lib.call("toc3d_pack_swiglu", dt, w1, w2, bb1, bb2, Hd, C, w12, b12, Hp, C, S())
+    hid_seq = torch.zeros(M, Hp, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear_ex", dt, lib.EPI_SWIGLU, 16, a_ln, C, w12, C, b12, hid_seq, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd, S())
+    # f64 reference from the updated f32 stream
+    xd = x_ref.double()
+    ln = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + eps) * g2.double() + b2.double()
+    h_ref = torch.nn.functional.silu(ln @ w1.double().T + bb1.double()) * (ln @ w2.double().T + bb2.double())
+    # folded
+    w12f = torch.empty(2 * Hp, C, dtype=tdt, device=DEV)
+    c1, c2 = torch.empty(2 * Hp, device=DEV), torch.empty(2 * Hp, device=DEV)
+    lib.call("toc3d_pack_swiglu_lnfold", dt, w1, w2, bb1, bb2, g2, b2, Hd, C, w12f, c1, c2, Hp, C, S())
+    cap2, cap = C // 64, 6
+    ref_a = ref_st = ref_h = None
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 114, 116, 117, 126, 145):
+        x = x0.clone()
+        a_raw = torch.full((M, C), 9.0, dtype=tdt, device=DEV)
+        st2 = torch.zeros(4 + M * cap2 * 2, device=DEV)
+        rep = torch.zeros(nrep, C, device=DEV)
+        lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_STATS, v, att, C, wproj, C, bp, x, C, x, C, 0, rep, rep_index, M, C, C, 0,
+                 st2, cap2, None, 0, None, 0, 0.0, a_raw, C, S())
+        assert torch.equal(x, x_ref) and torch.equal(rep, rep0), f"variant {v}: f32 output differs from EPI_RESIDUAL"
+        assert torch.equal(a_raw, x_ref.to(tdt)), f"variant {v}: act-dtype copy is not the rounded output"
+        assert int(st2[:1].view(torch.int32).item()) == cap2
+        s2 = st2[4:].view(M, cap2, 2)
+        if ref_st is None:
+            ref_a, ref_st = a_raw.clone(), s2.clone()
+            assert relerr(s2[..., 0].sum(1), a_raw.double().sum(1)) < 1e-5 and relerr(s2[..., 1].sum(1), (a_raw.double() ** 2).sum(1)) < 1e-5
+        assert torch.equal(s2, ref_st), f"variant {v}: row statistics depend on the tile variant"
+    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 116, 117, 126, 149):
+        hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
+        st = torch.zeros(4 + M * cap * 2, device=DEV)
+        lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS_LN, v, ref_a, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
+                 st, cap, st2, cap2, c1, C, eps, None, 0, S())
+        if ref_h is None:
+            ref_h, ref_hs = hid.clone(), st.clone()
+            e_fold, e_seq = relerr(hid[:, :Hd], h_ref), relerr(hid_seq[:, :Hd], h_ref)
+            print(f"[norm2 fold] hidden units rel err vs f64: folded {e_fold:.3e}, explicit LayerNorm launch {e_seq:.3e}")
+            assert e_fold < 1.5e-2 and e_fold < 1.5 * e_seq + 1e-3
+            assert torch.count_nonzero(hid[:, Hd:]) == 0
+            sl = st[4:].view(M, cap, 2)[:, : (2 * Hp + 127) // 128]
+            assert relerr(sl[..., 0].sum(1), hid.double().sum(1)) < 1e-5
+        assert torch.equal(hid, ref_h) and torch.equal(st, ref_hs), f"variant {v}: folded w1|w2 epilogue depends on the tile variant"
+    with pytest.raises(RuntimeError, match="different buffers"):
+        lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS_LN, 16, ref_a, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
+                 st2, cap2, st2, cap2, c1, C, eps, None, 0, S())
+
+
+@pytest.mark.parametrize("name,dt,tdt", DTYPES)
+def test_conv3x3_implicit_gemm_equals_im2col_gemm(name, dt, tdt):
+    """toc3d_conv3x3_nhwc (CPFPN's 3x3 conv, necks/cp_fpn.py:124-133, as an implicit GEMM) == toc3d_im2col_3x3 + toc3d_linear bit for bit
+    (same K order), for every tile variant, and == F.conv2d on the same rounded operands; ragged M (tiles past the last pixel)."""
+    V, h, w, C, Co = 3, 20, 50, 128, 256
+    x = rnd(V, h, w, C, seed=3)
+    Wc, b = rnd(Co, C, 3, 3, seed=4, scale=(9 * C) ** -0.5), rnd(Co, seed=5).to(DEV)
+    M = V * h * w
+    x_act = x.to(DEV).to(tdt).contiguous()
+    wp = pack(Wc.permute(0, 2, 3, 1).reshape(Co, 9 * C), dt, tdt)          # (Cout, ky, kx, Cin): toc3d_im2col_3x3's column order
+    col = torch.zeros(M, 9 * C, dtype=tdt, device=DEV)
+    lib.call("toc3d_im2col_3x3", dt, x_act.float(), col, 9 * C, V, h, w, C, S())
+    ref = torch.zeros(M, Co, device=DEV)
+    lib.call("toc3d_linear_ex", dt, lib.EPI_RESIDUAL, 16, col, 9 * C, wp, 9 * C, b, ref, Co, None, 0, 0, None, None, M, Co, 9 * C, 0, S())
+    conv = torch.nn.functional.conv2d(x_act.double().permute(0, 3, 1, 2), Wc.to(DEV).to(tdt).double(), b.double(), padding=1)
+    assert relerr(ref, conv.permute(0, 2, 3, 1).reshape(M, Co)) < (1e-5 if dt == lib.F32 else 1e-5)      # f32 accumulation of exact products
+    zeros = torch.zeros(256, dtype=torch.uint8, device=DEV)
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 26, 28, 33, 45, 49, 51, 110, 114, 126):
+        out = torch.full((M, Co), 7.0, device=DEV)
+        lib.call("toc3d_conv3x3_nhwc", dt, v, x_act, C, wp, 9 * C, b, out, Co, V, h, w, Co, zeros, S())
+        assert torch.equal(out, ref), f"variant {v}"
+    if dt == lib.BF16:
+        with pytest.raises(RuntimeError, match="cannot serve"):
+            lib.call("toc3d_conv3x3_nhwc", dt, 60, x_act, C, wp, 9 * C, b, out, Co, V, h, w, Co, zeros, S())
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        lib.call("toc3d_conv3x3_nhwc", dt, 16, x_act, 96, wp, 9 * C, b, out, Co, V, h, w, Co, zeros, S())

@@ -162,7 +162,7 @@ _flush = None                   # 256 MB scratch shared by all models: evicts L2
 _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 163),
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
-def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=(None, 0, None, 0, 0.0)):
+def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED):
     """toc3d_linear_fused with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
     real operands the first time the shape is seen (never while a launch plan is being recorded: shapes are warmed up eagerly).
     ``self`` = the owner of the table: anything with ``_tuned`` (dict), ``autotune`` (bool) and ``_dt`` (the backbones, the neck).
@@ -179,15 +179,15 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
             return
         if self.autotune and not torch.cuda.is_current_stream_capturing():
             o = out
-            if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN):   # in-place residual add: tune into scratch
+            if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # in-place residual add: tune into scratch
                 o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
             rep_s = torch.empty_like(rep_out) if rep_out is not None else None
             cands = _VARIANTS[self._dt]
-            if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS):
+            if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):
                 cands = [v for v in cands if v not in (33, 45, 145)]   # wave slabs that are not whole (w1, w2) 32-column groups
-            if epi == lib.EPI_SWIGLU_STATS:                            # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
+            if epi in (lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):  # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
                 cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47, 60, 63)]
-            if epi == lib.EPI_RESIDUAL_LN:
+            if epi in (lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # the phased tiles do not carry the folded-LayerNorm epilogues
                 cands = [v for v in cands if v % 100 not in (60, 63)]
             # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
             # L2 / Infinity Cache): time single launches behind a cache-sized memset, not a warm back-to-back loop, or the
@@ -197,7 +197,10 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
 
             def cold_time(v, reps):
                 args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, *fused, s)
-                lib.call("toc3d_linear_fused", *args)
+                try:
+                    lib.call("toc3d_linear_fused", *args)
+                except RuntimeError:                             # a tile variant that cannot serve this epilogue
+                    return float("inf")
                 ts = []
                 for _ in range(reps):
                     _flush.zero_()
@@ -270,8 +273,15 @@ class _BackboneBase(nn.Module):
         # bf16 path: SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused): no LayerNorm pass over
         # the hidden activations.  The strict-parity fp32 path keeps the reference's sequence (eva_vit.py:47-49).
         self.fold_ffn_ln = precision == "bf16" and os.environ.get("TOC3D_FOLD_LN", "1") != "0"
-        # software prefetch of the next block's packed weights on a side lane (toc3d_prefetch): workgroups per weight matrix, 0 = off
-        self.prefetch_weights = int(os.environ.get("TOC3D_PREFETCH", "0"))
+        # ... and norm2 folded across the attention-projection -> w1|w2 boundary the same way (EPI_RESIDUAL_STATS -> EPI_SWIGLU_STATS_LN): the
+        # projection's residual epilogue also leaves the updated rows in bf16 with their statistics, so the LayerNorm launch in front of the MLP goes
+        # Measured neutral (same-box A/B 191.1 vs 189.2 frames/s: the 6-8 us LayerNorm launches it removes cost what the extra epilogue phases of the
+        # latency-bound N = 1024 projection GEMMs cost), so it is OFF by default; TOC3D_FOLD_N2=1 enables it (7 launches per accelerated block).
+        self.fold_norm2 = self.fold_ffn_ln and os.environ.get("TOC3D_FOLD_N2", "0") != "0"
+        # software prefetch of the weights of the GEMMs that follow each attention launch, by extra workgroups of that launch
+        # (toc3d_window_attention_pf): number of prefetch workgroups, 0 = off
+        # (same-box A/B r02: 190.8 frames/s without, 193.8 / 193.4 / 192.8 / 191.6 with 128 / 256 / 512 / 1024 workgroups)
+        self.prefetch_weights = int(os.environ.get("TOC3D_PREFETCH", "192" if precision == "bf16" else "0"))
         # "plan": the frame's launch sequence is recorded once per (input shape, config) and replayed from C with one call per frame
         # (toc3d_plan_run, HIP streams + events); "graph": the same recording as an explicitly built hipGraph; "eager": every launch
         # issued from Python (what the first forward of a shape always does: it autotunes, and it is what gets recorded next).
@@ -340,6 +350,10 @@ class _BackboneBase(nn.Module):
             lib.call("toc3d_pack_swiglu", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias),
                      self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
             p["w12"], p["b12"] = w12, b12
+            if self.fold_norm2:                                   # gamma2-scaled interleaved weights + (c1, c2) in packed column order; replaces w12 / b12
+                p["c1_12"], p["c2_12"] = torch.empty(2 * Hp, device=dev), torch.empty(2 * Hp, device=dev)
+                lib.call("toc3d_pack_swiglu_lnfold", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias), self._f32(m.w2.bias),
+                         self._f32(blk.norm2.weight), self._f32(blk.norm2.bias), Hd, C, w12, p["c1_12"], p["c2_12"], Hp, C, lib.stream_ptr())
             if self.fold_ffn_ln:
                 N3, K3 = m.w3.weight.shape
                 w3f = torch.empty(_round_up(N3, 128), Hp, dtype=self._tdt, device=dev)
@@ -430,11 +444,13 @@ class _BackboneBase(nn.Module):
         if self.fold_ffn_ln:                                      # per-row partial (sum, sum^2) slots of the hidden units: header + [R, cap, 2]
             plan["stats_cap"] = _round_up(-(-2 * Hp // 128), 2)
             plan["stats"] = torch.zeros(4 + R * plan["stats_cap"] * 2, dtype=torch.float32, device=dev)
+            plan["stats2_cap"] = C // 64                          # norm2 fold: one slot per 64 residual-stream columns
+            plan["stats2"] = torch.zeros(4 + R * plan["stats2_cap"] * 2, dtype=torch.float32, device=dev)
         plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
-    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=(None, 0, None, 0, 0.0)):
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED):
         tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused)
 
     def save_packed(self, path):
@@ -491,15 +507,29 @@ class _BackboneBase(nn.Module):
         """One frame in the configured launch mode (toc3d_amd/plan.py: eager / recorded plan / explicit hipGraph)."""
         run_frame(master.setdefault("launch", {}).setdefault(variant, {}), self.launch_mode, n_lanes, frame_fn, self._stream_pool)
 
-    def _prefetch_block(self, ex, lane, pace_lane, P, i):
-        """Beside block i - 1 .. i: pull block i's four GEMM weight matrices (25 MB in bf16) towards the chip.  ``lane`` starts each
-        prefetch behind everything issued so far on ``pace_lane`` (= the end of the previous block), so it runs one block ahead."""
-        if not self.prefetch_weights or i >= self.depth:
+    def _attention(self, P, i, *args):
+        """toc3d_window_attention for block i; with ``prefetch_weights`` the launch also pulls the weights of the GEMMs that follow it
+        (this block's proj / w1|w2 / w3, the next block's q|k|v) towards the chip (toc3d_window_attention_pf)."""
+        s = lib.stream_ptr()
+        if not self.prefetch_weights:
+            lib.call("toc3d_window_attention", *args, s)
             return
+        import ctypes
         bp = P["blocks"][i]
-        ex.wait(lane, pace_lane)
-        with ex.lane(lane):
-            lib.prefetch([bp["wqkv"], bp["wproj"], bp["w12"], bp["w3"]], self.prefetch_weights, lib.stream_ptr())
+        ts = [bp["wproj"], bp["w12"], bp["w3"]] + ([P["blocks"][i + 1]["wqkv"]] if i + 1 < self.depth else [])
+        ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        nb = (ctypes.c_int64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
+        lib.call("toc3d_window_attention_pf", *args, len(ts), ptrs, nb, self.prefetch_weights, s)
+
+    def _proj(self, bp, plan, rows, res, rep_out, rep_index):
+        """attn.proj + residual add (eva_vit.py:115,262 / toc3d_eva_vit.py:514,379) in place on ``res`` f32 [rows, C]; with norm2 folded the
+        epilogue also leaves the updated rows in bf16 (plan["a"]) and their statistics (plan["stats2"]) for the w1|w2 GEMM."""
+        C = self.embed_dim
+        if self.fold_norm2:
+            self._linear(lib.EPI_RESIDUAL_STATS, plan["att"], C, bp["wproj"], C, bp["bproj"], res, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
+                         fused=(plan["stats2"], plan["stats2_cap"], None, 0, None, 0, 0.0, plan["a"], C))
+        else:
+            self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], res, C, res, C, 0, rep_out, rep_index, rows, C, C, 0)
 
     def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
         """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
@@ -507,15 +537,21 @@ class _BackboneBase(nn.Module):
         C, Hd = self.embed_dim, self.hidden_dim
         Hp = plan["hid"].shape[1]
         dt = self._dt
-        lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
         if self.fold_ffn_ln:
-            # ffn_ln folded: the SwiGLU GEMM leaves per-row (sum, sum^2) slots, the w3 GEMM (gamma-scaled weights) normalises in its epilogue
+            # ffn_ln folded: the SwiGLU GEMM leaves per-row (sum, sum^2) slots, the w3 GEMM (gamma-scaled weights) normalises in its epilogue;
+            # norm2 folded the same way: plan["a"] / plan["stats2"] were left by the projection GEMM (_proj), no LayerNorm launch here
             st, cap = plan["stats"], plan["stats_cap"]
-            self._linear(lib.EPI_SWIGLU_STATS, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                         fused=(st, cap, None, 0, 0.0))
+            if self.fold_norm2:
+                self._linear(lib.EPI_SWIGLU_STATS_LN, plan["a"], C, bp["w12"], C, bp["c2_12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
+                             fused=(st, cap, plan["stats2"], plan["stats2_cap"], bp["c1_12"], C, self.LN_EPS, None, 0))
+            else:
+                lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
+                self._linear(lib.EPI_SWIGLU_STATS, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
+                             fused=(st, cap, None, 0, None, 0, 0.0, None, 0))
             self._linear(lib.EPI_RESIDUAL_LN, plan["hid"], Hp, bp["w3"], bp["w3"].shape[1], bp["c2"], res, C, res, C, 0,
-                         rep_out, rep_index, rows, C, Hp, 0, fused=(st, cap, bp["c1"], Hd, self.LN_EPS))
+                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, st, cap, bp["c1"], Hd, self.LN_EPS, None, 0))
             return
+        lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
         self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)
         lib.call("toc3d_layernorm_act", dt, plan["hid"], Hp, bp["lnf_w"], bp["lnf_b"], self.LN_EPS, plan["hln"], Hp, rows, Hd, s)
         self._linear(lib.EPI_RESIDUAL, plan["hln"], Hp, bp["w3"], bp["w3"].shape[1], bp["b3"], res, C, res, C, 0,
@@ -530,9 +566,9 @@ class _BackboneBase(nn.Module):
         dm = plan["dense"][self._block_side(i)]
         lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0)
-        lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None,
-                 dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], bp["v_bias"], 64 ** -0.5, s)
-        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], x, C, x, C, 0, None, None, M, C, C, 0)
+        self._attention(P, i, dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None,
+                        dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], bp["v_bias"], 64 ** -0.5)
+        self._proj(bp, plan, M, x, None, None)
         self._mlp(bp, plan, M, x, None, None)
 
     # -- view groups: independent views processed concurrently on separate HIP streams ----------
@@ -926,11 +962,10 @@ class ToC3DEVAViT(_BackboneBase):
             lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, s)
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, rows, 3 * C, C, 0)
-        lib.call("toc3d_window_attention", dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"],
-                 None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], None, 64 ** -0.5, s)
+        self._attention(P, i, dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"],
+                        None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], None, 64 ** -0.5)
         ra, rb = (plan["rep3"], plan["rep4"]) if carry_in else (plan["rep1"], plan["rep2"])
-        self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], slow, C, slow, C, 0, ra, sel["rep_index"],
-                     rows, C, C, 0)
+        self._proj(bp, plan, rows, slow, ra, sel["rep_index"])
         self._mlp(bp, plan, rows, slow, rb, sel["rep_index"])
         if not carry_out:
             lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"],
@@ -1008,7 +1043,7 @@ class ToC3DEVAViT(_BackboneBase):
             self._stem_im2col(gp, x[gp["v0"]:gp["v0"] + gp["nv"]])
 
         # ---- the frame: lanes 0..G-1 = view groups, G..2G-1 = their side lanes, 2G = query-side scorer prep -----------------------
-        prep_lane, pf_lane = 2 * G, 2 * G + 1
+        prep_lane = 2 * G
 
         def frame(ex):
             for gp in groups:
@@ -1028,7 +1063,6 @@ class ToC3DEVAViT(_BackboneBase):
                 cin = pending
                 cout = self._accelerated(i) and self._carries(i) and not cin
                 pending = cout
-                self._prefetch_block(ex, pf_lane, 0, P, i + 1)    # block i + 1's weights travel while block i computes
                 for g, gp in enumerate(groups):
                     with ex.lane(g):
                         if i in self.pruning_loc:
@@ -1051,13 +1085,13 @@ class ToC3DEVAViT(_BackboneBase):
                         for st_ in range(ns):
                             lib.call("toc3d_copy_bytes", plan["mask"][st_][v0 * T:(v0 + nv) * T], gp["mask"][st_], nv * T * 4, lib.stream_ptr())
                             lib.call("toc3d_copy_bytes", plan["order"][st_][v0:v0 + nv], gp["order"][st_], nv * T * 8, lib.stream_ptr())
-            for l in range(1, 2 * G + 2):
+            for l in range(1, 2 * G + 1):
                 ex.wait(0, l)
 
         if forced is not None or self.block_hook is not None:
-            frame(EagerExec(2 * G + 2, self._stream_pool))
+            frame(EagerExec(2 * G + 1, self._stream_pool))
         else:
-            self._run_frame(plan, 2 * G + 2, frame, variant=(prev, ts_key))
+            self._run_frame(plan, 2 * G + 1, frame, variant=(prev, ts_key))
         h, w = plan["h"], plan["w"]
         cl = (lambda t: t) if self.alias_outputs else (lambda t: t.clone())
         masks = [cl(plan["mask"][s]).view(V, h, w, 1) for s in range(ns)]

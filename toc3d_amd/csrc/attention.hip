@@ -31,7 +31,32 @@ struct AttnArgs {
     int L;                                       // RoPE table side: tables are [L*L, 64]
     const float* cosT; const float* sinT; const float* v_bias;
     float scale;
+    // weight prefetch riding on this launch (toc3d_window_attention_pf): the first pf_rows rows of the grid's window dimension stream these
+    // buffers through the caches and discard them; nwin = number of real windows (the grid is pf_rows + nwin in its window dimension)
+    const f32x4* pf_ptr[4]; int64_t pf_n16[4]; int nwin, pf_rows;
 };
+
+// The attention kernels are latency-bound and leave HBM idle, and the GEMMs that follow them start on weights that were last touched a frame
+// ago (0.6 GB of bf16 weights cycle through a 256 MB Infinity Cache: 0.22 ms of a 5.7 ms frame, profiles/r02_where_time_goes.txt).  Extra
+// workgroups of the attention launch therefore read the weights of the next GEMMs (this block's proj / w1|w2 / w3, the next block's q|k|v) and
+// throw the values away -- no extra launch and no cross-stream edge (the standalone prefetch lane lost 3-5 % to exactly those).
+TOC3D_DEV void prefetch_weights(const AttnArgs& a, int wg, int nwg, int tid) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int sgm = 0; sgm < 4; ++sgm) {
+        const f32x4* __restrict__ p = a.pf_ptr[sgm];
+        const int64_t n16 = a.pf_n16[sgm];
+        const int64_t stride = (int64_t)nwg * 256;
+        int64_t i = (int64_t)wg * 256 + tid;
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            const f32x4 x0 = p[i], x1 = p[i + stride], x2 = p[i + 2 * stride], x3 = p[i + 3 * stride];
+            acc += (x0 + x1) + (x2 + x3);
+        }
+        for (; i < n16; i += stride) acc += p[i];
+    }
+    // never true for finite weights; keeps the loads alive without writing anything anyone reads
+    if (acc[0] != acc[0] && acc[1] != acc[1] && acc[2] != acc[2] && acc[3] != acc[3]) reinterpret_cast<volatile float*>(a.out)[0] = 0.f;
+}
 
 template <typename T> struct Pad;                // LDS row padding (elements) keeping 16-byte alignment
 template <> struct Pad<bf16_t> { static constexpr int ld = HD + 8; };
@@ -128,7 +153,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     float* s_sin = s_cos + 2 * a.L * 16;
     const int L = a.L;
 
-    const int qt = blockIdx.x, head = blockIdx.y, win = blockIdx.z;
+    const int qt = blockIdx.x, head = blockIdx.y, win = (int)blockIdx.z - a.pf_rows;
+    if (win < 0) {                               // prefetch rows come FIRST in the grid (dispatched with the first attention workgroups, not behind the last)
+        prefetch_weights(a, (blockIdx.z * gridDim.y + head) * gridDim.x + qt, a.pf_rows * gridDim.y * gridDim.x, threadIdx.x);
+        return;
+    }
     const int n = a.count[win];                  // queries: the window's compact rows
     if (qt * QB >= n) return;                    // uniform for the workgroup
     const int nkeys = a.count_k ? a.count_k[win] : n;   // keys: the same rows + virtual kept-pad keys (rows[j] < 0)
@@ -334,7 +363,11 @@ template <typename T, int MAXSUB>
 __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     constexpr int LD = Pad<T>::ld;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int head = blockIdx.x, win = blockIdx.y;
+    const int head = blockIdx.x, win = (int)blockIdx.y - a.pf_rows;
+    if (win < 0) {                               // prefetch rows come FIRST in the grid (dispatched with the first attention workgroups, not behind the last)
+        prefetch_weights(a, blockIdx.y * gridDim.x + head, a.pf_rows * gridDim.x, threadIdx.x);
+        return;
+    }
     const int n = a.count[win];
     if (n == 0) return;
     const int nkeys = a.count_k ? a.count_k[win] : n;
@@ -528,7 +561,7 @@ template <typename T, int MAXSUB>
 void launch_small(const AttnArgs& a, size_t lds, int64_t num_heads, int64_t nwin, hipStream_t s) {
     static Toc3dLdsAttr attr;                    // per function instantiation, per device
     attr.ensure(reinterpret_cast<const void*>(&attn_small_kernel<T, MAXSUB>), 96 * 1024);
-    toc3d_launch((attn_small_kernel<T, MAXSUB>), dim3((unsigned)num_heads, (unsigned)nwin), dim3(256), lds, s, a);
+    toc3d_launch((attn_small_kernel<T, MAXSUB>), dim3((unsigned)num_heads, (unsigned)(nwin + a.pf_rows)), dim3(256), lds, s, a);
 }
 
 template <typename T>
@@ -545,10 +578,10 @@ void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_
             return;
         }
     }
-    // larger windows: flash-style kernel, 64-query workgroups (measured faster than 128-query ones on every window
-    // size of this model: more, fuller workgroups beat the halved K/V staging)
+    // larger windows: flash-style kernel, 64-query workgroups (measured faster than or equal to 128-query ones on every window size of this
+    // model, again in round 2 with P in registers: 256 keys 58.1 vs 55.9 us, 400 keys 60.9 vs 67.8 us, frames/s equal)
     const size_t lds = (size_t)(KT + HD) * Pad<T>::ld * sizeof(T) + (size_t)((a.stride + 3) & ~3) * 8 + (size_t)a.L * 16 * 4 * 4;
-    dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)nwin);
+    dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)(nwin + a.pf_rows));
     toc3d_launch((attn_kernel<T, 1>), grid, dim3(256), lds, s, a);
 }
 
@@ -577,11 +610,12 @@ __global__ void window_map_dense_kernel(int V, int h, int w, int L, int32_t* row
 
 extern "C" {
 
-int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
-                           const int32_t* slots, const int32_t* count, const int32_t* count_k, const int32_t* npad,
-                           const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
-                           const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
-                           toc3d_stream_t stream) {
+int toc3d_window_attention_pf(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
+                              const int32_t* slots, const int32_t* count, const int32_t* count_k, const int32_t* npad,
+                              const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
+                              const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
+                              int64_t n_prefetch, const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int64_t prefetch_workgroups,
+                              toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_window_attention: bad dtype %d", dtype);
     TOC3D_REQUIRE(qkv && out && rows && slots && count && rope_cos && rope_sin, "toc3d_window_attention: null buffer");
     TOC3D_REQUIRE(!npad || v_bias, "toc3d_window_attention: npad given without v_bias");
@@ -593,13 +627,37 @@ int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out,
     const int esz = dtype == TOC3D_BF16 ? 2 : 4;
     TOC3D_REQUIRE((ldqkv * esz) % 16 == 0 && ((uintptr_t)qkv % 16) == 0, "toc3d_window_attention: qkv rows must be 16-byte aligned");
     TOC3D_REQUIRE(ldo % 4 == 0 && ((uintptr_t)out % 16) == 0, "toc3d_window_attention: out must be 16-byte aligned with ldo a multiple of 4");
-    TOC3D_REQUIRE(num_heads <= 65535 && nwin <= 65535, "toc3d_window_attention: grid too large");
+    TOC3D_REQUIRE(num_heads <= 65535 && nwin <= 65535 - 128, "toc3d_window_attention: grid too large");
     if (nwin == 0 || max_count == 0) return TOC3D_OK;
-    AttnArgs a{qkv, ldqkv, out, ldo, rows, slots, count, count_k, npad, pad_qkv, stride, (int)C, (int)rope_side, rope_cos, rope_sin, v_bias, scale};
+    TOC3D_REQUIRE(n_prefetch >= 0 && n_prefetch <= 4 && (n_prefetch == 0 || (prefetch_ptrs && prefetch_bytes)), "toc3d_window_attention: at most 4 prefetch buffers (host arrays)");
+    AttnArgs a{qkv, ldqkv, out, ldo, rows, slots, count, count_k, npad, pad_qkv, stride, (int)C, (int)rope_side, rope_cos, rope_sin, v_bias, scale,
+               {nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, (int)nwin, 0};
+    int64_t pf_total = 0;
+    for (int64_t i = 0; i < n_prefetch; ++i) {
+        TOC3D_REQUIRE(prefetch_bytes[i] >= 0 && ((uintptr_t)prefetch_ptrs[i] % 16) == 0, "toc3d_window_attention: prefetch buffers must be 16-byte aligned");
+        a.pf_ptr[i] = (const f32x4*)prefetch_ptrs[i];
+        a.pf_n16[i] = prefetch_bytes[i] / 16;
+        pf_total += a.pf_n16[i];
+    }
+    if (pf_total > 0) {
+        // prefetch workgroups come in rows of the grid's window dimension: at least num_heads workgroups per row
+        const int64_t per_row = num_heads;
+        int64_t rows_pf = ((prefetch_workgroups > 0 ? prefetch_workgroups : 256) + per_row - 1) / per_row;
+        a.pf_rows = (int)(rows_pf < 1 ? 1 : (rows_pf > 128 ? 128 : rows_pf));
+    }
     if (dtype == TOC3D_BF16) launch_attn<bf16_t>(a, max_count, num_heads, nwin, as_stream(stream));
     else launch_attn<float>(a, max_count, num_heads, nwin, as_stream(stream));
     TOC3D_LAUNCH_CHECK("toc3d_window_attention");
     return TOC3D_OK;
+}
+
+int toc3d_window_attention(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows,
+                           const int32_t* slots, const int32_t* count, const int32_t* count_k, const int32_t* npad,
+                           const void* pad_qkv, int64_t stride, int64_t nwin, int64_t max_count, int64_t num_heads,
+                           const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
+                           toc3d_stream_t stream) {
+    return toc3d_window_attention_pf(dtype, qkv, ldqkv, out, ldo, rows, slots, count, count_k, npad, pad_qkv, stride, nwin, max_count, num_heads,
+                                     rope_cos, rope_sin, rope_side, v_bias, scale, 0, nullptr, nullptr, 0, stream);
 }
 
 int toc3d_window_map_dense(int64_t V, int64_t h, int64_t w, int64_t L, int32_t* rows, int32_t* slots, int32_t* count,

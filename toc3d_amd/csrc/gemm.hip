@@ -33,13 +33,21 @@ struct GemmArgs {
     int M, N, K, n_valid;
     int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
     int vec;                                             // epilogue may use 4-element vector accesses (alignment checked on the host)
-    // LayerNorm folded across a GEMM boundary (TOC3D_EPI_SWIGLU_STATS writes, TOC3D_EPI_RESIDUAL_LN reads; include/toc3d.h)
-    float* stats; int stats_cap;                         // int32 header [4] + f32 [M, stats_cap, 2]
-    const float* c1; float ln_inv_n, ln_eps;
+    // LayerNorms folded across GEMM boundaries (include/toc3d.h, toc3d_linear_fused): statistics this launch leaves / consumes
+    float* stats; int stats_cap;                         // written:  int32 header [4] + f32 [M, stats_cap, 2]
+    const float* stats_in; int stats_in_cap;             // consumed: same layout, written by the launch that produced A
+    const float* c1; float ln_inv_n, ln_eps;             // consumed side: column sums of the gamma-scaled W, 1 / (normalised width), eps
+    void* out_act; int64_t ld_act;                       // EPI_RESIDUAL_STATS: act-dtype copy of the f32 output rows (the next GEMM's A operand)
+    // EPI_CONV3X3: A is an NHWC act tensor [V, conv_h, conv_w, lda]; the kernel gathers the 3x3 (pad 1) patches itself, K = 9 * lda in (ky, kx, c) order
+    int conv_h, conv_w; const void* zeros;               // zeros: >= 128 bytes of zeros (the out-of-image taps)
 };
 
-constexpr bool epi_is_swiglu(int epi) { return epi == TOC3D_EPI_SWIGLU || epi == TOC3D_EPI_SWIGLU_STATS; }
-constexpr bool epi_is_residual(int epi) { return epi == TOC3D_EPI_RESIDUAL || epi == TOC3D_EPI_RESIDUAL_LN; }
+constexpr bool epi_is_swiglu(int epi) { return epi == TOC3D_EPI_SWIGLU || epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN; }
+constexpr bool epi_is_residual(int epi) { return epi == TOC3D_EPI_RESIDUAL || epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_RESIDUAL_STATS || epi == TOC3D_EPI_CONV3X3; }
+constexpr bool epi_ln_in(int epi) { return epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_SWIGLU_STATS_LN; }        // LayerNorm of the A rows folded in
+constexpr bool epi_stats_out(int epi) { return epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN || epi == TOC3D_EPI_RESIDUAL_STATS; }
+// statistics groups per wave-tile row: one per 32 packed columns (SwiGLU) or per 16 output columns (residual)
+constexpr int epi_stat_groups(int epi, int NT) { return epi_is_swiglu(epi) ? (NT / 2 > 0 ? NT / 2 : 1) : NT; }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -83,7 +91,12 @@ TOC3D_DEV Frag<float> lds_frag(const char* tile, int r, int s, int g, float) {
 }
 
 TOC3D_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-TOC3D_DEV float silu(float x) { return x / (1.0f + expf(-x)); }
+// SiLU of the SwiGLU epilogue.  The precise expf + IEEE division are ~35 VALU instructions per element, 16 elements per lane in the
+// epilogue of the frame's largest GEMM (w1|w2); the bf16 path rounds the product to 8 bits anyway, so it takes the hardware exp2 / rcp
+// (v_exp_f32, v_rcp_f32: ~1 ulp) -- the strict-parity f32 instantiation keeps the precise forms.
+template <typename T> TOC3D_DEV float silu(float x);
+template <> TOC3D_DEV float silu<float>(float x) { return x / (1.0f + expf(-x)); }
+template <> TOC3D_DEV float silu<bf16_t>(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int N> TOC3D_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -110,17 +123,21 @@ TOC3D_DEV void lds_barrier() {
 // with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
 // .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
 // alignment / leading dims) enables the vector path. ----
-// EPI_SWIGLU_STATS: gs / gq [MT][NT / 2] receive, per row tile i and 32-column group jp, this lane's share of (sum h, sum h^2) over the
-// ROUNDED hidden units it wrote (zero for rows / columns outside the matrix); the caller completes the sums.
+// Statistics-writing epilogues: gs / gq [MT * G] (G = epi_stat_groups) receive, per row tile i and column group, this lane's share of
+// (sum, sum of squares) over the ROUNDED act-dtype values it wrote (zero for rows / columns outside the matrix); the caller completes the sums.
+// LayerNorm-consuming epilogues: lnrow = (mean, rstd) per tile row, prepared in LDS by the kernel.
 template <typename T, int EPI, int MT, int NT>
-TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, int col0, int r16, int g, float (*gs)[NT / 2 > 0 ? NT / 2 : 1] = nullptr,
-                             float (*gq)[NT / 2 > 0 ? NT / 2 : 1] = nullptr, const f32x2* lnrow = nullptr) {
+TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, int col0, int r16, int g, float* gs = nullptr,
+                             float* gq = nullptr, const f32x2* lnrow = nullptr) {
+    constexpr int G = epi_stat_groups(EPI, NT);
     if (epi_is_swiglu(EPI)) {
         // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
         T* out = reinterpret_cast<T*>(a.out);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = row0 + i * 16 + r16;
+            float mu = 0.f, rs = 1.f;
+            if (epi_ln_in(EPI)) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
 #pragma unroll
             for (int jp = 0; jp < NT / 2; ++jp) {
                 const int pc = col0 + jp * 32 + g * 4;    // packed col of the w1 half, first of 4
@@ -130,9 +147,16 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                     T hs[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float x1 = acc[i][2 * jp][r] + a.bias[pc + r], x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
-                        hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu(x1) * x2 : 0.f);
-                        if (EPI == TOC3D_EPI_SWIGLU_STATS) {
+                        float x1, x2;
+                        if (epi_ln_in(EPI)) {               // bias = c2 (beta . W + b), c1 = column sums of the gamma-scaled packed weights
+                            x1 = rs * (acc[i][2 * jp][r] - mu * a.c1[pc + r]) + a.bias[pc + r];
+                            x2 = rs * (acc[i][2 * jp + 1][r] - mu * a.c1[pc + 16 + r]) + a.bias[pc + 16 + r];
+                        } else {
+                            x1 = acc[i][2 * jp][r] + a.bias[pc + r];
+                            x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
+                        }
+                        hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu<T>(x1) * x2 : 0.f);
+                        if (epi_stats_out(EPI)) {
                             const float hv = from_act(hs[r]);       // what the next GEMM multiplies: the rounded value
                             ssum += hv;
                             sq = __builtin_fmaf(hv, hv, sq);
@@ -142,13 +166,17 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                     if (a.vec) store4(dst, hs);
                     else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
                 }
-                if (EPI == TOC3D_EPI_SWIGLU_STATS) { gs[i][jp] = ssum; gq[i][jp] = sq; }
+                if (epi_stats_out(EPI)) { gs[i * G + jp] = ssum; gq[i * G + jp] = sq; }
             }
         }
         return;
     }
     float bcol[NT][4];
     float ccol[EPI == TOC3D_EPI_RESIDUAL_LN ? NT : 1][4];    // c1: column sums of the gamma-scaled weights
+    if (EPI == TOC3D_EPI_RESIDUAL_STATS) {
+#pragma unroll
+        for (int q = 0; q < MT * G; ++q) { gs[q] = 0.f; gq[q] = 0.f; }
+    }
     int nok[NT];                                         // valid columns among the lane's 4 (0..4)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -166,6 +194,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
         if (row >= a.M) continue;
         float mu = 0.f, rs = 1.f;                        // EPI_RESIDUAL_LN: (mean, rstd) of this A row, prepared in LDS by the kernel
         if (EPI == TOC3D_EPI_RESIDUAL_LN) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
+        (void)mu; (void)rs;
         if (epi_is_residual(EPI)) {
             // the modular residual row and the representative-row test cost an integer division / a load each: once per row
             const int rr = a.res_mod > 0 ? row % a.res_mod : row;
@@ -183,15 +212,37 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                     if (EPI == TOC3D_EPI_RESIDUAL_LN) raw[r] = rs * (acc[i][j][r] - mu * ccol[j][r]) + bcol[j][r];
                     else raw[r] = acc[i][j][r] + bcol[j][r];
                 }
+                float sum4[4] = {0.f, 0.f, 0.f, 0.f};
                 if (a.vec && nok[j] == 4) {
                     f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{rv[0] + raw[0], rv[1] + raw[1], rv[2] + raw[2], rv[3] + raw[3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum4[r] = rv[r] + raw[r];
+                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{sum4[0], sum4[1], sum4[2], sum4[3]};
                     if (reprow) *reinterpret_cast<f32x4*>(reprow + col) = f32x4{raw[0], raw[1], raw[2], raw[3]};
                 } else {
                     for (int r = 0; r < nok[j]; ++r) {
-                        orow[col + r] = (resrow ? resrow[col + r] : 0.f) + raw[r];
+                        sum4[r] = (resrow ? resrow[col + r] : 0.f) + raw[r];
+                        orow[col + r] = sum4[r];
                         if (reprow) reprow[col + r] = raw[r];
                     }
+                }
+                if (EPI == TOC3D_EPI_RESIDUAL_STATS) {
+                    // the updated residual-stream row also leaves in the act dtype (the next GEMM's A operand, its LayerNorm folded into that
+                    // GEMM) together with the sums of those rounded values
+                    T* arow = reinterpret_cast<T*>(a.out_act) + (int64_t)row * a.ld_act + col;
+                    T o4[4];
+                    float ssum = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o4[r] = to_act<T>(r < nok[j] ? sum4[r] : 0.f);
+                        const float hv = from_act(o4[r]);
+                        ssum += hv;
+                        sq = __builtin_fmaf(hv, hv, sq);
+                    }
+                    if (nok[j] == 4) store4(arow, o4);
+                    else for (int r = 0; r < nok[j]; ++r) arow[r] = o4[r];
+                    gs[i * G + j] = ssum;
+                    gq[i * G + j] = sq;
                 }
             }
         } else {
@@ -263,9 +314,40 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
 
     // W rows are padded to a multiple of 128 at pack time, A rows are clamped to M-1
     const int w_max = ((a.N + 127) / 128) * 128 - 1;
+    // EPI_CONV3X3 (necks/cp_fpn.py:124-133 as an implicit GEMM): the A tile of K-tile t is the (ky, kx) = tap t*BK / C neighbour of each
+    // row's pixel, channels (t*BK) % C ..; the 16-byte global_load_lds takes any per-lane source address, so the im2col matrix is never
+    // materialised -- out-of-image taps read a line of zeros.  Each thread's rows are fixed: their (y, x) are decoded once.
+    constexpr int LA = BM * (RB / 16) / NTHR;
+    int cv_m[EPI == TOC3D_EPI_CONV3X3 ? LA : 1], cv_yx[EPI == TOC3D_EPI_CONV3X3 ? LA : 1];
+    if constexpr (EPI == TOC3D_EPI_CONV3X3) {
+#pragma unroll
+        for (int t = 0; t < LA; ++t) {
+            const int r = (t * NTHR + wave * 64 + lane) / (RB / 16);
+            int m = m0 + r;
+            m = m < a.M ? m : a.M - 1;
+            cv_m[t] = m;
+            cv_yx[t] = (((m / a.conv_w) % a.conv_h) << 16) | (m % a.conv_w);
+        }
+    }
     auto request = [&](int t) {
         char* slot = smem + (t % STAGES) * STAGE_BYTES;
-        stage_tile<T, BM, RB, NTHR>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
+        if constexpr (EPI == TOC3D_EPI_CONV3X3) {
+            const int k0 = t * BK, C = (int)a.lda;
+            const int tap = k0 / C, c0 = k0 - tap * C;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+            for (int u = 0; u < LA; ++u) {
+                const int cidx = u * NTHR + wave * 64 + lane;
+                const int r = cidx / (RB / 16), pch = cidx % (RB / 16);
+                const int y2 = (cv_yx[u] >> 16) + dy, x2 = (cv_yx[u] & 0xffff) + dx;
+                const bool in = (unsigned)y2 < (unsigned)a.conv_h && (unsigned)x2 < (unsigned)a.conv_w;
+                const char* src = in ? reinterpret_cast<const char*>(A + (int64_t)(cv_m[u] + dy * a.conv_w + dx) * C + c0) : reinterpret_cast<const char*>(a.zeros);
+                src += (pch ^ swz<RB>(r)) << 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + (u * NTHR + wave * 64) * 16), 16, 0, 0);
+            }
+        } else {
+            stage_tile<T, BM, RB, NTHR>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
+        }
         stage_tile<T, BN, RB, NTHR>(W, a.ldw, n0, w_max, t * BK, slot + A_BYTES, wave, lane);
     };
     auto multiply = [&](int t) {
@@ -290,13 +372,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     // butterfly steps; f64.  The order is fixed: the bits do not depend on the tile variant that runs this kernel.
     f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
     auto ln_rows_prepare = [&]() {
-        const int nslots = *reinterpret_cast<const int*>(a.stats);
-        const f32x2* base = reinterpret_cast<const f32x2*>(a.stats + 4);
+        const int nslots = *reinterpret_cast<const int*>(a.stats_in);
+        const f32x2* base = reinterpret_cast<const f32x2*>(a.stats_in + 4);
         for (int w = tid; w < BM * 4; w += NTHR) {
             const int r = w >> 2, part = w & 3;
             int row = m0 + r;
             row = row < a.M ? row : a.M - 1;
-            const f32x2* sp = base + (int64_t)row * a.stats_cap;
+            const f32x2* sp = base + (int64_t)row * a.stats_in_cap;
             double s1 = 0.0, s2 = 0.0;
             for (int sl = part; sl < nslots; sl += 4) {
                 const f32x2 v = sp[sl];
@@ -316,7 +398,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
         for (int kt = 0; kt < nk; ++kt) {
             request(kt);
-            if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) { if (kt == 0) ln_rows_prepare(); }
+            if constexpr (epi_ln_in(EPI)) { if (kt == 0) ln_rows_prepare(); }
             wait_vmcnt<0>();
             tile_barrier();                              // every wave's pieces of tile kt have landed
             multiply(kt);
@@ -326,7 +408,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
             if (t < nk) request(t);
-        if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) ln_rows_prepare();
+        if constexpr (epi_ln_in(EPI)) ln_rows_prepare();
         for (int kt = 0; kt < nk; ++kt) {
             if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
             else wait_vmcnt<0>();                                                                   // pipeline tail
@@ -336,33 +418,36 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         }
     }
 
-    if constexpr (EPI == TOC3D_EPI_SWIGLU_STATS) {
-        // Row statistics of the written hidden units for the LayerNorm folded into the next GEMM (include/toc3d.h).  One slot per 128 packed
-        // columns, built in ONE fixed tree for every tile variant: lane -> 4 values in order; 32-column group = butterfly over the 4 lane
-        // groups; slot = (g0 + g1) + (g2 + g3) of its four groups, combined through LDS whatever wave computed them.
-        static_assert(BN % 128 == 0 && NT % 2 == 0, "EPI_SWIGLU_STATS needs N-tiles of whole 128-column slots");
-        constexpr int NG = NT / 2;                      // 32-column groups per wave
-        float gs[MT][NG], gq[MT][NG];
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq);
-        tile_barrier();                                  // every wave is done with the operand tiles (their reads fed MFMAs): LDS becomes the reduction scratch
+    if constexpr (epi_stats_out(EPI)) {
+        // Row statistics of the act-dtype values this launch wrote, for the LayerNorm folded into the next GEMM (include/toc3d.h).  A slot is
+        // 128 packed columns (SwiGLU: 64 hidden units) or 64 output columns (residual), i.e. always four column groups of the epilogue, and is
+        // built in ONE fixed tree for every tile variant: lane -> its 4 values in order; group = butterfly over the 4 lane groups;
+        // slot = (g0 + g1) + (g2 + g3), combined through LDS whatever wave computed the groups.
+        constexpr int G = epi_stat_groups(EPI, NT);      // groups per wave-tile row
+        constexpr int GW = epi_is_swiglu(EPI) ? 32 : 16; // columns per group
+        constexpr int SLOT = 4 * GW, GPT = BN / GW;      // columns per slot, groups per tile row
+        static_assert(BN % SLOT == 0 && (epi_is_swiglu(EPI) ? NT % 2 == 0 : true), "statistics need N-tiles of whole slots");
+        float gs[MT * G], gq[MT * G];
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq, lnrow + wm * TM);
+        tile_barrier();                                  // every wave is done with the operand tiles (their reads fed MFMAs) and with the row table
         f32x2* red = reinterpret_cast<f32x2*>(smem);     // [GPT][BM]
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int jp = 0; jp < NG; ++jp) {
-                const float s1 = g4_sum(gs[i][jp]), s2 = g4_sum(gq[i][jp]);
-                if (g == 0) red[(wn * NG + jp) * BM + wm * TM + i * 16 + r16] = f32x2{s1, s2};
+            for (int jp = 0; jp < G; ++jp) {
+                const float s1 = g4_sum(gs[i * G + jp]), s2 = g4_sum(gq[i * G + jp]);
+                if (g == 0) red[(wn * G + jp) * BM + wm * TM + i * 16 + r16] = f32x2{s1, s2};
             }
         lds_barrier();
         f32x2* data = reinterpret_cast<f32x2*>(a.stats + 4);
-        for (int w = tid; w < BM * (BN / 128); w += NTHR) {
+        for (int w = tid; w < BM * (GPT / 4); w += NTHR) {
             const int r = w % BM, sl = w / BM;
             const int row = m0 + r;
             if (row >= a.M) continue;
             const f32x2 v0 = red[(4 * sl) * BM + r], v1 = red[(4 * sl + 1) * BM + r], v2 = red[(4 * sl + 2) * BM + r], v3 = red[(4 * sl + 3) * BM + r];
-            data[(int64_t)row * a.stats_cap + n0 / 128 + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
+            data[(int64_t)row * a.stats_cap + n0 / SLOT + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
         }
-        if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + 127) / 128;
+        if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + SLOT - 1) / SLOT;
     } else if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) {
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM);
     } else {
@@ -530,15 +615,19 @@ thread_local bool g_bad_variant = false;               // variant cannot serve t
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
     // a wave must own whole (w1, w2) 32-column groups; the folded-LayerNorm statistics need N-tiles of whole 128-column slots; the fold is bf16 only
-    constexpr bool unsupported = (epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (EPI == TOC3D_EPI_SWIGLU_STATS && BN % 128 != 0) ||
-                                 (EPI >= TOC3D_EPI_SWIGLU_STATS && sizeof(T) != 2);
+    constexpr bool unsupported = (epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) ||
+                                 (EPI >= TOC3D_EPI_SWIGLU_STATS && EPI != TOC3D_EPI_CONV3X3 && sizeof(T) != 2);
     if constexpr (unsupported) {
         g_bad_variant = true;
     } else {
-        constexpr int lds = STAGES * (BM + BN) * RB + (EPI == TOC3D_EPI_RESIDUAL_LN ? BM * 8 : 0);   // + the (mean, rstd) row table
+        constexpr int lds = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);   // + the (mean, rstd) row table
         static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
         if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds);
-        if (a.K % (RB / (int)sizeof(T)) != 0) { launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s); return; }   // K-tile must divide K
+        if (a.K % (RB / (int)sizeof(T)) != 0 || (EPI == TOC3D_EPI_CONV3X3 && a.lda % (RB / (int)sizeof(T)) != 0)) {    // K-tile must divide K (conv: the channel count)
+            if (RB == 128) { g_bad_variant = true; return; }
+            launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s);
+            return;
+        }
         const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
         const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
         toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
@@ -547,7 +636,7 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 template <int EPI, int BM, int BN, int WM, int WN>
 void launch_phased(const GemmArgs& a, hipStream_t s) {
-    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || EPI >= TOC3D_EPI_SWIGLU_STATS) {   // the phased kernel does not carry the folded-LayerNorm epilogues
+    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || EPI >= TOC3D_EPI_SWIGLU_STATS) {   // the phased kernel carries neither the folded-LayerNorm epilogues nor the conv gather
         g_bad_variant = true;
     } else {
         constexpr int lds = 2 * (BM + BN) * 128;              // two K-tiles of 64 bf16
@@ -645,6 +734,9 @@ int launch_gemm(int epi, int variant, const GemmArgs& a, hipStream_t s) {
         case TOC3D_EPI_GELU: return launch_epi<T, TOC3D_EPI_GELU>(variant, a, s);
         case TOC3D_EPI_SWIGLU_STATS: return launch_epi<T, TOC3D_EPI_SWIGLU_STATS>(variant, a, s);
         case TOC3D_EPI_RESIDUAL_LN: return launch_epi<T, TOC3D_EPI_RESIDUAL_LN>(variant, a, s);
+        case TOC3D_EPI_RESIDUAL_STATS: return launch_epi<T, TOC3D_EPI_RESIDUAL_STATS>(variant, a, s);
+        case TOC3D_EPI_SWIGLU_STATS_LN: return launch_epi<T, TOC3D_EPI_SWIGLU_STATS_LN>(variant, a, s);
+        case TOC3D_EPI_CONV3X3: return launch_epi<T, TOC3D_EPI_CONV3X3>(variant, a, s);
         default: return TOC3D_ERR_ARG;
     }
 }
@@ -704,6 +796,36 @@ __global__ __launch_bounds__(256) void pack_lnfold_kernel(const float* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0 && n < N) { c1[n] = r1[0]; c2[n] = r2[0] + b3[n]; }
+}
+
+// norm2 folded into the w1|w2 GEMM: the interleaved SwiGLU weights scaled by gamma per input channel, c1 = row sums of the ROUNDED scaled
+// weights, c2 = beta . w + b, both in packed row order (toc3d_pack_swiglu_lnfold).  One workgroup per packed row.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_swiglu_lnfold_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ b1,
+                                                                 const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 int Hd, int K, T* __restrict__ out_w, float* __restrict__ c1, float* __restrict__ c2, int Kp) {
+    __shared__ float r1[256], r2[256];
+    const int pr = blockIdx.x;
+    const int unit = (pr >> 5) * 16 + (pr & 15);
+    const bool second = (pr & 16) != 0;
+    const float* w = (second ? w2 : w1) + (int64_t)unit * K;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = threadIdx.x; k < Kp; k += 256) {
+        T v = to_act<T>(0.f);
+        if (unit < Hd && k < K) {
+            v = to_act<T>(gamma[k] * w[k]);
+            s1 += from_act(v);
+            s2 = __builtin_fmaf(beta[k], w[k], s2);
+        }
+        out_w[(int64_t)pr * Kp + k] = v;
+    }
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { c1[pr] = r1[0]; c2[pr] = unit < Hd ? r2[0] + (second ? b2 : b1)[unit] : 0.f; }
 }
 
 // im2col for the k = s = patch conv: row m = (v, pr, pc), col kk = (ch, py, px) -- matches the
@@ -820,41 +942,59 @@ int toc3d_im2col_patches_u8(int dtype, const uint8_t* img, int64_t V, int64_t H,
 int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                       float* row_stats, int64_t stats_cap, const float* col_sums, int64_t ln_n, float ln_eps,
-                       toc3d_stream_t stream) {
+                       float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
+                       void* out_act, int64_t ld_act, toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && K > 0, "toc3d_linear: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     const int bk = 64;
     TOC3D_REQUIRE(K % bk == 0, "toc3d_linear: K=%lld must be a multiple of %d (pad at pack time)", (long long)K, bk);
-    TOC3D_REQUIRE(lda >= K && ldw >= K, "toc3d_linear: leading dims smaller than K");
+    TOC3D_REQUIRE((lda >= K || epilogue == TOC3D_EPI_CONV3X3) && ldw >= K, "toc3d_linear: leading dims smaller than K");
     TOC3D_REQUIRE((lda * (dtype == TOC3D_BF16 ? 2 : 4)) % 16 == 0 && (ldw * (dtype == TOC3D_BF16 ? 2 : 4)) % 16 == 0,
                   "toc3d_linear: rows must be 16-byte aligned");
     TOC3D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "toc3d_linear: A/W must be 16-byte aligned");
-    if (epilogue >= TOC3D_EPI_SWIGLU_STATS) {
-        TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear: the folded-LayerNorm epilogues are bf16 only");
-        TOC3D_REQUIRE(row_stats && ((uintptr_t)row_stats % 16) == 0 && stats_cap > 0, "toc3d_linear: epilogue %d needs a 16-byte aligned row_stats buffer", epilogue);
+    const bool e_stats_out = epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_SWIGLU_STATS_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS;
+    const bool e_ln_in = epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_SWIGLU_STATS_LN;
+    const bool e_swiglu = epilogue == TOC3D_EPI_SWIGLU || epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_SWIGLU_STATS_LN;
+    const bool e_residual = epilogue == TOC3D_EPI_RESIDUAL || epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS;
+    if (epilogue >= TOC3D_EPI_SWIGLU_STATS && epilogue != TOC3D_EPI_CONV3X3) TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear: the folded-LayerNorm epilogues are bf16 only");
+    if (e_stats_out) {
+        TOC3D_REQUIRE(stats_out && ((uintptr_t)stats_out % 16) == 0, "toc3d_linear: epilogue %d needs a 16-byte aligned stats_out buffer", epilogue);
+        const int64_t slot = e_swiglu ? 128 : 64;
+        TOC3D_REQUIRE(stats_out_cap >= (N + slot - 1) / slot, "toc3d_linear: stats_out_cap %lld < ceil(N / %lld)", (long long)stats_out_cap, (long long)slot);
     }
-    if (epilogue == TOC3D_EPI_SWIGLU_STATS) TOC3D_REQUIRE(stats_cap >= (N + 127) / 128, "toc3d_linear: stats_cap %lld < ceil(N / 128)", (long long)stats_cap);
-    if (epilogue == TOC3D_EPI_RESIDUAL_LN) TOC3D_REQUIRE(bias && col_sums && ln_n > 0, "toc3d_linear: EPI_RESIDUAL_LN needs bias (c2), col_sums (c1) and ln_n");
-    if (epilogue == TOC3D_EPI_SWIGLU || epilogue == TOC3D_EPI_SWIGLU_STATS) {
+    if (e_ln_in) {
+        TOC3D_REQUIRE(stats_in && ((uintptr_t)stats_in % 16) == 0 && stats_in_cap > 0, "toc3d_linear: epilogue %d needs a 16-byte aligned stats_in buffer", epilogue);
+        TOC3D_REQUIRE(bias && col_sums && ln_n > 0, "toc3d_linear: epilogue %d needs bias (c2), col_sums (c1) and ln_n", epilogue);
+        TOC3D_REQUIRE(stats_in != stats_out, "toc3d_linear: stats_in and stats_out must be different buffers");
+    }
+    if (epilogue == TOC3D_EPI_RESIDUAL_STATS)
+        TOC3D_REQUIRE(out_act && ld_act >= N && ((uintptr_t)out_act % 8) == 0 && ld_act % 4 == 0, "toc3d_linear: EPI_RESIDUAL_STATS needs out_act [M, ld_act >= N], 8-byte aligned rows");
+    if (e_swiglu) {
         TOC3D_REQUIRE(bias && N % 32 == 0 && n_valid > 0 && n_valid <= N / 2, "toc3d_linear: swiglu needs bias, N%%32==0, n_valid");
         TOC3D_REQUIRE(ldo >= N / 2, "toc3d_linear: swiglu ldo < N/2");
     } else {
         TOC3D_REQUIRE(ldo >= N, "toc3d_linear: ldo < N");
     }
-    if (epilogue == TOC3D_EPI_RESIDUAL || epilogue == TOC3D_EPI_RESIDUAL_LN) {
+    if (e_residual) {
         TOC3D_REQUIRE(!residual || ldr >= N, "toc3d_linear: ldr < N");
         TOC3D_REQUIRE(!rep_index || rep_out, "toc3d_linear: rep_index set without rep_out");
     }
     if (M == 0) return TOC3D_OK;
     // 4-wide epilogue accesses: every row start and column group must be 16-byte aligned in its own element size
-    const int64_t osz = (epilogue == TOC3D_EPI_RESIDUAL || epilogue == TOC3D_EPI_RESIDUAL_LN) ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
+    const int64_t osz = e_residual ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
     const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * osz) == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
                      (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0));
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0,
-               row_stats, (int)stats_cap, col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps};
+               stats_out, (int)stats_out_cap, stats_in, (int)stats_in_cap, col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
+               0, 0, nullptr};
+    if (epilogue == TOC3D_EPI_CONV3X3) {
+        // A = NHWC act tensor [V, h, w, lda]; ld_act carries h << 32 | w and out_act the zero line (toc3d_conv3x3_nhwc fills them in)
+        a.conv_h = (int)(ld_act >> 32); a.conv_w = (int)(ld_act & 0xffffffff); a.zeros = out_act;
+        TOC3D_REQUIRE(a.conv_h > 0 && a.conv_w > 0 && a.zeros && M % ((int64_t)a.conv_h * a.conv_w) == 0 && K == 9 * lda, "toc3d_linear: EPI_CONV3X3 goes through toc3d_conv3x3_nhwc");
+        a.out_act = nullptr; a.ld_act = 0;
+    }
     g_bad_variant = false;
     int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
@@ -863,13 +1003,21 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     return TOC3D_OK;
 }
 
+int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const void* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
+                       int64_t V, int64_t h, int64_t w, int64_t Cout, const void* zeros, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && W && out && zeros && V > 0 && h > 0 && w > 0 && h < 32768 && w < 65536, "toc3d_conv3x3_nhwc: bad arguments");
+    TOC3D_REQUIRE(C % 64 == 0, "toc3d_conv3x3_nhwc: the channel count must be a multiple of 64 (one K-tile never straddles two taps)");
+    return toc3d_linear_fused(dtype, TOC3D_EPI_CONV3X3, variant, x, C, W, ldw, bias, out, ldo, nullptr, 0, 0, nullptr, nullptr, V * h * w, Cout, 9 * C, 0,
+                              nullptr, 0, nullptr, 0, nullptr, 0, 0.f, const_cast<void*>(zeros), (h << 32) | w, stream);
+}
+
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                     void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                     float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                     toc3d_stream_t stream) {
     TOC3D_REQUIRE(epilogue < TOC3D_EPI_SWIGLU_STATS, "toc3d_linear_ex: epilogue %d takes the extra arguments of toc3d_linear_fused", epilogue);
     return toc3d_linear_fused(dtype, epilogue, variant, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index,
-                              M, N, K, n_valid, nullptr, 0, nullptr, 0, 0.f, stream);
+                              M, N, K, n_valid, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, stream);
 }
 
 int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -901,6 +1049,19 @@ int toc3d_pack_weight_lnfold(int dtype, const float* w3, const float* gamma, con
         toc3d_launch(pack_lnfold_kernel<float>, dim3((unsigned)Np), dim3(256), 0, as_stream(stream), w3, gamma, beta, b3, (int)N, (int)K, (float*)out_w, (int)Kp, c1, c2);
     else { toc3d_set_error("toc3d_pack_weight_lnfold: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_pack_weight_lnfold");
+    return TOC3D_OK;
+}
+
+int toc3d_pack_swiglu_lnfold(int dtype, const float* w1, const float* w2, const float* b1, const float* b2, const float* gamma, const float* beta,
+                             int64_t Hd, int64_t K, void* out_w, float* c1, float* c2, int64_t Hp, int64_t Kp, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(w1 && w2 && b1 && b2 && gamma && beta && out_w && c1 && c2, "toc3d_pack_swiglu_lnfold: null buffer");
+    TOC3D_REQUIRE(Hp >= Hd && Hp % 64 == 0 && Kp >= K, "toc3d_pack_swiglu_lnfold: Hp must be >= Hd and a multiple of 64");
+    if (dtype == TOC3D_BF16)
+        toc3d_launch(pack_swiglu_lnfold_kernel<bf16_t>, dim3((unsigned)(2 * Hp)), dim3(256), 0, as_stream(stream), w1, w2, b1, b2, gamma, beta, (int)Hd, (int)K, (bf16_t*)out_w, c1, c2, (int)Kp);
+    else if (dtype == TOC3D_F32)
+        toc3d_launch(pack_swiglu_lnfold_kernel<float>, dim3((unsigned)(2 * Hp)), dim3(256), 0, as_stream(stream), w1, w2, b1, b2, gamma, beta, (int)Hd, (int)K, (float*)out_w, c1, c2, (int)Kp);
+    else { toc3d_set_error("toc3d_pack_swiglu_lnfold: bad dtype"); return TOC3D_ERR_ARG; }
+    TOC3D_LAUNCH_CHECK("toc3d_pack_swiglu_lnfold");
     return TOC3D_OK;
 }
 

@@ -107,11 +107,14 @@ class CPFPN(nn.Module):
         key = (V, h, w)
         if key not in self._ws:
             Kl, Kf = P["w_lat"].shape[1], P["w_fpn"].shape[1]
-            self._ws[key] = dict(a=torch.zeros(M, Kl, dtype=tdt, device=dev), lat=torch.empty(M, Co, dtype=torch.float32, device=dev),
-                                 col=torch.zeros(M, Kf, dtype=tdt, device=dev), o0=torch.empty(M, Co, dtype=torch.float32, device=dev),
+            implicit = Co % 64 == 0                      # the implicit-GEMM conv needs whole 64-channel K-tiles per tap; otherwise im2col + GEMM
+            self._ws[key] = dict(a=torch.zeros(M, Kl, dtype=tdt, device=dev), implicit=implicit,
+                                 lat=torch.empty(M, Co, dtype=tdt if implicit else torch.float32, device=dev),
+                                 col=None if implicit else torch.zeros(M, Kf, dtype=tdt, device=dev),
+                                 zeros=torch.zeros(256, dtype=torch.uint8, device=dev), o0=torch.empty(M, Co, dtype=torch.float32, device=dev),
                                  out0=torch.empty(V, Co, h, w, dtype=torch.float32, device=dev))
         ws = self._ws[key]
-        Kl, Kf = ws["a"].shape[1], ws["col"].shape[1]
+        Kl, Kf = ws["a"].shape[1], P["w_fpn"].shape[1]
 
         def frame(ex):
             s = lib.stream_ptr()
@@ -120,10 +123,18 @@ class CPFPN(nn.Module):
             else:
                 a = ws["a"]
                 lib.call("toc3d_pack_weight", dt, nhwc, M, Cin, a, M, Kl, s)           # f32 -> act conversion with K padding
-            # both convolutions as GEMMs with a per-shape autotuned tile (N = 256 leaves 94 tiles of 128x128 for 256 CUs: the default tile is the wrong one)
-            tuned_linear(self, lib.EPI_RESIDUAL, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, None, M, Co, Kl, 0)
-            lib.call("toc3d_im2col_3x3", dt, ws["lat"], ws["col"], Kf, V, h, w, Co, s)
-            tuned_linear(self, lib.EPI_RESIDUAL, ws["col"], Kf, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, None, M, Co, Kf, 0)
+            # 1x1 lateral conv: a GEMM whose output stays in the act dtype (the reference's f32 lateral is rounded once on its way into the 3x3
+            # conv either way); 3x3 conv: an IMPLICIT GEMM (toc3d_conv3x3_nhwc) -- the operand loader gathers the nine neighbours of every pixel, the
+            # [M, 9*C] im2col matrix (27 MB per frame, one launch) is gone.  Both with a per-shape autotuned tile (N = 256 leaves 94 tiles of
+            # 128x128 for 256 CUs: the default tile is the wrong one).
+            if ws["implicit"]:
+                tuned_linear(self, lib.EPI_BIAS, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, None, M, Co, Kl, 0)
+                tuned_linear(self, lib.EPI_CONV3X3, ws["lat"], Co, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, None, M, Co, Kf, 0,
+                             fused=(None, 0, None, 0, None, 0, 0.0, ws["zeros"], (h << 32) | w))
+            else:                                        # channel counts that are not multiples of 64 (test configs): materialised im2col rows
+                tuned_linear(self, lib.EPI_RESIDUAL, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, None, M, Co, Kl, 0)
+                lib.call("toc3d_im2col_3x3", dt, ws["lat"], ws["col"], Kf, V, h, w, Co, s)
+                tuned_linear(self, lib.EPI_RESIDUAL, ws["col"], Kf, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, None, M, Co, Kf, 0)
             lib.call("toc3d_nhwc_to_nchw", ws["o0"], ws["out0"], V, h * w, Co, s)
 
         # The launch sequence names the input buffer: it can be recorded (and replayed with one C call) only for an input that sits

@@ -4,7 +4,7 @@ TAG=${1:-r02}
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 REPO="$GRAFT_REPO_ROOT"; cd "$REPO"
-CMD="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-breakdown"
+CMD="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-breakdown --no-parity-path"
 ( cd /tmp; rm -rf /tmp/p_*; 
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt -o kt -- $CMD > $REPO/gpurun_out/${TAG}_kt.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fs -o fs -- $CMD > /dev/null 2>&1
