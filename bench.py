@@ -185,6 +185,10 @@ def main():
     # max over ranks -- toc3d_amd/dist.py:timed_steps, the same function the world-2 gloo test drives
     elapsed = tdist.timed_steps(step, args.steps, max(0, args.warmup - 1), dev, finish=gather.drain if gather is not None else None)
 
+    last = step()
+    torch.cuda.synchronize()
+    assert last is None or bool(torch.isfinite(last.float()).all()), "non-finite neck features after the timed region"
+
     # ---- dominant-kernel timing: HIP events around every launch of each C-ABI op (eager, same stream) ------
     roof = None
     breakdown = {}

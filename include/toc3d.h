@@ -326,7 +326,7 @@ int toc3d_nhwc_to_nchw(const float* x, float* out, int64_t V, int64_t T, int64_t
 /* CPFPN's 3x3 conv (pad 1, necks/cp_fpn.py:124-133) as an IMPLICIT GEMM: x act [V, h, w, C] (NHWC, C a multiple of 64), W act packed
  * [ceil128(Cout), 9*C] in (ky, kx, c) column order (the layout toc3d_im2col_3x3 produces rows for), bias f32 [Cout] or NULL ->
  * out f32 [V*h*w, ldo].  The GEMM's operand loader gathers the nine neighbours of every pixel itself (out-of-image taps read `zeros`, a
- * device buffer of >= 128 zero bytes), so the [V*h*w, 9*C] im2col matrix is never written or read; same K order as toc3d_im2col_3x3 +
+ * device buffer of >= 16 zero bytes), so the [V*h*w, 9*C] im2col matrix is never written or read; same K order as toc3d_im2col_3x3 +
  * toc3d_linear, hence the same bits.  `variant` as toc3d_linear_ex (phased variants excluded). */
 int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const void* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
                        int64_t V, int64_t h, int64_t w, int64_t Cout, const void* zeros, toc3d_stream_t stream);

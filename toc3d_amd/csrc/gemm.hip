@@ -341,8 +341,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
                 const int r = cidx / (RB / 16), pch = cidx % (RB / 16);
                 const int y2 = (cv_yx[u] >> 16) + dy, x2 = (cv_yx[u] & 0xffff) + dx;
                 const bool in = (unsigned)y2 < (unsigned)a.conv_h && (unsigned)x2 < (unsigned)a.conv_w;
-                const char* src = in ? reinterpret_cast<const char*>(A + (int64_t)(cv_m[u] + dy * a.conv_w + dx) * C + c0) : reinterpret_cast<const char*>(a.zeros);
-                src += (pch ^ swz<RB>(r)) << 4;
+                // out-of-image taps: any 16 zero bytes (no chunk offset: K-tiles of 256 / 512 bytes would run past a small zero line)
+                const char* src = in ? reinterpret_cast<const char*>(A + (int64_t)(cv_m[u] + dy * a.conv_w + dx) * C + c0) + ((pch ^ swz<RB>(r)) << 4)
+                                     : reinterpret_cast<const char*>(a.zeros);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + (u * NTHR + wave * 64) * 16), 16, 0, 0);
             }
         } else {
