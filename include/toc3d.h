@@ -114,12 +114,16 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
  *   EPI_SWIGLU_STATS_LN  = EPI_SWIGLU_STATS on A = out_act with W = gamma-scaled interleaved weights, bias = c2, col_sums = c1 in packed column
  *                          order (toc3d_pack_swiglu_lnfold); reads stats_in, writes stats_out (different buffers).
  * stats_out / stats_in: int32 header [4] + f32 [M, cap, 2] each; ln_n = width of the normalised rows (valid hidden units for EPI_RESIDUAL_LN,
- * K for EPI_SWIGLU_STATS_LN).  Every other argument as toc3d_linear_ex; epilogues 0-3 ignore the nine extra arguments. */
+ * K for EPI_SWIGLU_STATS_LN).  residual_index (int32 [M] or NULL, residual epilogues): output row m takes its residual from row
+ * residual_index[m] of `residual` (a compact row whose f32 residual still sits in the token-major stream, toc3d_gather_merge_ln_ex with
+ * kept_copy = 0), or, where residual_index[m] < 0, from output row m itself, read in place (representative rows).
+ * Every other argument as toc3d_linear_ex; epilogues 0-3 ignore the extra arguments. */
 int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
                        const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                        float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap,
-                       const float* col_sums, int64_t ln_n, float ln_eps, void* out_act, int64_t ld_act, toc3d_stream_t stream);
+                       const float* col_sums, int64_t ln_n, float ln_eps, void* out_act, int64_t ld_act, const int32_t* residual_index,
+                       toc3d_stream_t stream);
 /* mlp.w1 / mlp.w2 interleaved as toc3d_pack_swiglu, scaled by norm2's gamma per input channel; c1 [2*Hp] = row sums of the ROUNDED scaled
  * weights, c2 [2*Hp] = beta . w + b, both in packed row order. */
 int toc3d_pack_swiglu_lnfold(int dtype, const float* w1, const float* w2, const float* b1, const float* b2, const float* gamma, const float* beta,
@@ -258,6 +262,11 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
 int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                           const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
                           const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, toc3d_stream_t stream);
+/* The same with kept_copy = 0: the f32 `shortcut` copy of the kept rows is NOT written (40 % of the kernel's bytes); only the representative
+ * rows are.  The projection GEMM then reads the residual of a kept row from x through crow_tok (toc3d_linear_fused residual_index). */
+int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
+                             const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
+                             const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy, toc3d_stream_t stream);
 /* toc3d_rebase_layernorm_rows: norm1 (toc3d_eva_vit.py:372) of a block that continues on the previous block's compact rows instead
  *   of re-gathering them (shortcut rows f32 [rows, C], in place; LN -> out act [rows, ldo]).  Representative rows (rep_index[r] = window
  *   i >= 0) are first turned into what merge_tokens (toc3d_utils.py:65-70) would produce from the updated dropped tokens:

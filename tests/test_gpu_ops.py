@@ -787,7 +787,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
         stats = torch.zeros(4 + M * cap * 2, device=DEV)
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd,
-                 stats, cap, None, 0, None, 0, 0.0, None, 0, S())
+                 stats, cap, None, 0, None, 0, 0.0, None, 0, None, S())
         assert torch.equal(hid, hid0), f"variant {v}: hidden units differ from EPI_SWIGLU"
         nslots = int(stats[:1].view(torch.int32).item())
         assert nslots == (2 * Hp + 127) // 128
@@ -800,7 +800,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
         out = res.clone()
         rep = torch.zeros(nrep, C, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,
-                 None, 0, stats, cap, c1, Hd, eps, None, 0, S())
+                 None, 0, stats, cap, c1, Hd, eps, None, 0, None, S())
         if ref_out is None:
             ref_out, ref_rep = out.clone(), rep.clone()
             e_fold, e_seq = relerr(out, ref), relerr(out0, ref)
@@ -811,11 +811,11 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
     for v, epi in ((47, lib.EPI_SWIGLU_STATS), (9, lib.EPI_SWIGLU_STATS), (60, lib.EPI_SWIGLU_STATS), (60, lib.EPI_RESIDUAL_LN)):
         with pytest.raises(RuntimeError, match="cannot serve"):
             if epi == lib.EPI_SWIGLU_STATS:
-                lib.call("toc3d_linear_fused", dt, epi, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, None, 0, 0.0, None, 0, S())
+                lib.call("toc3d_linear_fused", dt, epi, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, None, 0, 0.0, None, 0, None, S())
             else:
-                lib.call("toc3d_linear_fused", dt, epi, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, None, None, M, C, Hp, 0, None, 0, stats, cap, c1, Hd, eps, None, 0, S())
+                lib.call("toc3d_linear_fused", dt, epi, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, None, None, M, C, Hp, 0, None, 0, stats, cap, c1, Hd, eps, None, 0, None, S())
     with pytest.raises(RuntimeError, match="bf16 only"):
-        lib.call("toc3d_linear_fused", lib.F32, lib.EPI_SWIGLU_STATS, 16, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, None, 0, 0.0, None, 0, S())
+        lib.call("toc3d_linear_fused", lib.F32, lib.EPI_SWIGLU_STATS, 16, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, None, 0, 0.0, None, 0, None, S())
 
 
 def test_norm2_folded_across_the_projection_boundary():
@@ -861,7 +861,7 @@ def test_norm2_folded_across_the_projection_boundary():
         st2 = torch.zeros(4 + M * cap2 * 2, device=DEV)
         rep = torch.zeros(nrep, C, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_STATS, v, att, C, wproj, C, bp, x, C, x, C, 0, rep, rep_index, M, C, C, 0,
-                 st2, cap2, None, 0, None, 0, 0.0, a_raw, C, S())
+                 st2, cap2, None, 0, None, 0, 0.0, a_raw, C, None, S())
         assert torch.equal(x, x_ref) and torch.equal(rep, rep0), f"variant {v}: f32 output differs from EPI_RESIDUAL"
         assert torch.equal(a_raw, x_ref.to(tdt)), f"variant {v}: act-dtype copy is not the rounded output"
         assert int(st2[:1].view(torch.int32).item()) == cap2
@@ -874,7 +874,7 @@ def test_norm2_folded_across_the_projection_boundary():
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         st = torch.zeros(4 + M * cap * 2, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS_LN, v, ref_a, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
-                 st, cap, st2, cap2, c1, C, eps, None, 0, S())
+                 st, cap, st2, cap2, c1, C, eps, None, 0, None, S())
         if ref_h is None:
             ref_h, ref_hs = hid.clone(), st.clone()
             e_fold, e_seq = relerr(hid[:, :Hd], h_ref), relerr(hid_seq[:, :Hd], h_ref)
@@ -886,7 +886,7 @@ def test_norm2_folded_across_the_projection_boundary():
         assert torch.equal(hid, ref_h) and torch.equal(st, ref_hs), f"variant {v}: folded w1|w2 epilogue depends on the tile variant"
     with pytest.raises(RuntimeError, match="different buffers"):
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS_LN, 16, ref_a, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
-                 st2, cap2, st2, cap2, c1, C, eps, None, 0, S())
+                 st2, cap2, st2, cap2, c1, C, eps, None, 0, None, S())
 
 
 @pytest.mark.parametrize("name,dt,tdt", DTYPES)
@@ -916,3 +916,37 @@ def test_conv3x3_implicit_gemm_equals_im2col_gemm(name, dt, tdt):
             lib.call("toc3d_conv3x3_nhwc", dt, 60, x_act, C, wp, 9 * C, b, out, Co, V, h, w, Co, zeros, S())
     with pytest.raises(RuntimeError, match="multiple of 64"):
         lib.call("toc3d_conv3x3_nhwc", dt, 16, x_act, 96, wp, 9 * 96, b, out, Co, V, h, w, Co, zeros, S())
+
+
+def test_gathered_residual_equals_the_shortcut_copy():
+    """toc3d_gather_merge_ln_ex(kept_copy=0) + toc3d_linear_fused(residual_index=crow_tok): the projection GEMM reads the residual of a kept
+    row from x, of a representative row in place -- the same bits as reading the f32 shortcut copy the gather kernel used to write."""
+    dt, tdt = lib.BF16, torch.bfloat16
+    V, h, w, C, L, ratio = 2, 20, 50, 128, 16, 0.4
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(V, h, w, C, generator=g)
+    scores = -torch.rand(V, h, w, generator=g) * 3 - 0.1
+    gw, gb = (1 + 0.1 * rnd(C, seed=2)).to(DEV), (0.1 * rnd(C, seed=3)).to(DEV)
+    N = L * L
+    k = int(N * ratio)
+    b = _run_topk(scores, V, h, w, L, k)
+    ms, nW = b["ms"], b["tok"].shape[0]
+    xd = x.reshape(-1, C).to(DEV).contiguous()
+    outs = {}
+    for kept_copy in (1, 0):
+        short = torch.full((ms, C), float("nan"), device=DEV)             # rows the kernel does not write stay NaN
+        a = torch.empty(ms, C, dtype=tdt, device=DEV)
+        lib.call("toc3d_gather_merge_ln_ex", dt, xd, C, b["tok"], b["wgt"], b["crow_tok"], b["rep_row"], nW, N, k, ms, gw, gb, 1e-6, short, a, C, kept_copy, S())
+        att = as_act(rnd(ms, C, seed=4), tdt)
+        wp, bp = pack(rnd(C, C, seed=5, scale=C ** -0.5), dt, tdt), rnd(C, seed=6).to(DEV)
+        rep = torch.zeros(nW, C, device=DEV)
+        if kept_copy:
+            lib.call("toc3d_linear_ex", dt, lib.EPI_RESIDUAL, 16, att, C, wp, C, bp, short, C, short, C, 0, rep, b["rep_index"], ms, C, C, 0, S())
+        else:
+            kept = b["crow_tok"] >= 0
+            assert bool(torch.isnan(short[kept]).all()) and bool(torch.isfinite(short[~kept]).all())
+            lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL, 16, att, C, wp, C, bp, short, C, xd, C, 0, rep, b["rep_index"], ms, C, C, 0,
+                     *lib.NO_FUSED[:9], b["crow_tok"], S())
+        outs[kept_copy] = (short.clone(), rep.clone(), a.clone())
+    for t0, t1 in zip(outs[1], outs[0]):
+        assert bool(torch.isfinite(t1.float()).all()) and torch.equal(t0, t1)

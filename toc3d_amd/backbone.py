@@ -278,6 +278,9 @@ class _BackboneBase(nn.Module):
         # Measured neutral (same-box A/B 191.1 vs 189.2 frames/s: the 6-8 us LayerNorm launches it removes cost what the extra epilogue phases of the
         # latency-bound N = 1024 projection GEMMs cost), so it is OFF by default; TOC3D_FOLD_N2=1 enables it (7 launches per accelerated block).
         self.fold_norm2 = self.fold_ffn_ln and os.environ.get("TOC3D_FOLD_N2", "0") != "0"
+        # the gather kernel skips the f32 copy of the kept rows (40 % of its bytes); the projection GEMM reads their residual from x through
+        # crow_tok instead (toc3d_gather_merge_ln_ex kept_copy = 0 + toc3d_linear_fused residual_index).  Same bits either way.
+        self.gathered_residual = os.environ.get("TOC3D_GATHERED_RES", "1") != "0"
         # software prefetch of the weights of the GEMMs that follow each attention launch, by extra workgroups of that launch
         # (toc3d_window_attention_pf): number of prefetch workgroups, 0 = off
         # (same-box A/B r02: 190.8 frames/s without, 193.8 / 193.4 / 192.8 / 191.6 with 128 / 256 / 512 / 1024 workgroups)
@@ -521,15 +524,18 @@ class _BackboneBase(nn.Module):
         nb = (ctypes.c_int64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
         lib.call("toc3d_window_attention_pf", *args, len(ts), ptrs, nb, self.prefetch_weights, s)
 
-    def _proj(self, bp, plan, rows, res, rep_out, rep_index):
-        """attn.proj + residual add (eva_vit.py:115,262 / toc3d_eva_vit.py:514,379) in place on ``res`` f32 [rows, C]; with norm2 folded the
-        epilogue also leaves the updated rows in bf16 (plan["a"]) and their statistics (plan["stats2"]) for the w1|w2 GEMM."""
+    def _proj(self, bp, plan, rows, out, rep_out, rep_index, res=None, res_index=None):
+        """attn.proj + residual add (eva_vit.py:115,262 / toc3d_eva_vit.py:514,379) into ``out`` f32 [rows, C]: in place by default, or with the
+        residual of row m read from row ``res_index[m]`` of ``res`` (the token-major stream; compact rows that were never copied).  With
+        norm2 folded the epilogue also leaves the updated rows in bf16 (plan["a"]) and their statistics (plan["stats2"]) for the w1|w2 GEMM."""
         C = self.embed_dim
+        res = out if res is None else res
         if self.fold_norm2:
-            self._linear(lib.EPI_RESIDUAL_STATS, plan["att"], C, bp["wproj"], C, bp["bproj"], res, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
-                         fused=(plan["stats2"], plan["stats2_cap"], None, 0, None, 0, 0.0, plan["a"], C))
+            self._linear(lib.EPI_RESIDUAL_STATS, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
+                         fused=(plan["stats2"], plan["stats2_cap"], None, 0, None, 0, 0.0, plan["a"], C, res_index))
         else:
-            self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], res, C, res, C, 0, rep_out, rep_index, rows, C, C, 0)
+            self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
+                         fused=lib.NO_FUSED[:9] + (res_index,))
 
     def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
         """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
@@ -543,13 +549,13 @@ class _BackboneBase(nn.Module):
             st, cap = plan["stats"], plan["stats_cap"]
             if self.fold_norm2:
                 self._linear(lib.EPI_SWIGLU_STATS_LN, plan["a"], C, bp["w12"], C, bp["c2_12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                             fused=(st, cap, plan["stats2"], plan["stats2_cap"], bp["c1_12"], C, self.LN_EPS, None, 0))
+                             fused=(st, cap, plan["stats2"], plan["stats2_cap"], bp["c1_12"], C, self.LN_EPS, None, 0, None))
             else:
                 lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
                 self._linear(lib.EPI_SWIGLU_STATS, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                             fused=(st, cap, None, 0, None, 0, 0.0, None, 0))
+                             fused=(st, cap, None, 0, None, 0, 0.0, None, 0, None))
             self._linear(lib.EPI_RESIDUAL_LN, plan["hid"], Hp, bp["w3"], bp["w3"].shape[1], bp["c2"], res, C, res, C, 0,
-                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, st, cap, bp["c1"], Hd, self.LN_EPS, None, 0))
+                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, st, cap, bp["c1"], Hd, self.LN_EPS, None, 0, None))
             return
         lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
         self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)
@@ -959,13 +965,16 @@ class ToC3DEVAViT(_BackboneBase):
             lib.call("toc3d_rebase_layernorm_rows", dt, slow, C, sel["rep_index"], sel["tok"], sel["wgt"], N, k, plan["rep1"], plan["rep2"],
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, rows, s)
         else:
-            lib.call("toc3d_gather_merge_ln", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
-                     bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, s)
+            lib.call("toc3d_gather_merge_ln_ex", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
+                     bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1, s)
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, rows, 3 * C, C, 0)
         self._attention(P, i, dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"],
                         None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], None, 64 ** -0.5)
         ra, rb = (plan["rep3"], plan["rep4"]) if carry_in else (plan["rep1"], plan["rep2"])
-        self._proj(bp, plan, rows, slow, ra, sel["rep_index"])
+        if self.gathered_residual and not carry_in:      # kept rows were not copied: their residual comes from x through crow_tok
+            self._proj(bp, plan, rows, slow, ra, sel["rep_index"], res=plan["x"], res_index=sel["crow_tok"])
+        else:
+            self._proj(bp, plan, rows, slow, ra, sel["rep_index"])
         self._mlp(bp, plan, rows, slow, rb, sel["rep_index"])
         if not carry_out:
             lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"],

@@ -29,6 +29,7 @@ struct GemmArgs {
     const float* bias;
     void* out; int64_t ldo;
     const float* res; int64_t ldr; int res_mod;
+    const int32_t* res_index;                            // residual row of output row m = res_index[m] (< 0: the output row itself, read in place)
     float* rep_out; const int32_t* rep_index;
     int M, N, K, n_valid;
     int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
@@ -200,6 +201,10 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
             const int rr = a.res_mod > 0 ? row % a.res_mod : row;
             const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
             float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
+            if (a.res_index) {                           // compact rows whose residual still sits in the token-major stream (no f32 copy was made)
+                const int ti = a.res_index[row];
+                resrow = ti >= 0 ? a.res + (int64_t)ti * a.ldr : orow;
+            }
             float* reprow = nullptr;
             if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
 #pragma unroll
@@ -944,7 +949,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
                        void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                        float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
-                       void* out_act, int64_t ld_act, toc3d_stream_t stream) {
+                       void* out_act, int64_t ld_act, const int32_t* residual_index, toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && K > 0, "toc3d_linear: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -977,6 +982,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     } else {
         TOC3D_REQUIRE(ldo >= N, "toc3d_linear: ldo < N");
     }
+    TOC3D_REQUIRE(!residual_index || (e_residual && residual && residual_row_mod == 0), "toc3d_linear: residual_index needs a residual epilogue, a residual buffer and no row modulus");
     if (e_residual) {
         TOC3D_REQUIRE(!residual || ldr >= N, "toc3d_linear: ldr < N");
         TOC3D_REQUIRE(!rep_index || rep_out, "toc3d_linear: rep_index set without rep_out");
@@ -986,7 +992,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     const int64_t osz = e_residual ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
     const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * osz) == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
                      (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0));
-    GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, rep_out, rep_index,
+    GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0,
                stats_out, (int)stats_out_cap, stats_in, (int)stats_in_cap, col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
                0, 0, nullptr};
@@ -1009,7 +1015,7 @@ int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const v
     TOC3D_REQUIRE(x && W && out && zeros && V > 0 && h > 0 && w > 0 && h < 32768 && w < 65536, "toc3d_conv3x3_nhwc: bad arguments");
     TOC3D_REQUIRE(C % 64 == 0, "toc3d_conv3x3_nhwc: the channel count must be a multiple of 64 (one K-tile never straddles two taps)");
     return toc3d_linear_fused(dtype, TOC3D_EPI_CONV3X3, variant, x, C, W, ldw, bias, out, ldo, nullptr, 0, 0, nullptr, nullptr, V * h * w, Cout, 9 * C, 0,
-                              nullptr, 0, nullptr, 0, nullptr, 0, 0.f, const_cast<void*>(zeros), (h << 32) | w, stream);
+                              nullptr, 0, nullptr, 0, nullptr, 0, 0.f, const_cast<void*>(zeros), (h << 32) | w, nullptr, stream);
 }
 
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -1018,7 +1024,7 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
                     toc3d_stream_t stream) {
     TOC3D_REQUIRE(epilogue < TOC3D_EPI_SWIGLU_STATS, "toc3d_linear_ex: epilogue %d takes the extra arguments of toc3d_linear_fused", epilogue);
     return toc3d_linear_fused(dtype, epilogue, variant, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index,
-                              M, N, K, n_valid, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, stream);
+                              M, N, K, n_valid, nullptr, 0, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, nullptr, stream);
 }
 
 int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

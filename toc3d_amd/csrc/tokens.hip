@@ -343,7 +343,7 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
                                                                const float* __restrict__ wgt, const int32_t* __restrict__ crow_tok,
                                                                const int32_t* __restrict__ rep_row, int nW, int N, int k, int Ms,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                               float* __restrict__ shortcut, T* __restrict__ a_out, int64_t lda) {
+                                                               float* __restrict__ shortcut, T* __restrict__ a_out, int64_t lda, int kept_copy) {
     extern __shared__ __attribute__((aligned(16))) float s_part[];        // [16][C]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nvec = C >> 2;
@@ -425,7 +425,10 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (vi < nvec) {
             if (src >= 0) v[i] = *reinterpret_cast<const f32x4*>(x + (int64_t)src * C + 4 * vi);
-            *reinterpret_cast<f32x4*>(shortcut + orow * C + 4 * vi) = v[i];
+            // the f32 copy of a kept row is only needed when the projection GEMM reads its residual from the compact buffer; with
+            // kept_copy == 0 that GEMM gathers the row from x itself (toc3d_linear_fused residual_index) and 40 % of this kernel's bytes go
+            // (explicit zero rows, src < 0, keep theirs: the GEMM reads rows without a token in place)
+            if (kept_copy || src < 0) *reinterpret_cast<f32x4*>(shortcut + orow * C + 4 * vi) = v[i];
         }
     }
     float mean, rstd;
@@ -652,9 +655,9 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
     return TOC3D_OK;
 }
 
-int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
-                          const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
-                          const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, toc3d_stream_t stream) {
+int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
+                             const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
+                             const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy, toc3d_stream_t stream) {
     TOC3D_REQUIRE(x && tok && wgt && crow_tok && rep_row && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln: null buffer");
     TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
     TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW, "toc3d_gather_merge_ln: bad k / lda / rows");
@@ -667,14 +670,20 @@ int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* t
     if (dtype == TOC3D_BF16) {
         static Toc3dLdsAttr attr;
         attr.ensure(reinterpret_cast<const void*>(&gather_merge_ln_kernel<bf16_t, 4>), 65536);
-        toc3d_launch((gather_merge_ln_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (bf16_t*)a_out, lda);
+        toc3d_launch((gather_merge_ln_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (bf16_t*)a_out, lda, (int)(kept_copy != 0));
     } else if (dtype == TOC3D_F32) {
         static Toc3dLdsAttr attr;
         attr.ensure(reinterpret_cast<const void*>(&gather_merge_ln_kernel<float, 4>), 65536);
-        toc3d_launch((gather_merge_ln_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (float*)a_out, lda);
+        toc3d_launch((gather_merge_ln_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (float*)a_out, lda, (int)(kept_copy != 0));
     } else { toc3d_set_error("toc3d_gather_merge_ln: bad dtype"); return TOC3D_ERR_ARG; }
     TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln");
     return TOC3D_OK;
+}
+
+int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
+                          const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
+                          const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, toc3d_stream_t stream) {
+    return toc3d_gather_merge_ln_ex(dtype, x, C, tok, wgt, crow_tok, rep_row, nW, N, k, rows, gamma, beta, eps, shortcut, a_out, lda, 1, stream);
 }
 
 int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k,

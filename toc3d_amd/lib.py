@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3 = 0, 1, 2, 3, 4, 5, 6, 7, 8
-NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0)     # the nine extra arguments of toc3d_linear_fused for epilogues 0-3
+NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
 
 _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
@@ -23,7 +23,7 @@ _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 _SIGS = {
     "toc3d_linear": "iiplplpplpllppllllp",
     "toc3d_linear_ex": "iiiplplpplpllppllllp",
-    "toc3d_linear_fused": "iiiplplpplpllppllll" + "plplplf" + "pl" + "p",
+    "toc3d_linear_fused": "iiiplplpplpllppllll" + "plplplf" + "pl" + "p" + "p",
     "toc3d_pack_swiglu_lnfold": "ippppppllpppllp",
     "toc3d_pack_weight_lnfold": "ippppllpllppp",
     "toc3d_conv3x3_nhwc": "iiplplpplllllpp",
@@ -41,6 +41,7 @@ _SIGS = {
     "toc3d_rank_desc": "pllpp",
     "toc3d_window_topk": "plllllpppppppppppp",
     "toc3d_gather_merge_ln": "iplppppllllppfpplp",
+    "toc3d_gather_merge_ln_ex": "iplppppllllppfppllp",
     "toc3d_scatter_update": "plpplllpppppp",
     "toc3d_rebase_layernorm_rows": "iplpppllppppfpllp",
     "toc3d_pack_motion_weights": "p" * 24 + "p",

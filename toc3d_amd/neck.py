@@ -130,7 +130,7 @@ class CPFPN(nn.Module):
             if ws["implicit"]:
                 tuned_linear(self, lib.EPI_BIAS, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, None, M, Co, Kl, 0)
                 tuned_linear(self, lib.EPI_CONV3X3, ws["lat"], Co, P["w_fpn"], Kf, P["b_fpn"], ws["o0"], Co, None, 0, 0, None, None, M, Co, Kf, 0,
-                             fused=(None, 0, None, 0, None, 0, 0.0, ws["zeros"], (h << 32) | w))
+                             fused=(None, 0, None, 0, None, 0, 0.0, ws["zeros"], (h << 32) | w, None))
             else:                                        # channel counts that are not multiples of 64 (test configs): materialised im2col rows
                 tuned_linear(self, lib.EPI_RESIDUAL, a, Kl, P["w_lat"], Kl, P["b_lat"], ws["lat"], Co, None, 0, 0, None, None, M, Co, Kl, 0)
                 lib.call("toc3d_im2col_3x3", dt, ws["lat"], ws["col"], Kf, V, h, w, Co, s)
