@@ -86,7 +86,7 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
  * (bf16), 32 = 256x128 3-deep, 33 = 128x64 on 8 wavefronts 4-deep; 34-37 = 16-wavefront 256x128 / 256x256 / 128x256 tiles;
  * 38/39 = 128x128 on 8 wavefronts with 32-wide K tiles 2-/3-deep, 40-42 = 128x256 / 256x128 single buffer and K32 rings;
  * 43-48 = 128x192 and 128x96 tiles (43/44 single buffer, 45/46 double buffer, 47 = 128x192 with 32x96 per wavefront so that
- * it serves SWIGLU, 48 = 3-deep); 49/50 = 192x128 double / single buffer; 51 = variant 16 compiled for 64 registers (four workgroups per CU);
+ * it serves SWIGLU, 48 = 3-deep); 49/50 = 192x128 double / single buffer; 51 = variant 16 compiled for 64 registers (four workgroups per CU); 52/53 = 192x192 single / double buffer;
  * 60-63 = phased 256x256 / 256x128 / 128x256 / 128x128 tiles (bf16, one or two workgroups per CU, four phases per K-tile).  A variant whose per-wavefront column slab is not a
  * multiple of 32 cannot serve EPI_SWIGLU (error TOC3D_ERR_UNSUPPORTED).  variant + 100 = the same tile with the per-XCD band
  * order (each XCD keeps its A row band in L2 and walks the W panels once).  Every variant accumulates K in the same order: outputs are bit-identical across variants. */

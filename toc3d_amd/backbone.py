@@ -159,7 +159,7 @@ def _init_weights(m):
 _flush = None                   # 256 MB scratch shared by all models: evicts L2 + Infinity Cache between tuning launches
 
 
-_VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 163),
+_VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 152, 163),
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
 
 def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED):
@@ -184,7 +184,7 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
             rep_s = torch.empty_like(rep_out) if rep_out is not None else None
             cands = _VARIANTS[self._dt]
             if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):
-                cands = [v for v in cands if v not in (33, 45, 145)]   # wave slabs that are not whole (w1, w2) 32-column groups
+                cands = [v for v in cands if v not in (33, 45, 145, 52, 53, 152)]   # wave slabs that are not whole (w1, w2) 32-column groups
             if epi in (lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):  # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
                 cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47, 60, 63)]
             if epi in (lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # the phased tiles do not carry the folded-LayerNorm epilogues

@@ -16,733 +16,20 @@
 // bank-conflict swizzle (16-byte chunk c of row r lives at position c ^ (r & 7)) is applied on the
 // *source* address and undone on the ds_read side (cdna_hip_programming.md rule 21).
 // Workgroup ids are remapped XCD-aware so the tiles of one A row-panel share an L2.
-#include "capi.h"
-#include "common.h"
-
-namespace {
-
-// RB = bytes of K per LDS row per stage: 128 (64 bf16 / 32 f32 per K-tile) or 64 (32 bf16, bf16 only)
-
-struct GemmArgs {
-    const void* A; int64_t lda;
-    const void* W; int64_t ldw;
-    const float* bias;
-    void* out; int64_t ldo;
-    const float* res; int64_t ldr; int res_mod;
-    const int32_t* res_index;                            // residual row of output row m = res_index[m] (< 0: the output row itself, read in place)
-    float* rep_out; const int32_t* rep_index;
-    int M, N, K, n_valid;
-    int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
-    int vec;                                             // epilogue may use 4-element vector accesses (alignment checked on the host)
-    // LayerNorms folded across GEMM boundaries (include/toc3d.h, toc3d_linear_fused): statistics this launch leaves / consumes
-    float* stats; int stats_cap;                         // written:  int32 header [4] + f32 [M, stats_cap, 2]
-    const float* stats_in; int stats_in_cap;             // consumed: same layout, written by the launch that produced A
-    const float* c1; float ln_inv_n, ln_eps;             // consumed side: column sums of the gamma-scaled W, 1 / (normalised width), eps
-    void* out_act; int64_t ld_act;                       // EPI_RESIDUAL_STATS: act-dtype copy of the f32 output rows (the next GEMM's A operand)
-    // EPI_CONV3X3: A is an NHWC act tensor [V, conv_h, conv_w, lda]; the kernel gathers the 3x3 (pad 1) patches itself, K = 9 * lda in (ky, kx, c) order
-    int conv_h, conv_w; const void* zeros;               // zeros: >= 128 bytes of zeros (the out-of-image taps)
-};
-
-constexpr bool epi_is_swiglu(int epi) { return epi == TOC3D_EPI_SWIGLU || epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN; }
-constexpr bool epi_is_residual(int epi) { return epi == TOC3D_EPI_RESIDUAL || epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_RESIDUAL_STATS || epi == TOC3D_EPI_CONV3X3; }
-constexpr bool epi_ln_in(int epi) { return epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_SWIGLU_STATS_LN; }        // LayerNorm of the A rows folded in
-constexpr bool epi_stats_out(int epi) { return epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN || epi == TOC3D_EPI_RESIDUAL_STATS; }
-// statistics groups per wave-tile row: one per 32 packed columns (SwiGLU) or per 16 output columns (residual)
-constexpr int epi_stat_groups(int epi, int NT) { return epi_is_swiglu(epi) ? (NT / 2 > 0 ? NT / 2 : 1) : NT; }
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// LDS swizzle: 16-byte chunk c of row r is stored at chunk position c ^ swz(r).  128-byte rows: swz = r & 7;
-// 64-byte rows (4 rows per 256-byte bank row): swz = (-(r >> 2)) & 3; rows of 256 / 512 bytes (every row starts on
-// the same bank): swz = r & 15.  Each makes every ds_read_b128 lane group of the MFMA fragment reads hit 16
-// distinct 16-byte slots.
-template <int RB> TOC3D_DEV int swz(int r) { return RB >= 256 ? (r & 15) : (RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3)); }
-
-// stage one R-row x RB-byte operand tile with 16-byte global_load_lds: R*RB/16 chunks over 256 threads.
-template <typename T, int R, int RB, int NTHR>
-TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max_row, int k0, char* lds_tile, int wave, int lane) {
-    constexpr int CPR = RB / 16;                        // chunks per row
-#pragma unroll
-    for (int t = 0; t < R * CPR / NTHR; ++t) {
-        const int cidx = t * NTHR + wave * 64 + lane;
-        const int r = cidx / CPR, p = cidx % CPR;
-        int gr = row0 + r;
-        gr = gr < max_row ? gr : max_row;
-        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB>(r)) << 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + (t * NTHR + wave * 64) * 16), 16, 0, 0);
-    }
-}
-
-// fragment of row r (tile-local) for the 32-wide K step s, lane group g = lane >> 4
-template <int RB>
-TOC3D_DEV Frag<bf16_t> lds_frag(const char* tile, int r, int s, int g, bf16_t) {
-    const int cc = s * 4 + g;
-    Frag<bf16_t> f;
-    f.v = *reinterpret_cast<const bf16x8*>(tile + r * RB + ((cc ^ swz<RB>(r)) << 4));
-    return f;
-}
-template <int RB>
-TOC3D_DEV Frag<float> lds_frag(const char* tile, int r, int s, int g, float) {
-    static_assert(RB >= 128, "f32 tiles use rows of >= 128 bytes");
-    Frag<float> f;
-    f.lo = *reinterpret_cast<const f32x4*>(tile + r * RB + (((s * 8 + 2 * g) ^ swz<RB>(r)) << 4));
-    f.hi = *reinterpret_cast<const f32x4*>(tile + r * RB + (((s * 8 + 2 * g + 1) ^ swz<RB>(r)) << 4));
-    return f;
-}
-
-TOC3D_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// SiLU of the SwiGLU epilogue.  The precise expf + IEEE division are ~35 VALU instructions per element, 16 elements per lane in the
-// epilogue of the frame's largest GEMM (w1|w2); the bf16 path rounds the product to 8 bits anyway, so it takes the hardware exp2 / rcp
-// (v_exp_f32, v_rcp_f32: ~1 ulp) -- the strict-parity f32 instantiation keeps the precise forms.
-template <typename T> TOC3D_DEV float silu(float x);
-template <> TOC3D_DEV float silu<float>(float x) { return x / (1.0f + expf(-x)); }
-template <> TOC3D_DEV float silu<bf16_t>(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-
-template <int N> TOC3D_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Workgroup barrier of the K loop.  __builtin_amdgcn_s_barrier() alone does not order memory operations for the compiler: without
-// the fences the scheduler may hoist the next K-tile's global_load_lds above the barrier (or sink this tile's ds_reads below it),
-// and another wavefront then reads an operand piece that is being overwritten -- 8-row pieces of a tile came out wrong a few times
-// per thousand launches, only with other kernels co-resident on the CU (tests/test_gpu_ops.py::test_linear_is_bit_stable_under_load).
-TOC3D_DEV void tile_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-}
-
-// Barrier that also publishes this wave's LDS stores (the raw barrier above does not wait for them) -- but NOT its global stores: a
-// __syncthreads() here would hold every wave until its epilogue stores are acknowledged (s_waitcnt vmcnt(0)), microseconds per workgroup.
-TOC3D_DEV void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    tile_barrier();
-}
-
-// ---- epilogue of one wavefront's (MT*16) x (NT*16) accumulator block whose first row / column are row0 / col0.  The MFMA is issued
-// with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
-// .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
-// alignment / leading dims) enables the vector path. ----
-// Statistics-writing epilogues: gs / gq [MT * G] (G = epi_stat_groups) receive, per row tile i and column group, this lane's share of
-// (sum, sum of squares) over the ROUNDED act-dtype values it wrote (zero for rows / columns outside the matrix); the caller completes the sums.
-// LayerNorm-consuming epilogues: lnrow = (mean, rstd) per tile row, prepared in LDS by the kernel.
-template <typename T, int EPI, int MT, int NT>
-TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, int col0, int r16, int g, float* gs = nullptr,
-                             float* gq = nullptr, const f32x2* lnrow = nullptr) {
-    constexpr int G = epi_stat_groups(EPI, NT);
-    if (epi_is_swiglu(EPI)) {
-        // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
-        T* out = reinterpret_cast<T*>(a.out);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int row = row0 + i * 16 + r16;
-            float mu = 0.f, rs = 1.f;
-            if (epi_ln_in(EPI)) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
-#pragma unroll
-            for (int jp = 0; jp < NT / 2; ++jp) {
-                const int pc = col0 + jp * 32 + g * 4;    // packed col of the w1 half, first of 4
-                const int unit0 = (pc >> 5) * 16 + g * 4;
-                float ssum = 0.f, sq = 0.f;
-                if (pc < a.N && row < a.M) {
-                    T hs[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x1, x2;
-                        if (epi_ln_in(EPI)) {               // bias = c2 (beta . W + b), c1 = column sums of the gamma-scaled packed weights
-                            x1 = rs * (acc[i][2 * jp][r] - mu * a.c1[pc + r]) + a.bias[pc + r];
-                            x2 = rs * (acc[i][2 * jp + 1][r] - mu * a.c1[pc + 16 + r]) + a.bias[pc + 16 + r];
-                        } else {
-                            x1 = acc[i][2 * jp][r] + a.bias[pc + r];
-                            x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
-                        }
-                        hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu<T>(x1) * x2 : 0.f);
-                        if (epi_stats_out(EPI)) {
-                            const float hv = from_act(hs[r]);       // what the next GEMM multiplies: the rounded value
-                            ssum += hv;
-                            sq = __builtin_fmaf(hv, hv, sq);
-                        }
-                    }
-                    T* dst = out + (int64_t)row * a.ldo + unit0;
-                    if (a.vec) store4(dst, hs);
-                    else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
-                }
-                if (epi_stats_out(EPI)) { gs[i * G + jp] = ssum; gq[i * G + jp] = sq; }
-            }
-        }
-        return;
-    }
-    float bcol[NT][4];
-    float ccol[EPI == TOC3D_EPI_RESIDUAL_LN ? NT : 1][4];    // c1: column sums of the gamma-scaled weights
-    if (EPI == TOC3D_EPI_RESIDUAL_STATS) {
-#pragma unroll
-        for (int q = 0; q < MT * G; ++q) { gs[q] = 0.f; gq[q] = 0.f; }
-    }
-    int nok[NT];                                         // valid columns among the lane's 4 (0..4)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int col = col0 + j * 16 + g * 4;
-        nok[j] = a.N - col < 0 ? 0 : (a.N - col > 4 ? 4 : a.N - col);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
-            if (EPI == TOC3D_EPI_RESIDUAL_LN) ccol[j][r] = r < nok[j] ? a.c1[col + r] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = row0 + i * 16 + r16;
-        if (row >= a.M) continue;
-        float mu = 0.f, rs = 1.f;                        // EPI_RESIDUAL_LN: (mean, rstd) of this A row, prepared in LDS by the kernel
-        if (EPI == TOC3D_EPI_RESIDUAL_LN) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
-        (void)mu; (void)rs;
-        if (epi_is_residual(EPI)) {
-            // the modular residual row and the representative-row test cost an integer division / a load each: once per row
-            const int rr = a.res_mod > 0 ? row % a.res_mod : row;
-            const float* resrow = a.res ? a.res + (int64_t)rr * a.ldr : nullptr;
-            float* orow = reinterpret_cast<float*>(a.out) + (int64_t)row * a.ldo;
-            if (a.res_index) {                           // compact rows whose residual still sits in the token-major stream (no f32 copy was made)
-                const int ti = a.res_index[row];
-                resrow = ti >= 0 ? a.res + (int64_t)ti * a.ldr : orow;
-            }
-            float* reprow = nullptr;
-            if (a.rep_index) { const int ri = a.rep_index[row]; if (ri >= 0) reprow = a.rep_out + (int64_t)ri * a.N; }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (nok[j] == 0) continue;
-                const int col = col0 + j * 16 + g * 4;
-                float raw[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (EPI == TOC3D_EPI_RESIDUAL_LN) raw[r] = rs * (acc[i][j][r] - mu * ccol[j][r]) + bcol[j][r];
-                    else raw[r] = acc[i][j][r] + bcol[j][r];
-                }
-                float sum4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.vec && nok[j] == 4) {
-                    f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sum4[r] = rv[r] + raw[r];
-                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{sum4[0], sum4[1], sum4[2], sum4[3]};
-                    if (reprow) *reinterpret_cast<f32x4*>(reprow + col) = f32x4{raw[0], raw[1], raw[2], raw[3]};
-                } else {
-                    for (int r = 0; r < nok[j]; ++r) {
-                        sum4[r] = (resrow ? resrow[col + r] : 0.f) + raw[r];
-                        orow[col + r] = sum4[r];
-                        if (reprow) reprow[col + r] = raw[r];
-                    }
-                }
-                if (EPI == TOC3D_EPI_RESIDUAL_STATS) {
-                    // the updated residual-stream row also leaves in the act dtype (the next GEMM's A operand, its LayerNorm folded into that
-                    // GEMM) together with the sums of those rounded values
-                    T* arow = reinterpret_cast<T*>(a.out_act) + (int64_t)row * a.ld_act + col;
-                    T o4[4];
-                    float ssum = 0.f, sq = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        o4[r] = to_act<T>(r < nok[j] ? sum4[r] : 0.f);
-                        const float hv = from_act(o4[r]);
-                        ssum += hv;
-                        sq = __builtin_fmaf(hv, hv, sq);
-                    }
-                    if (nok[j] == 4) store4(arow, o4);
-                    else for (int r = 0; r < nok[j]; ++r) arow[r] = o4[r];
-                    gs[i * G + j] = ssum;
-                    gq[i * G + j] = sq;
-                }
-            }
-        } else {
-            T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (nok[j] == 0) continue;
-                const int col = col0 + j * 16 + g * 4;
-                T o4[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float raw = acc[i][j][r] + bcol[j][r];
-                    o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
-                }
-                if (a.vec && nok[j] == 4) store4(orow + col, o4);
-                else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
-            }
-        }
-    }
-}
-
-// Multi-stage pipeline: the LDS ring holds STAGES K-tiles; tile t+STAGES-1 is requested while tile t is
-// multiplied, so a K step no longer exposes an HBM/L2 round trip.  The in-flight global_load_lds are
-// tracked with a *counted* s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain them to
-// vmcnt(0), cdna_hip_programming.md "Pipelining across barriers").  One barrier per K-tile:
-//   wait(tile t landed) -> s_barrier -> request tile t+STAGES-1 into the slot tile t-1 just left -> MFMAs on tile t
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int OCC>
-__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
-    constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
-    constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
-    constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;
-    constexpr int LOADS = (BM + BN) * (RB / 16) / NTHR; // global_load_lds per thread per K-tile
-    constexpr int KS = RB / 32 / (int)sizeof(T);        // 32-wide K steps per K-tile
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r16 = lane & 15, g = lane >> 4;
-
-    const int tiles_n = (a.N + BN - 1) / BN;
-    const int tiles_m = (a.M + BM - 1) / BM;
-    int m0, n0;
-    if (a.order == 0) {
-        const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-        m0 = (tile / tiles_n) * BM;
-        n0 = (tile % tiles_n) * BN;
-    } else {
-        // Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Each XCD owns a band of M-tile rows
-        // whose A panels (band * K bytes, ~1.5 MB) stay resident in its 4 MB L2, and walks the W panels one after the
-        // other (m fastest), so every W panel is fetched from memory once per XCD instead of once per A row-panel.
-        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-        const int r0 = (xcd * tiles_m) >> 3, r1 = ((xcd + 1) * tiles_m) >> 3;
-        const int band = r1 - r0;
-        if (band <= 0 || l >= band * tiles_n) return;
-        m0 = (r0 + l % band) * BM;
-        n0 = (l / band) * BN;
-    }
-
-    const T* A = reinterpret_cast<const T*>(a.A);
-    const T* W = reinterpret_cast<const T*>(a.W);
-    constexpr int BK = RB / (int)sizeof(T);
-    const int nk = a.K / BK;
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // W rows are padded to a multiple of 128 at pack time, A rows are clamped to M-1
-    const int w_max = ((a.N + 127) / 128) * 128 - 1;
-    // EPI_CONV3X3 (necks/cp_fpn.py:124-133 as an implicit GEMM): the A tile of K-tile t is the (ky, kx) = tap t*BK / C neighbour of each
-    // row's pixel, channels (t*BK) % C ..; the 16-byte global_load_lds takes any per-lane source address, so the im2col matrix is never
-    // materialised -- out-of-image taps read a line of zeros.  Each thread's rows are fixed: their (y, x) are decoded once.
-    constexpr int LA = BM * (RB / 16) / NTHR;
-    int cv_m[EPI == TOC3D_EPI_CONV3X3 ? LA : 1], cv_yx[EPI == TOC3D_EPI_CONV3X3 ? LA : 1];
-    if constexpr (EPI == TOC3D_EPI_CONV3X3) {
-#pragma unroll
-        for (int t = 0; t < LA; ++t) {
-            const int r = (t * NTHR + wave * 64 + lane) / (RB / 16);
-            int m = m0 + r;
-            m = m < a.M ? m : a.M - 1;
-            cv_m[t] = m;
-            cv_yx[t] = (((m / a.conv_w) % a.conv_h) << 16) | (m % a.conv_w);
-        }
-    }
-    auto request = [&](int t) {
-        char* slot = smem + (t % STAGES) * STAGE_BYTES;
-        if constexpr (EPI == TOC3D_EPI_CONV3X3) {
-            const int k0 = t * BK, C = (int)a.lda;
-            const int tap = k0 / C, c0 = k0 - tap * C;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-#pragma unroll
-            for (int u = 0; u < LA; ++u) {
-                const int cidx = u * NTHR + wave * 64 + lane;
-                const int r = cidx / (RB / 16), pch = cidx % (RB / 16);
-                const int y2 = (cv_yx[u] >> 16) + dy, x2 = (cv_yx[u] & 0xffff) + dx;
-                const bool in = (unsigned)y2 < (unsigned)a.conv_h && (unsigned)x2 < (unsigned)a.conv_w;
-                // out-of-image taps: any 16 zero bytes (no chunk offset: K-tiles of 256 / 512 bytes would run past a small zero line)
-                const char* src = in ? reinterpret_cast<const char*>(A + (int64_t)(cv_m[u] + dy * a.conv_w + dx) * C + c0) + ((pch ^ swz<RB>(r)) << 4)
-                                     : reinterpret_cast<const char*>(a.zeros);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + (u * NTHR + wave * 64) * 16), 16, 0, 0);
-            }
-        } else {
-            stage_tile<T, BM, RB, NTHR>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
-        }
-        stage_tile<T, BN, RB, NTHR>(W, a.ldw, n0, w_max, t * BK, slot + A_BYTES, wave, lane);
-    };
-    auto multiply = [&](int t) {
-        const char* sA = smem + (t % STAGES) * STAGE_BYTES;
-        const char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            Frag<T> fa[MT], fb[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, s, g, T());
-#pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, s, g, T());
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) mma_step(acc[i][j], fb[j], fa[i]);   // swapped: C^T tile layout, see the epilogue
-        }
-    };
-    // EPI_RESIDUAL_LN -- folded LayerNorm of the A rows: (mean, rstd) per tile row from the partial sums the producing GEMM left (include/toc3d.h),
-    // into a row table behind the operand stages.  Done at kernel start, right after the first operand tiles were requested, so its one
-    // global round trip overlaps theirs.  Four threads per row; thread part p sums slots p, p + 4, ... in sequence, the parts meet in two
-    // butterfly steps; f64.  The order is fixed: the bits do not depend on the tile variant that runs this kernel.
-    f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
-    auto ln_rows_prepare = [&]() {
-        const int nslots = *reinterpret_cast<const int*>(a.stats_in);
-        const f32x2* base = reinterpret_cast<const f32x2*>(a.stats_in + 4);
-        for (int w = tid; w < BM * 4; w += NTHR) {
-            const int r = w >> 2, part = w & 3;
-            int row = m0 + r;
-            row = row < a.M ? row : a.M - 1;
-            const f32x2* sp = base + (int64_t)row * a.stats_in_cap;
-            double s1 = 0.0, s2 = 0.0;
-            for (int sl = part; sl < nslots; sl += 4) {
-                const f32x2 v = sp[sl];
-                s1 += (double)v[0];
-                s2 += (double)v[1];
-            }
-            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
-            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
-            const double mean = s1 * (double)a.ln_inv_n;
-            double var = s2 * (double)a.ln_inv_n - mean * mean;      // biased variance (F.layer_norm)
-            var = var > 0.0 ? var : 0.0;
-            if (part == 0) lnrow[r] = f32x2{(float)mean, 1.0f / sqrtf((float)var + a.ln_eps)};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // table rows written before this wave reaches the K loop's first barrier
-    };
-    if (STAGES == 1) {
-        // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
-        for (int kt = 0; kt < nk; ++kt) {
-            request(kt);
-            if constexpr (epi_ln_in(EPI)) { if (kt == 0) ln_rows_prepare(); }
-            wait_vmcnt<0>();
-            tile_barrier();                              // every wave's pieces of tile kt have landed
-            multiply(kt);
-            tile_barrier();                              // every wave is done reading: the buffer may be overwritten
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < STAGES - 1; ++t)
-            if (t < nk) request(t);
-        if constexpr (epi_ln_in(EPI)) ln_rows_prepare();
-        for (int kt = 0; kt < nk; ++kt) {
-            if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
-            else wait_vmcnt<0>();                                                                   // pipeline tail
-            tile_barrier();
-            if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);
-            multiply(kt);
-        }
-    }
-
-    if constexpr (epi_stats_out(EPI)) {
-        // Row statistics of the act-dtype values this launch wrote, for the LayerNorm folded into the next GEMM (include/toc3d.h).  A slot is
-        // 128 packed columns (SwiGLU: 64 hidden units) or 64 output columns (residual), i.e. always four column groups of the epilogue, and is
-        // built in ONE fixed tree for every tile variant: lane -> its 4 values in order; group = butterfly over the 4 lane groups;
-        // slot = (g0 + g1) + (g2 + g3), combined through LDS whatever wave computed the groups.
-        constexpr int G = epi_stat_groups(EPI, NT);      // groups per wave-tile row
-        constexpr int GW = epi_is_swiglu(EPI) ? 32 : 16; // columns per group
-        constexpr int SLOT = 4 * GW, GPT = BN / GW;      // columns per slot, groups per tile row
-        static_assert(BN % SLOT == 0 && (epi_is_swiglu(EPI) ? NT % 2 == 0 : true), "statistics need N-tiles of whole slots");
-        float gs[MT * G], gq[MT * G];
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq, lnrow + wm * TM);
-        tile_barrier();                                  // every wave is done with the operand tiles (their reads fed MFMAs) and with the row table
-        f32x2* red = reinterpret_cast<f32x2*>(smem);     // [GPT][BM]
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int jp = 0; jp < G; ++jp) {
-                const float s1 = g4_sum(gs[i * G + jp]), s2 = g4_sum(gq[i * G + jp]);
-                if (g == 0) red[(wn * G + jp) * BM + wm * TM + i * 16 + r16] = f32x2{s1, s2};
-            }
-        lds_barrier();
-        f32x2* data = reinterpret_cast<f32x2*>(a.stats + 4);
-        for (int w = tid; w < BM * (GPT / 4); w += NTHR) {
-            const int r = w % BM, sl = w / BM;
-            const int row = m0 + r;
-            if (row >= a.M) continue;
-            const f32x2 v0 = red[(4 * sl) * BM + r], v1 = red[(4 * sl + 1) * BM + r], v2 = red[(4 * sl + 2) * BM + r], v3 = red[(4 * sl + 3) * BM + r];
-            data[(int64_t)row * a.stats_cap + n0 / SLOT + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
-        }
-        if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + SLOT - 1) / SLOT;
-    } else if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) {
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM);
-    } else {
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Phased big-tile kernel (bf16): BM x BN per 512-thread workgroup, ONE workgroup per CU, latency hidden inside the workgroup.
 //
-// The 128x128 family above is bound by the L2 -> LDS fill rate (32 KB per 2.1 MFLOP K-step) and hides
-// latency only through co-resident workgroups.  Here a K-step of a 256x256 tile brings 64 KB for 8.4 MFLOP (half the bytes per
-// FLOP), every wavefront owns a 128x64 block (half the LDS read bytes per FLOP of the 64x32 blocks above), and the K loop is
-// cut into four *phases* per 64-deep K-tile (cdna_hip_programming.md "8-phase" template, re-derived for this ring):
-//
-//   the wave's block = 2 x 2 sub-blocks (a0 | a1 rows) x (b0 | b1 columns); the LDS ring holds two K-tiles, each as four
-//   half-tiles  A0 A1 B0 B1  (A_h = the a_h rows of every wave row, B_h likewise);
-//   phase 1: read B0, A0 | stage A1[t+1] | MFMA a0.b0          phase 3: read A1 | stage A0[t+2] | MFMA a1.b1
-//   phase 2: read B1     | stage B0[t+1] | MFMA a0.b1          phase 4: read B0 | stage B1[t+2], wait | MFMA a1.b0
-//
-//   each phase = [LDS reads + one half-tile of global_load_lds] s_barrier [MFMAs] s_barrier, and the second half of the
-//   wavefronts (waves 4-7, which share the SIMDs of waves 0-3) runs ONE barrier behind the first: on every SIMD one wave is in its
-//   MFMA segment while its partner issues loads, so the matrix pipe and the memory path stay busy from a single workgroup.
-//
-// Hazards (both wave groups, the lagging one included):
-//   RAW  a half-tile is read one phase or more after the counted s_waitcnt vmcnt that retires it (phase 4, once per K-tile: only
-//        the two newest half-tiles may still be in flight) and a barrier every wave has passed;
-//   WAR  a slot is restaged two phases or more after its last read (A0: read ph1 -> restaged ph3; B1: ph2 -> ph4; A1: ph3 -> next
-//        ph1; B0: ph4 -> next ph2), i.e. behind a barrier that follows the readers' own lgkmcnt(0).
-// ---------------------------------------------------------------------------------------------------
-template <int ROWS, int TB, int NTHR>
-TOC3D_DEV void stage_half(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0, int h, char* lds_half, int wave, int lane) {
-    // half-tile h of an operand whose wave blocks are TB rows tall: LDS row lr = (wave-row w) * TB/2 + j  <->  tile row w * TB + h * TB/2 + j
-    constexpr int L = ROWS * 8 / NTHR;
-    static_assert(L * NTHR == ROWS * 8, "half-tile must be a whole number of 16-byte loads per thread");
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-        const int c = i * NTHR + wave * 64 + lane;
-        const int lr = c >> 3, p = c & 7;
-        const int w = lr / (TB / 2), j = lr % (TB / 2);
-        int gr = row0 + w * TB + h * (TB / 2) + j;
-        gr = gr < max_row ? gr : max_row;
-        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ (lr & 7)) << 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_half + (i * NTHR + wave * 64) * 16), 16, 0, 0);
-    }
-}
-
-template <int EPI, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(WM * WN == 8, "eight wavefronts");
-    constexpr int NTHR = 512;
-    constexpr int TM = BM / WM, TN = BN / WN;             // per-wave block
-    constexpr int HM = TM / 2, HN = TN / 2;               // sub-blocks
-    constexpr int MT2 = HM / 16, NT2 = HN / 16;           // MFMA tiles per sub-block
-    static_assert(HM % 16 == 0 && HN % 16 == 0, "sub-blocks are whole MFMA tiles");
-    constexpr int AH = (BM / 2) * 128, BH = (BN / 2) * 128;   // bytes per half-tile (128-byte rows: 64 bf16 of K)
-    constexpr int KT = 2 * AH + 2 * BH;                   // one K-tile in the ring: A0 | A1 | B0 | B1
-    constexpr int LA = (BM / 2) * 8 / NTHR, LB = (BN / 2) * 8 / NTHR;   // global_load_lds per thread per half-tile
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r16 = lane & 15, g = lane >> 4;
-    const bool late = wave >= 4;                          // the group that runs one barrier behind
-
-    const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
-    int m0, n0;
-    if (a.order == 0) {
-        const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-        m0 = (tile / tiles_n) * BM;
-        n0 = (tile % tiles_n) * BN;
-    } else {
-        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-        const int r0 = (xcd * tiles_m) >> 3, r1 = ((xcd + 1) * tiles_m) >> 3;
-        const int band = r1 - r0;
-        if (band <= 0 || l >= band * tiles_n) return;
-        m0 = (r0 + l % band) * BM;
-        n0 = (l / band) * BN;
-    }
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
-    const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
-    const int nk = a.K / 64;
-    const int a_max = a.M - 1, w_max = ((a.N + 127) / 128) * 128 - 1;
-
-    f32x4 acc[2 * MT2][2 * NT2];
-#pragma unroll
-    for (int i = 0; i < 2 * MT2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2 * NT2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    Frag<bf16_t> fa[MT2][2], fb[NT2][2];                  // [tile][32-wide K step]
-
-    auto slot = [&](int t, int kind, int h) -> char* { return smem + (t & 1) * KT + kind * 2 * AH + h * (kind ? BH : AH); };
-    auto stage_a = [&](int t, int h) { stage_half<BM / 2, TM, NTHR>(A, a.lda, m0, a_max, t * 64, h, slot(t, 0, h), wave, lane); };
-    auto stage_b = [&](int t, int h) { stage_half<BN / 2, TN, NTHR>(W, a.ldw, n0, w_max, t * 64, h, slot(t, 1, h), wave, lane); };
-    auto read_a = [&](int t, int h) {
-        const char* base = slot(t, 0, h);
-#pragma unroll
-        for (int i = 0; i < MT2; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_frag<128>(base, wm * HM + i * 16 + r16, ks, g, bf16_t());
-    };
-    auto read_b = [&](int t, int h) {
-        const char* base = slot(t, 1, h);
-#pragma unroll
-        for (int j = 0; j < NT2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = lds_frag<128>(base, wn * HN + j * 16 + r16, ks, g, bf16_t());
-    };
-    auto mfma = [&](auto HA, auto HB) {
-        constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < MT2; ++i)
-#pragma unroll
-                for (int j = 0; j < NT2; ++j) mma_step(acc[ha * MT2 + i][hb * NT2 + j], fb[j][ks], fa[i][ks]);   // swapped: see gemm_epilogue
-        __builtin_amdgcn_s_setprio(0);
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-
-    // ---- prologue: K-tile 0 complete, A0 / B1 of K-tile 1 on their way (what phases 3, 4 of a tile "-1" would have staged) ----
-    stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1);
-    if (nk > 1) { stage_a(1, 0); stage_b(1, 1); wait_vmcnt<LA + LB>(); }
-    else wait_vmcnt<0>();
-    tile_barrier();
-    if (late) tile_barrier();
-
-    for (int t = 0; t < nk; ++t) {
-        const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-        // phase 1
-        read_b(t, 0); read_a(t, 0);
-        if (n1) stage_a(t + 1, 1);
-        tile_barrier();
-        mfma(I0(), I0());
-        tile_barrier();
-        // phase 2
-        read_b(t, 1);
-        if (n1) stage_b(t + 1, 0);
-        tile_barrier();
-        mfma(I0(), I1());
-        tile_barrier();
-        // phase 3
-        read_a(t, 1);
-        if (n2) stage_a(t + 2, 0);
-        tile_barrier();
-        mfma(I1(), I1());
-        tile_barrier();
-        // phase 4: everything of K-tile t+1 that phase 1 reads must have landed (A0, B0; B1 / A1 are older): only A0 / B1 of K-tile t+2,
-        // staged in phase 3 and here, may stay in flight
-        read_b(t, 0);
-        if (n2) { stage_b(t + 2, 1); wait_vmcnt<LA + LB>(); }
-        else wait_vmcnt<0>();
-        tile_barrier();
-        mfma(I1(), I0());
-        tile_barrier();
-    }
-    if (!late) tile_barrier();                            // every wave executes the same number of barriers
-
-    gemm_epilogue<bf16_t, EPI, 2 * MT2, 2 * NT2>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
-}
+// This file: the C ABI of the linear layers, weight packing and the im2col / image kernels.  The GEMM kernels live in gemm_kernels.h and are
+// instantiated by gemm_epi_{plain,residual,swiglu}.hip.
+#include "gemm_kernels.h"
 
 thread_local bool g_bad_variant = false;               // variant cannot serve the requested epilogue
 
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
-void launch_cfg(const GemmArgs& a, hipStream_t s) {
-    // a wave must own whole (w1, w2) 32-column groups; the folded-LayerNorm statistics need N-tiles of whole 128-column slots; the fold is bf16 only
-    constexpr bool unsupported = (epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) ||
-                                 (EPI >= TOC3D_EPI_SWIGLU_STATS && EPI != TOC3D_EPI_CONV3X3 && sizeof(T) != 2);
-    if constexpr (unsupported) {
-        g_bad_variant = true;
-    } else {
-        constexpr int lds = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);   // + the (mean, rstd) row table
-        static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
-        if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds);
-        if (a.K % (RB / (int)sizeof(T)) != 0 || (EPI == TOC3D_EPI_CONV3X3 && a.lda % (RB / (int)sizeof(T)) != 0)) {    // K-tile must divide K (conv: the channel count)
-            if (RB == 128) { g_bad_variant = true; return; }
-            launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s);
-            return;
-        }
-        const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
-        const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
-        toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
-    }
-}
+namespace {
 
-template <int EPI, int BM, int BN, int WM, int WN>
-void launch_phased(const GemmArgs& a, hipStream_t s) {
-    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || EPI >= TOC3D_EPI_SWIGLU_STATS) {   // the phased kernel carries neither the folded-LayerNorm epilogues nor the conv gather
-        g_bad_variant = true;
-    } else {
-        constexpr int lds = 2 * (BM + BN) * 128;              // two K-tiles of 64 bf16
-        static Toc3dLdsAttr attr;
-        attr.ensure(reinterpret_cast<const void*>(&gemm_phased_kernel<EPI, BM, BN, WM, WN>), lds);
-        const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
-        const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;
-        toc3d_launch((gemm_phased_kernel<EPI, BM, BN, WM, WN>), dim3(tiles), dim3(512), lds, s, a);
-    }
-}
-
-// tile / pipeline variants (toc3d_linear_ex `variant`); 0 = heuristic
-template <typename T, int EPI>
-int launch_epi(int variant, GemmArgs a, hipStream_t s) {
-    if (variant >= 100) { a.order = 1; variant -= 100; }      // variant + 100: same tile shape, per-XCD band order
-    if (variant == 0) {
-        // measured on MI355X (tools/gemm_sweep.py): occupancy beats ring depth on these shapes -- single-buffer tiles
-        // (24-32 KiB LDS, >= 3 workgroups per CU); the narrower tile when there are few 128x128 tiles
-        const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-        variant = t128 < 700 ? 17 : 16;
-    }
-    switch (variant) {
-        case 1: launch_cfg<T, EPI, 128, 128, 2>(a, s); break;
-        case 2: launch_cfg<T, EPI, 128, 128, 3>(a, s); break;
-        case 3: launch_cfg<T, EPI, 128, 128, 4>(a, s); break;
-        case 4: launch_cfg<T, EPI, 128, 64, 3>(a, s); break;
-        case 5: launch_cfg<T, EPI, 128, 64, 4>(a, s); break;
-        case 6: launch_cfg<T, EPI, 64, 128, 3>(a, s); break;
-        case 7: launch_cfg<T, EPI, 64, 64, 4>(a, s); break;
-        case 8: launch_cfg<T, EPI, 128, 128, 1>(a, s); break;
-        case 9: launch_cfg<T, EPI, 128, 64, 2>(a, s); break;
-        case 10: launch_cfg<T, EPI, 64, 128, 2>(a, s); break;
-        case 11: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 2, 64>(a, s); else return TOC3D_ERR_ARG; break;
-        case 12: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64>(a, s); else return TOC3D_ERR_ARG; break;
-        case 13: launch_cfg<T, EPI, 128, 64, 1>(a, s); break;
-        case 14: launch_cfg<T, EPI, 64, 64, 2>(a, s); break;
-        case 15: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 2, 4>(a, s); break;      // v8 forced to <= 128 registers: 4 workgroups / CU
-        case 16: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 6 : 1)>(a, s); break;   // 8 waves, 64x32 per wave; bf16 held to 80 registers (6 waves / SIMD = 3 workgroups / CU; the SwiGLU epilogue would take 82)
-        case 17: launch_cfg<T, EPI, 128, 128, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, double buffered (64 KiB)
-        case 18: launch_cfg<T, EPI, 256, 128, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128 tile, double buffered (96 KiB)
-        case 19: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128, single buffer (48 KiB)
-        case 20: launch_cfg<T, EPI, 128, 256, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, 128x256 tile, double buffered
-        case 21: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves 256x256, 128x128... per-wave 64x128
-        // big K-tiles for latency-bound launches (about one tile per CU): fewer, fatter load rounds
-        case 22: launch_cfg<T, EPI, 128, 128, 1, 256, 2, 4, 1>(a, s); break;      // K-tile 128 bf16, 64 KiB
-        case 23: launch_cfg<T, EPI, 128, 128, 1, 512, 2, 4, 1>(a, s); break;      // K-tile 256 bf16, 128 KiB
-        case 24: launch_cfg<T, EPI, 64, 128, 1, 512, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 256, 96 KiB
-        case 25: launch_cfg<T, EPI, 128, 128, 2, 256, 2, 4, 1>(a, s); break;      // K-tile 128, double buffered, 128 KiB
-        case 26: launch_cfg<T, EPI, 64, 128, 1, 256, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 128, 48 KiB
-        case 27: launch_cfg<T, EPI, 64, 64, 1, 512, 2, 2, 1>(a, s); break;        // 64x64 tile, 4 waves, K-tile 256, 64 KiB
-        // deep LDS rings on 8 wavefronts: more bytes continuously in flight per CU (counted vmcnt, one barrier per K-tile)
-        case 28: launch_cfg<T, EPI, 128, 128, 3, 128, 2, 4, 1>(a, s); break;      // 96 KiB
-        case 29: launch_cfg<T, EPI, 128, 128, 4, 128, 2, 4, 1>(a, s); break;      // 128 KiB
-        case 30: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 4, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 64 KiB
-        case 31: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 6, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 96 KiB
-        case 32: launch_cfg<T, EPI, 256, 128, 3, 128, 4, 2, 1>(a, s); break;      // 256x128, 3-deep, 144 KiB
-        case 33: launch_cfg<T, EPI, 128, 64, 4, 128, 2, 4, 1>(a, s); break;       // 128x64, 4-deep, 96 KiB
-        // 16 wavefronts per workgroup: 256-wide tiles (fewer L2->LDS bytes per FLOP) without giving up waves per CU
-        case 34: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 4, 1>(a, s); break;      // 256x128, 64x32 per wave, 48 KiB
-        case 35: launch_cfg<T, EPI, 256, 256, 1, 128, 4, 4, 1>(a, s); break;      // 256x256, 64x64 per wave, 64 KiB
-        case 36: launch_cfg<T, EPI, 128, 256, 1, 128, 4, 4, 1>(a, s); break;      // 128x256, 32x64 per wave, 48 KiB
-        case 37: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 4, 1>(a, s); break;      // 256x256 double buffered, 128 KiB
-        // K-tile 32 rings on 8 wavefronts at the LDS footprint of the single-buffer tile: prefetch inside the workgroup without losing occupancy
-        case 38: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 32 KiB
-        case 39: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 48 KiB
-        case 40: launch_cfg<T, EPI, 128, 256, 1, 128, 2, 4, 1>(a, s); break;      // 128x256, 64x64 per wave, 48 KiB
-        case 41: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 256, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 128x256, K-tile 32 x 2, 48 KiB
-        case 42: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 256, 128, 2, 64, 4, 2, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 256x128, K-tile 32 x 2, 48 KiB
-        // N-tiles that are not powers of two (the vendor library's answer to tile-count quantisation on N = 3072 / 1024)
-        case 43: launch_cfg<T, EPI, 128, 192, 1, 128, 2, 4, 1>(a, s); break;      // 128x192, 64x48 per wave, 40 KiB
-        case 44: launch_cfg<T, EPI, 128, 96, 1, 128, 2, 2, 1>(a, s); break;       // 128x96, 4 waves, 64x48 per wave, 28 KiB
-        case 45: launch_cfg<T, EPI, 128, 192, 2, 128, 2, 4, 1>(a, s); break;      // 128x192 double buffered, 80 KiB
-        case 46: launch_cfg<T, EPI, 128, 96, 2, 128, 2, 2, 1>(a, s); break;       // 128x96 double buffered, 56 KiB
-        case 47: launch_cfg<T, EPI, 128, 192, 2, 128, 4, 2, 1>(a, s); break;      // 128x192 double buffered, 32x96 per wave (serves SwiGLU)
-        case 48: launch_cfg<T, EPI, 128, 192, 3, 128, 2, 4, 1>(a, s); break;      // 128x192, 3-deep ring, 120 KiB
-        case 49: launch_cfg<T, EPI, 192, 128, 2, 128, 2, 4, 1>(a, s); break;      // 192x128 double buffered, 96x32 per wave (serves SwiGLU), 80 KiB
-        case 50: launch_cfg<T, EPI, 192, 128, 1, 128, 2, 4, 1>(a, s); break;      // 192x128 single buffer, 40 KiB
-        case 51: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 8 : 1)>(a, s); break;   // variant 16 held to 64 registers (bf16): FOUR workgroups per CU -- the loop is bound by operand bytes in flight per CU
-        // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
-        case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB
-        case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
-        case 62: if (sizeof(T) == 2) launch_phased<EPI, 128, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
-        case 63: if (sizeof(T) == 2) launch_phased<EPI, 128, 128, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x32 per wave, 64 KiB: two per CU
-        default: return TOC3D_ERR_ARG;
-    }
-    return TOC3D_OK;
-}
-
-template <typename T>
-int launch_gemm(int epi, int variant, const GemmArgs& a, hipStream_t s) {
+int launch_gemm(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s) {
     switch (epi) {
-        case TOC3D_EPI_BIAS: return launch_epi<T, TOC3D_EPI_BIAS>(variant, a, s);
-        case TOC3D_EPI_RESIDUAL: return launch_epi<T, TOC3D_EPI_RESIDUAL>(variant, a, s);
-        case TOC3D_EPI_SWIGLU: return launch_epi<T, TOC3D_EPI_SWIGLU>(variant, a, s);
-        case TOC3D_EPI_GELU: return launch_epi<T, TOC3D_EPI_GELU>(variant, a, s);
-        case TOC3D_EPI_SWIGLU_STATS: return launch_epi<T, TOC3D_EPI_SWIGLU_STATS>(variant, a, s);
-        case TOC3D_EPI_RESIDUAL_LN: return launch_epi<T, TOC3D_EPI_RESIDUAL_LN>(variant, a, s);
-        case TOC3D_EPI_RESIDUAL_STATS: return launch_epi<T, TOC3D_EPI_RESIDUAL_STATS>(variant, a, s);
-        case TOC3D_EPI_SWIGLU_STATS_LN: return launch_epi<T, TOC3D_EPI_SWIGLU_STATS_LN>(variant, a, s);
-        case TOC3D_EPI_CONV3X3: return launch_epi<T, TOC3D_EPI_CONV3X3>(variant, a, s);
+        case TOC3D_EPI_BIAS: case TOC3D_EPI_GELU: case TOC3D_EPI_CONV3X3: return toc3d_gemm_launch_plain(is_bf16, epi, variant, a, s);
+        case TOC3D_EPI_RESIDUAL: case TOC3D_EPI_RESIDUAL_LN: case TOC3D_EPI_RESIDUAL_STATS: return toc3d_gemm_launch_residual(is_bf16, epi, variant, a, s);
+        case TOC3D_EPI_SWIGLU: case TOC3D_EPI_SWIGLU_STATS: case TOC3D_EPI_SWIGLU_STATS_LN: return toc3d_gemm_launch_swiglu(is_bf16, epi, variant, a, s);
         default: return TOC3D_ERR_ARG;
     }
 }
@@ -1003,7 +290,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
         a.out_act = nullptr; a.ld_act = 0;
     }
     g_bad_variant = false;
-    int rc = dtype == TOC3D_BF16 ? launch_gemm<bf16_t>(epilogue, variant, a, as_stream(stream)) : launch_gemm<float>(epilogue, variant, a, as_stream(stream));
+    int rc = launch_gemm(dtype == TOC3D_BF16, epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
     if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab not a multiple of 32, or N-tile not a multiple of 128 for the statistics)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
