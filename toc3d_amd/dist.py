@@ -60,8 +60,9 @@ class FeatureGather:
     ``submit`` first waits for the exchange that last used it (a no-op unless the consumer lags ``depth`` frames behind).
     """
 
-    def __init__(self, shape, device, dtype=torch.bfloat16, depth: int = 2):
+    def __init__(self, shape, device, dtype=torch.bfloat16, depth: int = 2, force_collective: bool = False):
         self.world = _world()
+        self.force_collective = force_collective         # tests: issue the collective even in a one-rank group (exercises the RCCL / stream path)
         self.device = torch.device(device)
         self.depth = depth
         self.send = [torch.empty(tuple(shape), dtype=dtype, device=self.device) for _ in range(depth)]
@@ -75,7 +76,7 @@ class FeatureGather:
         slot = self.n % self.depth
         self._finish(slot)
         self.send[slot].copy_(feat)                      # dtype conversion + layout, on the caller's stream
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             self.out[slot][0].copy_(self.send[slot])
         elif self.cuda:
             ready = torch.cuda.Event()
