@@ -134,6 +134,8 @@ def main():
     # weak scaling (default): every rank gets its own frame (seed = rank) -- independent units, one per rank per step.
     # strong scaling (--frames-total F): F frames per step in total, rank r owns the reference sampler's contiguous chunk
     # (datasets/samplers/distributed_sampler.py:41-44), every frame its own inputs (seed = frame id).
+    assert not args.frames_total or args.frames_total % world == 0, \
+        "--frames-total must be a multiple of the rank count: every rank issues one feature exchange per frame, uneven chunks would not pair up"
     my_frames = list(tdist.frames_for_rank(args.frames_total, rank, world)) if args.frames_total else [rank]
     frames_per_step = args.frames_total if args.frames_total else world
     to_dev = lambda d: {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in d.items()}
