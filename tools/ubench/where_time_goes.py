@@ -60,14 +60,14 @@ if tune:
     m.save_tuning(tune)
 base = measure("baseline (plan, 1 group)")
 measure("baseline again")
-for name in ("toc3d_window_attention", "toc3d_window_attention_pf", "toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_scatter_update",
+for name in ("toc3d_window_attention", "toc3d_window_attention_pf", "toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_gather_merge_ln_ex", "toc3d_scatter_update",
              "toc3d_rebase_layernorm_rows", "toc3d_motion_queries", "toc3d_collapse_query_scorer", "toc3d_window_topk", "toc3d_rank_desc",
              "toc3d_score_tokens"):
     measure(f"skip {name}", skip=(name,))
 measure("skip every row kernel (ln_act, ln_rows, gather, scatter, rebase)",
-        skip=("toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_scatter_update", "toc3d_rebase_layernorm_rows"))
+        skip=("toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_gather_merge_ln_ex", "toc3d_scatter_update", "toc3d_rebase_layernorm_rows"))
 measure("skip all GEMMs", skip=("toc3d_linear_ex", "toc3d_linear", "toc3d_linear_fused"))
-measure("skip everything but GEMMs", skip=("toc3d_window_attention", "toc3d_window_attention_pf", "toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_scatter_update",
+measure("skip everything but GEMMs", skip=("toc3d_window_attention", "toc3d_window_attention_pf", "toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_gather_merge_ln_ex", "toc3d_scatter_update",
                                             "toc3d_rebase_layernorm_rows", "toc3d_motion_queries", "toc3d_collapse_query_scorer", "toc3d_window_topk", "toc3d_rank_desc",
                                             "toc3d_score_tokens"))
 # weights resident in the Infinity Cache: every block reads block 0's GEMM weights (25 MB instead of 600 MB per frame)
@@ -77,7 +77,7 @@ for b in P["blocks"][1:]:
     for k in ("wqkv", "wproj", "w12", "w3"):
         b[k] = P["blocks"][0][k]
 measure("all blocks share block 0's GEMM weights (weights cache-resident)")
-measure("  ... and only GEMMs", skip=("toc3d_window_attention", "toc3d_window_attention_pf", "toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_scatter_update",
+measure("  ... and only GEMMs", skip=("toc3d_window_attention", "toc3d_window_attention_pf", "toc3d_layernorm_act", "toc3d_layernorm_rows", "toc3d_gather_merge_ln", "toc3d_gather_merge_ln_ex", "toc3d_scatter_update",
                                        "toc3d_rebase_layernorm_rows", "toc3d_motion_queries", "toc3d_collapse_query_scorer", "toc3d_window_topk", "toc3d_rank_desc",
                                        "toc3d_score_tokens"))
 for b, s in zip(P["blocks"], saved):
