@@ -117,6 +117,8 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
  * K for EPI_SWIGLU_STATS_LN).  residual_index (int32 [M] or NULL, residual epilogues): output row m takes its residual from row
  * residual_index[m] of `residual` (a compact row whose f32 residual still sits in the token-major stream, toc3d_gather_merge_ln_ex with
  * kept_copy = 0), or, where residual_index[m] < 0, from output row m itself, read in place (representative rows).
+ * EPI_CONV3X3 is reached through toc3d_conv3x3_nhwc below, which is this call with A = the NHWC tensor, lda = C, K = 9 * C, out_act = the zero
+ * line and ld_act = h << 32 | w (hosts that tune the tile variant per shape call it in this form directly).
  * Every other argument as toc3d_linear_ex; epilogues 0-3 ignore the extra arguments. */
 int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
                        const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
