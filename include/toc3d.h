@@ -113,7 +113,8 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
  *                          columns (N-tiles must be multiples of 64); stats_out_cap >= ceil(N / 64).
  *   EPI_SWIGLU_STATS_LN  = EPI_SWIGLU_STATS on A = out_act with W = gamma-scaled interleaved weights, bias = c2, col_sums = c1 in packed column
  *                          order (toc3d_pack_swiglu_lnfold); reads stats_in, writes stats_out (different buffers).
- * stats_out / stats_in: int32 header [4] + f32 [M, cap, 2] each; ln_n = width of the normalised rows (valid hidden units for EPI_RESIDUAL_LN,
+ * stats_out / stats_in: int32 header [4] + f32 [M, cap, 2] each; stats_in_cap may carry the number of slots per row the producer wrote in its
+ * upper 32 bits (cap | slots << 32) when the host knows it, which saves the consumer the dependent read of the header; ln_n = width of the normalised rows (valid hidden units for EPI_RESIDUAL_LN,
  * K for EPI_SWIGLU_STATS_LN).  residual_index (int32 [M] or NULL, residual epilogues): output row m takes its residual from row
  * residual_index[m] of `residual` (a compact row whose f32 residual still sits in the token-major stream, toc3d_gather_merge_ln_ex with
  * kept_copy = 0), or, where residual_index[m] < 0, from output row m itself, read in place (representative rows).

@@ -808,6 +808,12 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
             assert e_fold < 4e-3 and e_fold < 1.5 * e_seq + 1e-4
             assert relerr(rep, delta_ref[rep_index.cpu() >= 0]) < 6e-3            # representative rows capture the raw branch output
         assert torch.equal(out, ref_out) and torch.equal(rep, ref_rep), f"variant {v}: folded epilogue depends on the tile variant"
+    # the host may pass the slot count (upper half of stats_in_cap) instead of letting the kernel read it from the buffer's header: same bits
+    out = res.clone()
+    rep = torch.zeros(nrep, C, device=DEV)
+    lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, 16, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,
+             None, 0, stats, cap | ((2 * Hp + 127) // 128) << 32, c1, Hd, eps, None, 0, None, S())
+    assert torch.equal(out, ref_out) and torch.equal(rep, ref_rep)
     for v, epi in ((47, lib.EPI_SWIGLU_STATS), (9, lib.EPI_SWIGLU_STATS), (60, lib.EPI_SWIGLU_STATS), (60, lib.EPI_RESIDUAL_LN)):
         with pytest.raises(RuntimeError, match="cannot serve"):
             if epi == lib.EPI_SWIGLU_STATS:

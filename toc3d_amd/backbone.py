@@ -549,13 +549,13 @@ class _BackboneBase(nn.Module):
             st, cap = plan["stats"], plan["stats_cap"]
             if self.fold_norm2:
                 self._linear(lib.EPI_SWIGLU_STATS_LN, plan["a"], C, bp["w12"], C, bp["c2_12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                             fused=(st, cap, plan["stats2"], plan["stats2_cap"], bp["c1_12"], C, self.LN_EPS, None, 0, None))
+                             fused=(st, cap, plan["stats2"], plan["stats2_cap"] | (C // 64) << 32, bp["c1_12"], C, self.LN_EPS, None, 0, None))
             else:
                 lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
                 self._linear(lib.EPI_SWIGLU_STATS, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
                              fused=(st, cap, None, 0, None, 0, 0.0, None, 0, None))
             self._linear(lib.EPI_RESIDUAL_LN, plan["hid"], Hp, bp["w3"], bp["w3"].shape[1], bp["c2"], res, C, res, C, 0,
-                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, st, cap, bp["c1"], Hd, self.LN_EPS, None, 0, None))
+                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, st, cap | (-(-2 * Hp // 128)) << 32, bp["c1"], Hd, self.LN_EPS, None, 0, None))
             return
         lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
         self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)

@@ -257,7 +257,8 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
         TOC3D_REQUIRE(stats_out_cap >= (N + slot - 1) / slot, "toc3d_linear: stats_out_cap %lld < ceil(N / %lld)", (long long)stats_out_cap, (long long)slot);
     }
     if (e_ln_in) {
-        TOC3D_REQUIRE(stats_in && ((uintptr_t)stats_in % 16) == 0 && stats_in_cap > 0, "toc3d_linear: epilogue %d needs a 16-byte aligned stats_in buffer", epilogue);
+        TOC3D_REQUIRE(stats_in && ((uintptr_t)stats_in % 16) == 0 && (stats_in_cap & 0xffffffff) > 0 && (stats_in_cap >> 32) <= (stats_in_cap & 0xffffffff),
+                      "toc3d_linear: epilogue %d needs a 16-byte aligned stats_in buffer (and at most stats_in_cap slots per row)", epilogue);
         TOC3D_REQUIRE(bias && col_sums && ln_n > 0, "toc3d_linear: epilogue %d needs bias (c2), col_sums (c1) and ln_n", epilogue);
         TOC3D_REQUIRE(stats_in != stats_out, "toc3d_linear: stats_in and stats_out must be different buffers");
     }
@@ -281,7 +282,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
                      (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0));
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0,
-               stats_out, (int)stats_out_cap, stats_in, (int)stats_in_cap, col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
+               stats_out, (int)stats_out_cap, stats_in, (int)(stats_in_cap & 0xffffffff), (int)(stats_in_cap >> 32), col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
                0, 0, nullptr};
     if (epilogue == TOC3D_EPI_CONV3X3) {
         // A = NHWC act tensor [V, h, w, lda]; ld_act carries h << 32 | w and out_act the zero line (toc3d_conv3x3_nhwc fills them in)

@@ -37,6 +37,7 @@ struct GemmArgs {
     // LayerNorms folded across GEMM boundaries (include/toc3d.h, toc3d_linear_fused): statistics this launch leaves / consumes
     float* stats; int stats_cap;                         // written:  int32 header [4] + f32 [M, stats_cap, 2]
     const float* stats_in; int stats_in_cap;             // consumed: same layout, written by the launch that produced A
+    int stats_in_slots;                                  // slots per row the producer wrote, when the host knows it (0: read the header -- one more dependent round trip)
     const float* c1; float ln_inv_n, ln_eps;             // consumed side: column sums of the gamma-scaled W, 1 / (normalised width), eps
     void* out_act; int64_t ld_act;                       // EPI_RESIDUAL_STATS: act-dtype copy of the f32 output rows (the next GEMM's A operand)
     // EPI_CONV3X3: A is an NHWC act tensor [V, conv_h, conv_w, lda]; the kernel gathers the 3x3 (pad 1) patches itself, K = 9 * lda in (ky, kx, c) order
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     // butterfly steps; f64.  The order is fixed: the bits do not depend on the tile variant that runs this kernel.
     f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
     auto ln_rows_prepare = [&]() {
-        const int nslots = *reinterpret_cast<const int*>(a.stats_in);
+        const int nslots = a.stats_in_slots > 0 ? a.stats_in_slots : *reinterpret_cast<const int*>(a.stats_in);
         const f32x2* base = reinterpret_cast<const f32x2*>(a.stats_in + 4);
         for (int w = tid; w < BM * 4; w += NTHR) {
             const int r = w >> 2, part = w & 3;
