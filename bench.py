@@ -76,6 +76,40 @@ def cpu_baseline(cfg, sd_cpu, inp):
             "sample": "1 frame (6 views @ 800x320) of the same ToC3D_faster workload, eager PyTorch fp32 oracle, after a 1-view warm-up"}
 
 
+def dry_run(args, rank, world, tdist):
+    """See main(): the script's multi-rank control flow with a stand-in step (CPU, gloo).  Not a benchmark."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert not args.frames_total or args.frames_total % world == 0
+    my_frames = list(tdist.frames_for_rank(args.frames_total, rank, world)) if args.frames_total else [rank]
+    frames_per_step = args.frames_total if args.frames_total else world
+    gather = tdist.FeatureGather((6, 4, 2, 5), "cpu", dtype=torch.float32) if world > 1 and not args.sync_gather else None
+    seen = []
+
+    def step():
+        for f in my_frames:
+            time.sleep(0.002 * (1 + rank))
+            n0 = torch.full((6, 4, 2, 5), float(f))
+            if gather is not None:
+                t = gather.submit(n0)
+                if t >= 1:
+                    seen.append(gather.wait(t - 1)[:, 0, 0, 0, 0].tolist())
+            elif world > 1:
+                seen.append(tdist.all_gather_features(n0, dtype=torch.float32)[:, 0, 0, 0, 0].tolist())
+
+    elapsed = tdist.timed_steps(step, args.steps, max(0, args.warmup), "cpu", finish=gather.drain if gather is not None else None)
+    if rank == 0:
+        print(json.dumps({"metric": "LAUNCHER DRY RUN -- not a measurement", "value": frames_per_step * args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                          "scaling": "strong" if args.frames_total else "weak", "vs_baseline": None, "dtype": "none", "data": "stand-in step, no kernels (TOC3D_BENCH_DRY_RUN=1)",
+                          "config": {"workload": "dry run", "frames_per_step": frames_per_step, "last_exchange": seen[-1] if seen else None}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,10 +138,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    from toc3d_amd import dist as tdist
+    if os.environ.get("TOC3D_BENCH_DRY_RUN") == "1":
+        # LAUNCHER DRY RUN (tests/test_cpu_dist.py only): no model, no kernel, no measurement -- a stand-in step on the CPU over gloo, so that
+        # the N > 1 control flow of this script (rank env, frame sharding, overlapped exchange, barriers, max over ranks, the one JSON line of
+        # rank 0) can be exercised where there is no GPU.  The line it prints says so in "data" and can never be mistaken for a result.
+        return dry_run(args, rank, world, tdist)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP extension is the only compute path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    from toc3d_amd import dist as tdist
     dist = None
     if world > 1:
         import torch.distributed as dist

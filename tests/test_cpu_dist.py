@@ -143,3 +143,27 @@ def test_single_process_allgather_is_a_copy():
     f = torch.randn(6, 8, 2, 3)
     g = tdist.all_gather_features(f, dtype=torch.float32)
     assert g.shape == (1, 6, 8, 2, 3) and torch.equal(g[0], f)
+
+
+def test_bench_py_launcher_contract_world2_dry_run():
+    """bench.py launched exactly as the driver launches it for N = 2 (python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 ... bench.py --gpus 2 --steps K --warmup W), in its dry-run mode (stand-in step on gloo, no kernels): rank env
+    handling, frame sharding, the overlapped exchange, barriers, max over ranks and the ONE JSON line of rank 0 -- weak and strong scaling."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TOC3D_BENCH_DRY_RUN="1")
+    for extra, scaling, fps, last in (([], "weak", 2, [0.0, 1.0]), (["--frames-total", "4"], "strong", 4, None)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout                                   # rank 0 prints exactly one JSON line
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == scaling and d["higher_is_better"] is True
+        assert d["config"]["frames_per_step"] == fps and d["value"] > 0 and "DRY RUN" in d["metric"]
+        assert abs(d["value"] - fps * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+        if last is not None:
+            assert d["config"]["last_exchange"] == last                    # every rank's frame, in rank order
