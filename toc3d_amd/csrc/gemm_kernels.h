@@ -134,6 +134,28 @@ TOC3D_DEV void lds_barrier() {
     tile_barrier();
 }
 
+// Epilogue stores.  TOC3D_WT_STORES (experiment, profiles/r02_write_through_stores.txt): write-through (sc1) stores, so the output does not sit
+// dirty in the XCD's L2 until the end-of-kernel release writes it back in one burst.
+#ifdef TOC3D_WT_STORES
+TOC3D_DEV void epi_store4(bf16_t* p, const bf16_t (&v)[4]) {
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    const bf16x4_t x = bf16x4_t{v[0], v[1], v[2], v[3]};
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+TOC3D_DEV void epi_store4(float* p, const float (&v)[4]) {
+#if TOC3D_WT_STORES >= 2
+    const f32x2 lo = f32x2{v[0], v[1]}, hi = f32x2{v[2], v[3]};
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    store4(p, v);
+#endif
+}
+#else
+TOC3D_DEV void epi_store4(bf16_t* p, const bf16_t (&v)[4]) { store4(p, v); }
+TOC3D_DEV void epi_store4(float* p, const float (&v)[4]) { store4(p, v); }
+#endif
+
 // ---- epilogue of one wavefront's (MT*16) x (NT*16) accumulator block whose first row / column are row0 / col0.  The MFMA is issued
 // with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
 // .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
@@ -178,7 +200,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                         }
                     }
                     T* dst = out + (int64_t)row * a.ldo + unit0;
-                    if (a.vec) store4(dst, hs);
+                    if (a.vec) epi_store4(dst, hs);
                     else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
                 }
                 if (epi_stats_out(EPI)) { gs[i * G + jp] = ssum; gq[i * G + jp] = sq; }
@@ -236,7 +258,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                     f32x4 rv = resrow ? *reinterpret_cast<const f32x4*>(resrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sum4[r] = rv[r] + raw[r];
-                    *reinterpret_cast<f32x4*>(orow + col) = f32x4{sum4[0], sum4[1], sum4[2], sum4[3]};
+                    epi_store4(orow + col, sum4);
                     if (reprow) *reinterpret_cast<f32x4*>(reprow + col) = f32x4{raw[0], raw[1], raw[2], raw[3]};
                 } else {
                     for (int r = 0; r < nok[j]; ++r) {
@@ -258,7 +280,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                         ssum += hv;
                         sq = __builtin_fmaf(hv, hv, sq);
                     }
-                    if (nok[j] == 4) store4(arow, o4);
+                    if (nok[j] == 4) epi_store4(arow, o4);
                     else for (int r = 0; r < nok[j]; ++r) arow[r] = o4[r];
                     gs[i * G + j] = ssum;
                     gq[i * G + j] = sq;
@@ -276,7 +298,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                     const float raw = acc[i][j][r] + bcol[j][r];
                     o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
                 }
-                if (a.vec && nok[j] == 4) store4(orow + col, o4);
+                if (a.vec && nok[j] == 4) epi_store4(orow + col, o4);
                 else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
             }
         }

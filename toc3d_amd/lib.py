@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtoc3d_gfx950.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so"))       # TOC3D_LIB: an experimental build beside the shipped one
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
 F32, BF16 = 0, 1
