@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TOC3D_ABI_VERSION 1
+#define TOC3D_ABI_VERSION 3   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
 
 #define TOC3D_OK 0
 #define TOC3D_ERR_ARG (-1)

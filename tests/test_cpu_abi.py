@@ -20,7 +20,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(dll, n), f"{n} declared in include/toc3d.h but not exported"
     l = lib.load()
-    assert l.toc3d_abi_version() == 1
+    hdr = int(re.search(r"#define\s+TOC3D_ABI_VERSION\s+(\d+)", open(lib.HEADER_PATH).read()).group(1))
+    assert l.toc3d_abi_version() == hdr == lib.ABI_VERSION
     assert l.toc3d_motion_weights_floats() > 500000
 
 
@@ -89,7 +90,7 @@ def test_launch_plan_api_validates_without_gpu():
     l = lib.load()
     h = ctypes.c_void_p()
     assert l.toc3d_plan_create(ctypes.addressof(h)) == 0 and h.value
-    assert l.toc3d_plan_lane_stream(0) and l.toc3d_plan_lane_stream(3) and not l.toc3d_plan_lane_stream(16)
+    assert l.toc3d_plan_lane_stream(0) and l.toc3d_plan_lane_stream(3) and not l.toc3d_plan_lane_stream(64)
     assert l.toc3d_plan_num_launches(h.value) == 0
     assert l.toc3d_plan_wait(h.value, 1, 0) == -1 and b"not recording" in l.toc3d_last_error()
     assert l.toc3d_plan_run(h.value, None) == -1 and b"not finalized" in l.toc3d_last_error()
@@ -183,3 +184,53 @@ def test_registration_on_an_mmcv_style_registry():
         importlib.reload(registry)
         registry.register_all()
     assert not registry.HAVE_MMDET
+
+
+def test_copies_of_modules_drop_recorded_plans_and_packed_weights():
+    """A LaunchPlan's launches carry baked device pointers of the module that recorded it: plans are not copyable, and copies /
+    pickles of the modules start without plans, workspaces and packed weights (they re-pack and re-record)."""
+    import copy
+    import pickle
+
+    from toc3d_amd.plan import LaunchPlan
+    lp = LaunchPlan()
+    with pytest.raises(TypeError):
+        copy.deepcopy(lp)
+    with pytest.raises(TypeError):
+        copy.copy(lp)
+    with pytest.raises(TypeError):
+        pickle.dumps(lp)
+    m = toc3d_amd.build_backbone(configs.get("toc3d_tiny"))
+    m._plans = {"k": {"launch": {None: {"cplan": lp}}, "x": torch.zeros(2)}}
+    m._packed = {"dev": "cuda", "blocks": [lp]}
+    m._tuned[(0, 1, 2, 3)] = 16
+    for c in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert c._plans == {} and c._packed is None and c._stream_pool == []
+        assert c._tuned == {(0, 1, 2, 3): 16} and c.pruning_loc == m.pruning_loc
+        assert all(torch.equal(a, b) for a, b in zip(c.state_dict().values(), m.state_dict().values()))
+        assert c.blocks[0].attn.q_proj.weight.data_ptr() != m.blocks[0].attn.q_proj.weight.data_ptr()
+    n = toc3d_amd.build_neck(configs.CPFPN_TINY)
+    n._ws = {(1, 2, 3): {"launch": {7: {"cplan": lp}}}}
+    n._packed = {"w": lp}
+    c = copy.deepcopy(n)
+    assert c._ws == {} and c._packed is None
+    # weights arriving through a parent module (mmcv load_checkpoint on the detector) invalidate the neck's packed state too
+    parent = torch.nn.Module()
+    parent.neck = n
+    parent.load_state_dict({"neck." + k: v for k, v in n.state_dict().items()})
+    assert n._ws == {} and n._packed is None
+
+
+def test_recording_lane_is_thread_local():
+    """lib.stream_ptr() hands out lane handles only on the thread that records (the C side's recording flag is thread_local)."""
+    import threading
+    lib.set_rec_lane(2)
+    try:
+        assert lib.recording() and lib.stream_ptr() == lib.load().toc3d_plan_lane_stream(2)
+        seen = {}
+        t = threading.Thread(target=lambda: seen.update(rec=lib.recording(), lane=lib.rec_lane()))
+        t.start(); t.join()
+        assert seen == {"rec": False, "lane": None}
+    finally:
+        lib.set_rec_lane(None)
+    assert not lib.recording()

@@ -309,6 +309,23 @@ class _BackboneBase(nn.Module):
         self._plans = {}
         return super().load_state_dict(*a, **k)
 
+    # -- copies / pickles: recorded launch plans (native handles with baked device pointers), workspaces and packed weights belong to
+    # THIS instance's buffers; a copy starts without them and re-packs / re-records on its first forward -----------------------------
+    _TRANSIENT = ("_packed", "_plans", "_stream_pool")
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_packed"], d["_plans"], d["_stream_pool"] = None, {}, []
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     # -- helpers ---------------------------------------------------------------------------------------
     @property
     def _dt(self):

@@ -20,7 +20,7 @@ thread_local Toc3dPlan* toc3d_tls_recording = nullptr;
 
 namespace {
 constexpr intptr_t LANE_TAG = 0x70c3d000;        // lane handle = LANE_TAG + lane (never a valid hipStream_t: not 16-byte aligned heap memory)
-constexpr int MAX_LANES = 16;
+constexpr int MAX_LANES = 64;                 // toc3d_amd/plan.py MAX_LANES mirrors this (frames with more lanes launch eagerly)
 }  // namespace
 
 struct Toc3dPlan {

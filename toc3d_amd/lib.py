@@ -8,11 +8,13 @@ from __future__ import annotations
 import ctypes
 import os
 import re
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so"))       # TOC3D_LIB: an experimental build beside the shipped one
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
+ABI_VERSION = 3                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
@@ -91,7 +93,16 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is not built. Run `make -C toc3d_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
-    lib.toc3d_abi_version.restype = _I
+    try:
+        lib.toc3d_abi_version.restype = _I
+        abi = lib.toc3d_abi_version()
+    except AttributeError:
+        abi = None
+    if abi != ABI_VERSION:
+        # checked BEFORE any symbol is bound: an older / experimental build (TOC3D_LIB) fails here with a message, not with a bare
+        # AttributeError on the first entry point it lacks
+        raise RuntimeError(f"{LIB_PATH} reports ABI version {abi}, this package binds ABI {ABI_VERSION} (include/toc3d.h): "
+                           "rebuild the library (`make -C toc3d_amd/csrc`)")
     lib.toc3d_last_error.restype = ctypes.c_char_p
     lib.toc3d_motion_weights_floats.restype = _I64
     lib.toc3d_window_topk_rows.restype = _I64
@@ -104,8 +115,6 @@ def load():
         fn = getattr(lib, name)
         fn.restype = _I
         fn.argtypes = [_CT[c] for c in sig]
-    if lib.toc3d_abi_version() != 1:
-        raise RuntimeError("libtoc3d_gfx950.so ABI version mismatch")
     _lib = lib
     return lib
 
@@ -146,18 +155,29 @@ def prefetch(tensors, workgroups, stream):
     call("toc3d_prefetch", n, p, b, workgroups, stream)
 
 
-# Lane of the launch plan being recorded by this thread (toc3d_amd/plan.py); None = launch on torch's current stream.
-_rec_lane = None
+# Lane of the launch plan being recorded by THIS thread (toc3d_amd/plan.py); None = launch on torch's current stream.  Thread-local
+# like the C side's recording flag (csrc/plan.cpp, toc3d_tls_recording): another Python thread that calls a toc3d op while this one
+# records must get a real stream, not a lane handle the C side would not recognise for that thread.
+_tls = threading.local()
+
+
+def rec_lane():
+    return getattr(_tls, "lane", None)
+
+
+def set_rec_lane(lane):
+    _tls.lane = lane
 
 
 def stream_ptr():
-    """The `stream` argument of a C-ABI call: torch's current HIP stream, or -- while a launch plan is being recorded -- the
-    handle of the current lane (include/toc3d.h, toc3d_plan_lane_stream)."""
-    if _rec_lane is not None:
-        return load().toc3d_plan_lane_stream(_rec_lane)
+    """The `stream` argument of a C-ABI call: torch's current HIP stream, or -- while a launch plan is being recorded by this
+    thread -- the handle of the current lane (include/toc3d.h, toc3d_plan_lane_stream)."""
+    lane = rec_lane()
+    if lane is not None:
+        return load().toc3d_plan_lane_stream(lane)
     import torch
     return torch.cuda.current_stream().cuda_stream
 
 
 def recording() -> bool:
-    return _rec_lane is not None
+    return rec_lane() is not None

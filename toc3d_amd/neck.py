@@ -67,6 +67,27 @@ class CPFPN(nn.Module):
         self._ws = {}
         return super()._apply(fn, *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):
+        # weights that arrive through the parent detector (mmcv load_checkpoint -> detector.load_state_dict) reach this module only
+        # here: the packed weights and the recorded launch plans (they point into them) are stale from then on
+        self._packed = None
+        self._ws = {}
+        return super()._load_from_state_dict(*a, **k)
+
+    # copies / pickles start without workspaces, packed weights and recorded plans (see _BackboneBase.__getstate__)
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_packed"], d["_ws"], d["_stream_pool"] = None, {}, []
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def _pack(self, dev):
         dt = lib.BF16 if self.precision == "bf16" else lib.F32
         tdt = torch.bfloat16 if self.precision == "bf16" else torch.float32

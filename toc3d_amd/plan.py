@@ -20,6 +20,7 @@ import torch
 from . import lib
 
 MODES = {"eager": None, "plan": 0, "graph": 1}     # launch_mode -> toc3d_plan_end mode
+MAX_LANES = 64                                     # csrc/plan.cpp MAX_LANES: frames that need more lanes launch eagerly
 
 
 class EagerExec:
@@ -58,6 +59,17 @@ class LaunchPlan:
     def num_launches(self) -> int:
         return int(lib.load().toc3d_plan_num_launches(self.handle))
 
+    # A plan's recorded launches carry baked device pointers (workspaces, packed weights) of the module that recorded it: a copy
+    # of the handle would replay on the ORIGINAL module's buffers and free the C object twice.  Plans are therefore never copied
+    # or pickled; the owning modules drop them in __deepcopy__ / __getstate__ and re-record on their next forward.
+    def __deepcopy__(self, memo):
+        raise TypeError("LaunchPlan is not copyable: it points into the buffers of the module that recorded it (copy the module; it re-records)")
+
+    __copy__ = lambda self: LaunchPlan.__deepcopy__(self, None)     # noqa: E731
+
+    def __reduce__(self):
+        raise TypeError("LaunchPlan cannot be pickled: it owns a native toc3d_plan_t with baked device pointers")
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
@@ -77,11 +89,11 @@ class RecordExec:
         if lib.recording():
             raise RuntimeError("a launch plan is already being recorded on this thread")
         lib.call("toc3d_plan_begin", self.plan.handle)
-        lib._rec_lane = 0
+        lib.set_rec_lane(0)
         return self
 
     def __exit__(self, et, ev, tb):
-        lib._rec_lane = None
+        lib.set_rec_lane(None)
         if et is not None:
             # leave recording mode on the C side as well; the plan is unusable and the caller drops it
             try:
@@ -96,12 +108,12 @@ class RecordExec:
 
     @contextlib.contextmanager
     def lane(self, i: int):
-        prev = lib._rec_lane
-        lib._rec_lane = i
+        prev = lib.rec_lane()
+        lib.set_rec_lane(i)
         try:
             yield
         finally:
-            lib._rec_lane = prev
+            lib.set_rec_lane(prev)
 
     def wait(self, waiting: int, on: int):
         lib.call("toc3d_plan_wait", self.plan.handle, waiting, on)
@@ -112,7 +124,7 @@ def run_frame(state: dict, launch_mode: str, n_lanes: int, frame_fn, pool: List[
     into a launch plan (second call with this ``state``; the first one runs eagerly, which is also when GEMM tiles are autotuned) and
     from then on replayed with one C call per frame.  ``state`` is the caller's per-(shape, variant) dict."""
     mode = MODES[launch_mode]
-    if mode is None:
+    if mode is None or n_lanes > MAX_LANES:
         frame_fn(EagerExec(n_lanes, pool))
         return
     if state.get("cplan") is not None and state.get("mode") == mode:
