@@ -51,6 +51,7 @@ extern "C" {
 #define TOC3D_EPI_RESIDUAL_STATS 6    /* RESIDUAL + act-dtype copy of the output rows + their per-row statistics (toc3d_linear_fused) */
 #define TOC3D_EPI_SWIGLU_STATS_LN 7   /* SWIGLU_STATS with a LayerNorm of the A rows folded into the epilogue   (toc3d_linear_fused) */
 #define TOC3D_EPI_CONV3X3 8           /* out(f32) = conv3x3(NHWC act tensor) + bias as an implicit GEMM          (toc3d_conv3x3_nhwc) */
+#define TOC3D_EPI_QKV_ROPE 9          /* out(act) = [rope(q) * scale | rope(k) | v] of the fused q|k|v projection  (toc3d_linear_qkv_rope) */
 
 typedef void* toc3d_stream_t;
 
@@ -244,12 +245,39 @@ int toc3d_window_attention_pf(int dtype, const void* qkv, int64_t ldqkv, void* o
  *     arows/aslots [nW, k+1] int32  attention key list: compact rows first (queries = the first acount_q[i] = cap_i
  *                      entries; representative token uses RoPE slot k, :434), then the kept pads as virtual keys
  *                      (arows = -1, aslots = their slot);  acount_k[i] = k + 1
+ *     crow_rc   [rows]  int32   (optional, NULL = not wanted) RoPE position of each compact row as (slot / L) << 16 | (slot % L),
+ *                      representative rows at slot k: the per-row table toc3d_linear_qkv_rope consumes
  */
 int toc3d_rank_desc(const float* scores, int64_t B, int64_t n, int64_t* order, toc3d_stream_t stream);
 int64_t toc3d_window_topk_rows(int64_t V, int64_t h, int64_t w, int64_t L, int64_t k);
 int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int64_t L, int64_t k, int32_t* order,
                       int32_t* tok, float* wgt, int32_t* prow, int32_t* crow_tok, int32_t* rep_index, int32_t* rep_row,
-                      int32_t* arows, int32_t* aslots, int32_t* acount_q, int32_t* acount_k, toc3d_stream_t stream);
+                      int32_t* arows, int32_t* aslots, int32_t* acount_q, int32_t* acount_k, int32_t* crow_rc, toc3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Pre-rotated attention (bf16 path, round 3): RoPE and the q scale move from the attention kernel into the q|k|v projection's epilogue, so the
+ * attention kernel stages K and V by DMA (global_load_lds) with no arithmetic at all.
+ * toc3d_linear_qkv_rope: out act [M, ldo >= N] = [rope(q) * q_scale | rope(k) | v] for the fused projection W = [q; k; v] packed by
+ *   toc3d_pack_weight (N = 3C, heads of 64 dims; backbones/eva_vit.py:97-109, toc3d_eva_vit.py:495-508, eva_utils.py:378-379).  Row m is rotated by
+ *   the table rows rope_rc[m] = r << 16 | c: dims 0..31 of every head by row r of the first table half, dims 32..63 by row c of the second
+ *   (VisionRotaryEmbeddingFast's axial layout, eva_utils.py:362-371; r = slot / rope_side, c = slot % rope_side for window slot `slot`);
+ *   rope_tab holds the compact tables f32 [cos | sin][2, rope_side <= 64, 16] (one entry per frequency pair; extracted from the module's
+ *   freqs_cos / freqs_sin buffers by the host; 16-byte aligned: the kernel copies it into LDS by DMA while its K loop runs).  The rotation runs on the f32 accumulators (+ bias): one rounding to bf16 instead of two.
+ * toc3d_window_attention_rot: toc3d_window_attention_pf on such a buffer.  Same window lists (rows / count / count_k / npad, stride <= 416);
+ *   virtual kept-pad keys (rows[j] < 0) read row slots[j] of pad_rot [window slots, ldqkv] -- the projection of LN(0) = beta rotated for every
+ *   window slot, produced at pack time by toc3d_linear_qkv_rope itself (identical bits to an explicit pad row).  One workgroup per (window, head)
+ *   holds the window's K and V of that head in LDS; scores transposed, P in registers, V read with ds_read_b64_tr_b16.  The prefetch buffers
+ *   (as for toc3d_window_attention_pf; prefetch_workgroups != 0 enables them) are pulled through the caches by the attention wavefronts
+ *   themselves, a few KB each by LDS-DMA while they compute -- no extra workgroups.
+ */
+int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                          int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
+                          float q_scale, toc3d_stream_t stream);
+int toc3d_window_attention_rot(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows, const int32_t* slots,
+                               const int32_t* count, const int32_t* count_k, const int32_t* npad, const void* pad_rot, int64_t stride,
+                               int64_t nwin, int64_t max_count, int64_t num_heads, const float* v_bias,
+                               int64_t n_prefetch, const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int64_t prefetch_workgroups,
+                               toc3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Accelerated block front / back end (backbones/toc3d_eva_vit.py:421-430 and :449-467).

@@ -111,6 +111,35 @@ def test_world2_timed_steps_strong_scaling_chunks():
     assert log0 == log1 == [0.0, 2.0]                                      # the one before: each rank's first frame of the last step
 
 
+def _census_worker(rank, world, port, corrupt, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    feat = torch.randn(6, 8, 4, 5, generator=torch.Generator().manual_seed(rank))
+    if corrupt:
+        # a broken exchange: rank 1's slice arrives damaged on every rank (the census must notice, on every rank)
+        real = tdist.all_gather_features
+
+        def damaged(f, out=None, dtype=torch.bfloat16):
+            g = real(f, out, dtype)
+            g[1, 0, 0, 0, 0] += 1.0
+            return g
+        tdist.all_gather_features = damaged
+    c = tdist.exchange_census(feat, "cpu")
+    q.put((rank, c["ranks_seen"], c["gather_bytes"], c["verified"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_exchange_census_proves_the_collective_saw_every_rank():
+    for corrupt in (False, True):
+        res = _run_world2(_census_worker, corrupt)
+        for rank, seen, nbytes, ok in res:
+            assert seen == [0, 1] and nbytes == 2 * 6 * 8 * 4 * 5 * 2
+            assert ok is (not corrupt)
+    one = tdist.exchange_census(torch.randn(6, 8, 4, 5), "cpu")            # no process group: a one-rank census
+    assert one == {"ranks_seen": [0], "gather_bytes": 6 * 8 * 4 * 5 * 2, "verified": True}
+
+
 def test_feature_gather_single_process_ring():
     g = tdist.FeatureGather((2, 3), "cpu", dtype=torch.float32, depth=2)
     t0 = g.submit(torch.full((2, 3), 1.0))
@@ -167,3 +196,6 @@ def test_bench_py_launcher_contract_world2_dry_run():
         assert abs(d["value"] - fps * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
         if last is not None:
             assert d["config"]["last_exchange"] == last                    # every rank's frame, in rank order
+        # the self-proving part of an N > 1 line: rank census + per-rank checksums through the collective itself
+        assert d["config"]["ranks_seen"] == [0, 1] and d["config"]["gather_verified"] is True
+        assert d["config"]["gather_bytes"] == 2 * 6 * 4 * 2 * 5 * 2         # two ranks x bf16 features

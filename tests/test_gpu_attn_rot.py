@@ -1,0 +1,188 @@
+"""GPU: the pre-rotated attention path of the bf16 build (round 3) against the oracle through the C ABI:
+toc3d_linear_qkv_rope (RoPE + q scale in the q|k|v projection's epilogue) and toc3d_window_attention_rot (K / V staged by DMA,
+V read with the transposing LDS read).  Tolerances as in test_gpu_ops.py: the reference sees the same bf16-rounded operands."""
+import pytest
+import torch
+
+from oracle import toc3d_oracle as O
+from toc3d_amd import configs, lib, synth
+
+from test_gpu_ops import DEV, S, as_act, pack, relerr, rnd
+
+pytestmark = pytest.mark.gpu
+BF, TBF = lib.BF16, torch.bfloat16
+
+
+def compact_tables(cos, sin):
+    """[L*L, 64] reference buffers -> the [2, L, 16] tables toc3d_linear_qkv_rope consumes (what backbone._pack_blocks builds)."""
+    L = int(round(cos.shape[0] ** 0.5))
+    out = []
+    for t in (cos, sin):
+        g = t.view(L, L, 64)
+        out.append(torch.stack([g[:, 0, 0:32:2], g[0, :, 32:64:2]]))
+    return torch.stack(out).contiguous().to(DEV), L
+
+
+def rc_of(slots, L):
+    return (((slots // L) << 16) | (slots % L)).to(torch.int32).contiguous().to(DEV)
+
+
+def rope_ref(x, cos, sin):
+    """eva_utils.py:378-379 with rotate_half over pairs (2t, 2t+1); x [..., 64], cos / sin broadcastable."""
+    x2 = torch.stack([-x[..., 1::2], x[..., 0::2]], -1).flatten(-2)
+    return x * cos + x2 * sin
+
+
+def qkv_rope(a_d, wqkv_p, bqkv, M, C, rc, tab, L, variant=0):
+    out = torch.empty(M, 3 * C, dtype=TBF, device=DEV)
+    lib.call("toc3d_linear_qkv_rope", BF, variant, a_d, C, wqkv_p, C, bqkv, out, 3 * C, M, 3 * C, C, rc, tab, L, 64 ** -0.5, S())
+    return out
+
+
+@pytest.mark.parametrize("C,M,L", [(128, 333, 16), (1024, 777, 20)])
+def test_qkv_projection_with_rope_in_the_epilogue(C, M, L):
+    heads = C // 64
+    cos, sin = synth.rope_tables(L)
+    A, W, b = rnd(M, C, seed=1), rnd(3 * C, C, seed=2, scale=C ** -0.5), rnd(3 * C, seed=3)
+    g = torch.Generator().manual_seed(4)
+    slots = torch.randint(0, L * L, (M,), generator=g)
+    y = (A.to(TBF).double() @ W.to(TBF).double().T + b.double()).view(M, 3, heads, 64)
+    cs, sn = cos[slots].double()[:, None, :], sin[slots].double()[:, None, :]
+    ref = torch.stack([rope_ref(y[:, 0], cs, sn) * 64 ** -0.5, rope_ref(y[:, 1], cs, sn), y[:, 2]], 1).reshape(M, 3 * C)
+    tab, _ = compact_tables(cos, sin)
+    a_d, w_d = as_act(A, TBF), pack(W, BF, TBF)
+    out = qkv_rope(a_d, w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L)
+    assert relerr(out.float(), ref) < 6e-3
+    # one rounding: every element within half a bf16 ulp (+ accumulation order) of the exact value
+    assert ((out.float().cpu().double() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-6).all()
+    plain = torch.empty(M, 3 * C, dtype=TBF, device=DEV)
+    lib.call("toc3d_linear", BF, lib.EPI_BIAS, a_d, C, w_d, C, b.to(DEV), plain, 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0, S())
+    assert torch.equal(out[:, 2 * C:], plain[:, 2 * C:]), "the v columns are the plain projection"
+    for v in (1, 8, 14, 16, 17, 19, 29, 45, 49, 52, 53, 116, 117, 149, 152):
+        assert torch.equal(qkv_rope(a_d, w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L, v), out), f"variant {v} differs"
+
+
+def _proj_weights(sd, pre, C):
+    wqkv = torch.cat([sd[pre + "q_proj.weight"], sd[pre + "k_proj.weight"], sd[pre + "v_proj.weight"]])
+    bqkv = torch.cat([sd[pre + "q_bias"], torch.zeros(C), sd[pre + "v_bias"]])
+    return pack(wqkv, BF, TBF), bqkv.to(DEV)
+
+
+@pytest.mark.parametrize("L", [16, 20])
+def test_rot_attention_dense_windows_with_analytic_pads(L):
+    """Block.forward attention part (eva_vit.py:249-262) on the pre-rotated path: 256 / 400-key windows, ragged edge windows."""
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    C, heads, V, h, w = cfg["embed_dim"], cfg["num_heads"], 2, 20, 50
+    pre = "blocks.2.attn." if L == 20 else "blocks.0.attn."
+    y = rnd(V, h, w, C, seed=7)
+    yw, pad_hw = O.window_partition(y, L)
+    nB = yw.shape[0]
+    sd2 = dict(sd)
+    sd2[pre + "proj.weight"], sd2[pre + "proj.bias"] = torch.eye(C), torch.zeros(C)
+    cos, sin = sd[pre + "rope.freqs_cos"], sd[pre + "rope.freqs_sin"]
+    ref = O.attention(yw.reshape(nB, L * L, C), sd2, pre, heads, cos, sin)
+    ref = O.window_unpartition(ref.reshape(nB, L, L, C), L, pad_hw, (h, w)).reshape(-1, C)
+    M = V * h * w
+    wq, bq = _proj_weights(sd, pre, C)
+    tab, _ = compact_tables(cos, sin)
+    r = torch.arange(h).view(1, h, 1).expand(V, h, w)
+    c = torch.arange(w).view(1, 1, w).expand(V, h, w)
+    rc = (((r % L) << 16) | (c % L)).reshape(-1).to(torch.int32).to(DEV)
+    qkv = qkv_rope(as_act(y.reshape(M, C), TBF), wq, bq, M, C, rc, tab, L)
+    nW, N = nB, L * L
+    rows = torch.empty(nW, N, dtype=torch.int32, device=DEV)
+    slots, count, npad = torch.empty_like(rows), torch.empty(nW, dtype=torch.int32, device=DEV), torch.empty(nW, dtype=torch.int32, device=DEV)
+    lib.call("toc3d_window_map_dense", V, h, w, L, rows, slots, count, npad, S())
+    out = torch.zeros(M, C, dtype=TBF, device=DEV)
+    lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, out, C, rows, slots, count, None, npad, None, N, nW, int(count.max()), heads,
+             sd[pre + "v_bias"].to(DEV), 0, None, None, 0, S())
+    err = relerr(out.float(), ref)
+    assert err < 3e-2, err
+
+
+@pytest.mark.parametrize("n", [33, 77, 103, 129, 161, 201, 256, 300, 401])
+def test_rot_attention_selected_slots(n):
+    """ToC3DEVAAttention (toc3d_eva_vit.py:484-518): compact rows, RoPE rows gathered by slot index -- every instantiation of the kernel."""
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    C, heads, nW = cfg["embed_dim"], cfg["num_heads"], 5
+    pre = "blocks.5.attn."
+    cosT, sinT = synth.rope_tables(21)                          # 441 slots: room for n = 401 distinct ones
+    y = rnd(nW, n, C, seed=11)
+    g = torch.Generator().manual_seed(12)
+    slots = torch.stack([torch.randperm(441, generator=g)[:n] for _ in range(nW)])
+    sd2 = dict(sd)
+    sd2[pre + "proj.weight"], sd2[pre + "proj.bias"] = torch.eye(C), torch.zeros(C)
+    ref = O.attention(y, sd2, pre, heads, cosT[slots], sinT[slots]).reshape(-1, C)
+    M = nW * n
+    wq, bq = _proj_weights(sd, pre, C)
+    tab, L = compact_tables(cosT, sinT)
+    qkv = qkv_rope(as_act(y.reshape(M, C), TBF), wq, bq, M, C, rc_of(slots.reshape(-1), L), tab, L)
+    # scattered compact rows: the kernel must go through the index list
+    perm = torch.randperm(M, generator=g)
+    qkv_s = torch.empty_like(qkv)
+    qkv_s[perm.to(DEV)] = qkv
+    rows = perm.to(torch.int32).reshape(nW, n).to(DEV)
+    count = torch.full((nW,), n, dtype=torch.int32, device=DEV)
+    out = torch.zeros(M, C, dtype=TBF, device=DEV)
+    lib.call("toc3d_window_attention_rot", BF, qkv_s, 3 * C, out, C, rows, None, count, None, None, None, n, nW, n, heads, None, 0, None, None, 0, S())
+    err = relerr(out[perm.to(DEV)].float(), ref)
+    assert err < 3e-2, err
+
+
+def test_rot_attention_virtual_pad_keys_equal_explicit_pad_rows():
+    """toc3d_eva_vit.py:414,421,372: kept padded slots are LN(0) = beta rows.  As virtual keys (rows = -1, k taken from pad_rot[slot]) they must give
+    the real rows exactly the output they get when the pads are explicit rows; ragged query counts per window."""
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    C, heads, nW, n_real, n_pad, L = cfg["embed_dim"], cfg["num_heads"], 4, 37, 60, 16
+    pre = "blocks.3.attn."
+    tab, _ = compact_tables(sd[pre + "rope.freqs_cos"], sd[pre + "rope.freqs_sin"])
+    beta_row = (0.1 * rnd(1, C, seed=21)).to(TBF).float()
+    y = torch.cat([rnd(nW, n_real, C, seed=22), beta_row.expand(nW, n_pad, C)], 1)
+    n = n_real + n_pad
+    gsl = torch.Generator().manual_seed(23)
+    slots = torch.stack([torch.randperm(256, generator=gsl)[:n] for _ in range(nW)]).int()
+    wq, bq = _proj_weights(sd, pre, C)
+    M = nW * n
+    qkv = qkv_rope(as_act(y.reshape(M, C), TBF), wq, bq, M, C, rc_of(slots.reshape(-1).long(), L), tab, L)
+    rows = torch.arange(M, dtype=torch.int32).reshape(nW, n).to(DEV)
+    cnt = torch.full((nW,), n, dtype=torch.int32, device=DEV)
+    full = torch.zeros(M, C, dtype=TBF, device=DEV)
+    lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, full, C, rows, slots.to(DEV), cnt, None, None, None, n, nW, n, heads, None, 0, None, None, 0, S())
+    # the pad row rotated for every window slot, by the same epilogue (what ToC3DEVAViT._pack builds)
+    pad_rot = qkv_rope(as_act(beta_row.expand(256, C).contiguous(), TBF), wq, bq, 256, C, rc_of(torch.arange(256), L), tab, L)
+    rows_v = rows.clone()
+    rows_v[:, n_real:] = -1
+    cq = torch.full((nW,), n_real, dtype=torch.int32, device=DEV)
+    virt = torch.zeros(M, C, dtype=TBF, device=DEV)
+    lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, virt, C, rows_v, slots.to(DEV), cq, cnt, None, pad_rot, n, nW, n_real, heads, None, 0, None, None, 0, S())
+    fr = full.view(nW, n, C)[:, :n_real].float()
+    vr = virt.view(nW, n, C)[:, :n_real].float()
+    assert torch.equal(fr, vr)
+    assert (virt.view(nW, n, C)[:, n_real:] == 0).all(), "pad rows must not be written"
+
+
+def test_rot_attention_is_bit_stable_and_rides_prefetch():
+    """Many workgroups per CU, repeated launches, with and without the weight-prefetch rows in the grid: identical bits every time."""
+    import ctypes
+    V, h, w, L, C, heads = 12, 20, 50, 16, 128, 2
+    M, N = V * h * w, L * L
+    nW = V * 2 * 4
+    qkv = as_act(rnd(M, 3 * C, seed=3), TBF)
+    rows = torch.empty(nW, N, dtype=torch.int32, device=DEV)
+    slots, count, npad = torch.empty_like(rows), torch.empty(nW, dtype=torch.int32, device=DEV), torch.empty(nW, dtype=torch.int32, device=DEV)
+    lib.call("toc3d_window_map_dense", V, h, w, L, rows, slots, count, npad, S())
+    vb = rnd(C, seed=6).to(DEV)
+    junk = torch.randn(1 << 20, device=DEV)
+    ptrs = (ctypes.c_void_p * 1)(junk.data_ptr())
+    nb = (ctypes.c_int64 * 1)(junk.numel() * 4)
+    outs = [torch.zeros(M, C, dtype=TBF, device=DEV) for _ in range(12)]
+    for i, o in enumerate(outs):
+        lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, o, C, rows, slots, count, None, npad, None, N, nW, int(count.max()), heads, vb,
+                 i % 2, ptrs, nb, 64, S())
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.uint8), outs[0].view(torch.uint8))
+    assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0

@@ -286,8 +286,9 @@ def _topk_bufs(V, h, w, L, k):
 
 def _run_topk(scores, V, h, w, L, k):
     b = _topk_bufs(V, h, w, L, k)
+    b["crow_rc"] = torch.full((b["ms"],), -9, dtype=torch.int32, device=DEV)
     lib.call("toc3d_window_topk", scores.to(DEV), V, h, w, L, k, b["order"], b["tok"], b["wgt"], b["prow"], b["crow_tok"], b["rep_index"],
-             b["rep_row"], b["arows"], b["aslots"], b["acount_q"], b["acount_k"], S())
+             b["rep_row"], b["arows"], b["aslots"], b["acount_q"], b["acount_k"], b["crow_rc"], S())
     return b
 
 
@@ -783,7 +784,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
     assert relerr(c1, (gamma * W3).to(tdt).double().sum(1)) < 1e-5 and relerr(c2, (W3.double() * beta.double()).sum(1) + b3.double()) < 1e-5
     cap = 6
     ref_stats = ref_out = ref_rep = None
-    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 116, 117, 126, 149):
+    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 116, 117, 119, 126, 149, 151):      # incl. every variant a shipped table names for this epilogue
         stats = torch.zeros(4 + M * cap * 2, device=DEV)
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd,
@@ -796,7 +797,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
             ref_stats = st.clone()
             assert relerr(st[..., 0].sum(1), hid0.double().sum(1)) < 1e-5 and relerr(st[..., 1].sum(1), (hid0.double() ** 2).sum(1)) < 1e-5
         assert torch.equal(st, ref_stats), f"variant {v}: row statistics depend on the tile variant"
-    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 114, 116, 117, 126, 145):
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 52, 53, 110, 114, 116, 117, 126, 145, 149, 151, 152):
         out = res.clone()
         rep = torch.zeros(nrep, C, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,

@@ -171,6 +171,15 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
     key = (epi, M, N, K)
     var = self._tuned.get(key)
     s = lib.stream_ptr()
+    if epi == lib.EPI_QKV_ROPE:
+        # the rotating epilogue costs what the bias epilogue costs: it shares that epilogue's tile table (no second tuning sweep)
+        rope = fused
+        if var is None:
+            var = self._tuned.get((lib.EPI_BIAS, M, N, K), 0)
+        if var % 100 in (60, 61, 62, 63):                        # the phased tiles do not carry the RoPE tables
+            var = 0
+        lib.call("toc3d_linear_qkv_rope", self._dt, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
+        return
     if var is None:
         var = 0
         if lib.recording():
@@ -285,6 +294,9 @@ class _BackboneBase(nn.Module):
         # (toc3d_window_attention_pf): number of prefetch workgroups, 0 = off
         # (same-box A/B r02: 190.8 frames/s without, 193.8 / 193.4 / 192.8 / 191.6 with 128 / 256 / 512 / 1024 workgroups)
         self.prefetch_weights = int(os.environ.get("TOC3D_PREFETCH", "192" if precision == "bf16" else "0"))
+        # bf16 path, round 3: RoPE + the q scale applied by the q|k|v GEMM's epilogue on the f32 accumulators (toc3d_linear_qkv_rope), attention on the
+        # pre-rotated buffer with K / V staged by DMA (toc3d_window_attention_rot).  The strict-parity fp32 path keeps the reference's sequence.
+        self.attn_rot = precision == "bf16" and os.environ.get("TOC3D_ATTN_ROT", "1") != "0"
         # "plan": the frame's launch sequence is recorded once per (input shape, config) and replayed from C with one call per frame
         # (toc3d_plan_run, HIP streams + events); "graph": the same recording as an explicitly built hipGraph; "eager": every launch
         # issued from Python (what the first forward of a shape always does: it autotunes, and it is what gets recorded next).
@@ -387,6 +399,13 @@ class _BackboneBase(nn.Module):
                 p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
             p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
             p["rope_side"] = self._check_axial_rope(p["cos"], p["sin"])
+            if self.attn_rot:                                     # compact axial tables [2, L, 16]: one entry per frequency pair (toc3d_linear_qkv_rope)
+                L = p["rope_side"]
+                tabs = []
+                for nm in ("cos", "sin"):
+                    t = p[nm].view(L, L, 64)
+                    tabs.append(torch.stack([t[:, 0, 0:32:2], t[0, :, 32:64:2]]))
+                p["rope_tab"] = torch.stack(tabs).contiguous()       # [cos | sin][2, L, 16]
             blocks.append(p)
         torch.cuda.current_stream().synchronize()      # the f32 temporaries above must outlive the pack kernels
         return blocks
@@ -467,6 +486,11 @@ class _BackboneBase(nn.Module):
             plan["stats2_cap"] = C // 64                          # norm2 fold: one slot per 64 residual-stream columns
             plan["stats2"] = torch.zeros(4 + R * plan["stats2_cap"] * 2, dtype=torch.float32, device=dev)
         plan["dense"] = {L: self._dense_map(V, h, w, L, dev) for L in {self.window_size, self.global_window_size}}
+        if self.attn_rot:                                         # RoPE position of every token row per window type: (r % L) << 16 | (c % L)
+            r = torch.arange(h, device=dev, dtype=torch.int32).view(1, h, 1).expand(V, h, w)
+            c = torch.arange(w, device=dev, dtype=torch.int32).view(1, 1, w).expand(V, h, w)
+            for L, d in plan["dense"].items():
+                d["rc"] = (((r % L) << 16) | (c % L)).reshape(-1).contiguous()
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
@@ -541,6 +565,26 @@ class _BackboneBase(nn.Module):
         nb = (ctypes.c_int64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
         lib.call("toc3d_window_attention_pf", *args, len(ts), ptrs, nb, self.prefetch_weights, s)
 
+    def _qkv_attention(self, P, i, plan, M, rope_rc, arows, aslots, count_q, count_k, npad, pad, stride, nwin, max_count, v_bias):
+        """q|k|v projection + windowed attention of block i on plan["a"] [M, C] -> plan["att"] (eva_vit.py:97-113, toc3d_eva_vit.py:495-512)."""
+        bp = P["blocks"][i]
+        C, dt = self.embed_dim, self._dt
+        if self.attn_rot and stride <= 416:
+            self._linear(lib.EPI_QKV_ROPE, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
+                         fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5))
+            import ctypes
+            ts = [bp["wproj"], bp["w12"], bp["w3"]] + ([P["blocks"][i + 1]["wqkv"]] if i + 1 < self.depth else [])
+            if not self.prefetch_weights:
+                ts = []
+            ptrs = (ctypes.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+            nb = (ctypes.c_int64 * max(1, len(ts)))(*[t.numel() * t.element_size() for t in ts])
+            lib.call("toc3d_window_attention_rot", dt, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad, stride, nwin, max_count,
+                     self.num_heads, v_bias, len(ts), ptrs, nb, self.prefetch_weights, lib.stream_ptr())
+            return
+        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0)
+        self._attention(P, i, dt, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad,
+                        stride, nwin, max_count, self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], v_bias, 64 ** -0.5)
+
     def _proj(self, bp, plan, rows, out, rep_out, rep_index, res=None, res_index=None):
         """attn.proj + residual add (eva_vit.py:115,262 / toc3d_eva_vit.py:514,379) into ``out`` f32 [rows, C]: in place by default, or with the
         residual of row m read from row ``res_index[m]`` of ``res`` (the token-major stream; compact rows that were never copied).  With
@@ -588,9 +632,7 @@ class _BackboneBase(nn.Module):
         x = plan["x"]
         dm = plan["dense"][self._block_side(i)]
         lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
-        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0)
-        self._attention(P, i, dt, plan["qkv"], 3 * C, plan["att"], C, dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None,
-                        dm["N"], dm["nW"], dm["max_count"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], bp["v_bias"], 64 ** -0.5)
+        self._qkv_attention(P, i, plan, M, dm.get("rc"), dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None, dm["N"], dm["nW"], dm["max_count"], bp["v_bias"])
         self._proj(bp, plan, M, x, None, None)
         self._mlp(bp, plan, M, x, None, None)
 
@@ -768,6 +810,7 @@ class ToC3DEVAViT(_BackboneBase):
         # projection is a per-block constant, produced here by the same LayerNorm + GEMM kernels as a real row
         C = self.embed_dim
         minus1 = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        keep_alive = []                                    # temporaries of the pack launches, dropped after the synchronize below
         for i, bp in enumerate(P["blocks"]):
             if not self._accelerated(i):
                 continue
@@ -776,6 +819,17 @@ class ToC3DEVAViT(_BackboneBase):
             lib.call("toc3d_layernorm_rows", self._dt, bp["ln1_w"], C, minus1, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, a_row, C, 1, C, s)
             lib.call("toc3d_linear", self._dt, lib.EPI_BIAS, a_row, C, bp["wqkv"], C, bp["bqkv"], bp["pad_qkv"], 3 * C, None, 0, 0, None, None,
                      1, 3 * C, C, 0, s)
+            if self.attn_rot:
+                # ... and, for the pre-rotated attention, that row rotated for EVERY window slot by the same GEMM epilogue that rotates real rows
+                # (bit-identical to an explicit pad row at that slot): pad_rot [L*L, 3C], row = window slot
+                L = bp["rope_side"]
+                sl = torch.arange(L * L, device=dev, dtype=torch.int32)
+                rc = (((sl // L) << 16) | (sl % L)).to(torch.int32).contiguous()
+                a_rep = a_row.expand(L * L, C).contiguous()
+                bp["pad_rot"] = torch.empty(L * L, 3 * C, dtype=self._tdt, device=dev)
+                lib.call("toc3d_linear_qkv_rope", self._dt, 0, a_rep, C, bp["wqkv"], C, bp["bqkv"], bp["pad_rot"], 3 * C, L * L, 3 * C, C,
+                         rc, bp["rope_tab"], L, 64 ** -0.5, s)
+                keep_alive += [a_rep, rc]
         torch.cuda.current_stream().synchronize()
         nfl = lib.load().toc3d_motion_weights_floats()
         # positional_encoding.py:18,32 -- same torch expression as the reference, evaluated on the host
@@ -844,7 +898,8 @@ class ToC3DEVAViT(_BackboneBase):
                                     order=torch.empty(nW, N, **i32), tok=torch.empty(nW, N, **i32), wgt=torch.empty(nW, N, **f32),
                                     prow=torch.empty(nW, N, **i32), crow_tok=torch.empty(ms, **i32), rep_index=torch.empty(ms, **i32),
                                     rep_row=torch.empty(nW, **i32), arows=torch.empty(nW, k + 1, **i32),
-                                    aslots=torch.empty(nW, k + 1, **i32), acount_q=torch.empty(nW, **i32), acount_k=torch.empty(nW, **i32))
+                                    aslots=torch.empty(nW, k + 1, **i32), acount_q=torch.empty(nW, **i32), acount_k=torch.empty(nW, **i32),
+                                    crow_rc=torch.zeros(ms, **i32))
         ns = len(self.pruning_loc)
         plan["pred"] = [torch.empty(M, 2, **f32) for _ in range(ns)]
         plan["u1"] = plan["u2"] = None                    # first-frame scorer scratch, allocated on demand
@@ -925,7 +980,7 @@ class ToC3DEVAViT(_BackboneBase):
         def topk(L):
             sel = plan["sel"][(st, L)]
             lib.call("toc3d_window_topk", score, V, plan["h"], plan["w"], L, sel["k"], sel["order"], sel["tok"], sel["wgt"], sel["prow"],
-                     sel["crow_tok"], sel["rep_index"], sel["rep_row"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], lib.stream_ptr())
+                     sel["crow_tok"], sel["rep_index"], sel["rep_row"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], sel["crow_rc"], lib.stream_ptr())
         # image-level keep/drop lists are only returned to the caller (vis / loss): rank them beside the blocks
         # ... and so is the selection for the window type the next block does not use (first needed two blocks later)
         first = self._block_side(self.pruning_loc[st])
@@ -984,9 +1039,9 @@ class ToC3DEVAViT(_BackboneBase):
         else:
             lib.call("toc3d_gather_merge_ln_ex", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1, s)
-        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, rows, 3 * C, C, 0)
-        self._attention(P, i, dt, plan["qkv"], 3 * C, plan["att"], C, sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"],
-                        None, bp["pad_qkv"], k + 1, nW, sel["max_q"], self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], None, 64 ** -0.5)
+        rot = self.attn_rot and k + 1 <= 416
+        self._qkv_attention(P, i, plan, rows, sel["crow_rc"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], None,
+                            bp["pad_rot"] if rot else bp["pad_qkv"], k + 1, nW, sel["max_q"], None)
         ra, rb = (plan["rep3"], plan["rep4"]) if carry_in else (plan["rep1"], plan["rep2"])
         if self.gathered_residual and not carry_in:      # kept rows were not copied: their residual comes from x through crow_tok
             self._proj(bp, plan, rows, slow, ra, sel["rep_index"], res=plan["x"], res_index=sel["crow_tok"])

@@ -1,0 +1,328 @@
+// Windowed multi-head self-attention on PRE-ROTATED q / k (bf16, gfx950): the RoPE of q and k and the 1/sqrt(d) scale of q were applied
+// by the q|k|v projection's epilogue (gemm_kernels.h, EPI_QKV_ROPE), so this kernel does no arithmetic on its operands before the MFMAs.
+//
+// Reference: backbones/eva_vit.py:101-113 (dense windows), backbones/toc3d_eva_vit.py:499-512 (kept tokens + representative token,
+// RoPE rows gathered by slot index, backbones/eva_utils.py:396-403).
+//
+// One workgroup = one (window, head): the window's K and V rows of that head go HBM/L2 -> LDS by 16-byte global_load_lds straight
+// from the q|k|v buffer (no VGPR round trip, no conversion, no transposing 2-byte stores: the staging of the r02 kernels was ~1300 VALU
+// instructions per wave and 42 % LDS bank conflicts, profiles/r02_attention_pmc_summary.txt), every load of the workgroup in flight at
+// once behind ONE dependent index read.  Both images are row-major [key][64 dims] with the 16-byte chunks of a row XOR-permuted on the
+// SOURCE address (the DMA image is lane-linear, cdna_hip_programming.md rule 21):
+//   K: chunk c of row r at position c ^ (r & 7)             -> conflict-free ds_read_b128 of the S^T = K.Q^T A fragments;
+//   V: chunk c of row r at position c ^ (((r >> 1) & 3) * 2) -> conflict-free ds_read_b64_tr_b16: the hardware transposing read hands
+//      lane (d, g) the values V[4 keys of group g][dim d], i.e. the A fragment of O^T = V^T.P^T, from the row-major image.
+// Scores are computed transposed (a lane owns ONE query, its keys spread over the 4 lane groups), P stays in registers and is the B
+// operand of O^T = V^T.P^T, whose accumulator gives a lane 4 consecutive output dims of its own query: the softmax statistics never
+// leave the lane (one butterfly over the lane groups) and the output leaves in 8-byte stores.
+//
+// Virtual kept-pad keys of accelerated blocks (rows[j] < 0): their q|k|v is the projection of LN(0) = beta, a per-block constant, but
+// the RoPE of its k depends on the window slot -- the host packs pad_rot [window slots, 3C] with the same GEMM epilogue, and the key
+// reads row slots[j] of it.  Dense blocks: the npad zero-pad keys are folded analytically (attention.hip header).
+#include "capi.h"
+#include "common.h"
+
+// Development instrumentation (tools/ubench/attn_timeline.py builds a private copy with -DTOC3D_ATTN_TRACE; the library never defines it):
+// per-workgroup stamps of the 100 MHz real-time counter at entry / indices back / operands landed / compute done / stores acknowledged.
+#ifdef TOC3D_ATTN_TRACE
+__device__ unsigned long long* toc3d_attn_trace_buf;     // [workgroup][8]
+extern "C" int toc3d_attn_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(toc3d_attn_trace_buf), &p, sizeof(p)); }
+#define ATTN_TRACE(slot)                                                                                                        \
+    do {                                                                                                                        \
+        asm volatile("" ::: "memory");                                                                                          \
+        if (threadIdx.x == 0 && toc3d_attn_trace_buf)                                                                           \
+            toc3d_attn_trace_buf[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+        asm volatile("" ::: "memory");                                                                                          \
+    } while (0)
+#else
+#define ATTN_TRACE(slot) do {} while (0)
+#endif
+
+namespace {
+
+constexpr int HD = 64;
+constexpr float NEG_BIG = -1.0e30f;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct AttnRotArgs {
+    const bf16_t* qkv; int64_t ldqkv;
+    bf16_t* out; int64_t ldo;
+    const int32_t* rows; const int32_t* slots; const int32_t* count; const int32_t* count_k; const int32_t* npad;
+    const bf16_t* pad_rot;
+    int64_t stride;
+    int C;
+    const float* v_bias;
+    // weight prefetch riding on this launch: every wavefront pulls pf_instr KB of these buffers through the caches (see prefetch_weights)
+    const char* pf_ptr[4]; int64_t pf_n16[4]; int pf_instr;
+};
+
+// The attention kernels leave HBM idle, and the GEMMs that follow them start on weights that were last touched a frame ago (0.6 GB of bf16
+// weights cycle through a 256 MB Infinity Cache).  Round 2 streamed the next GEMMs' weights through extra "rider" workgroups in front of the
+// attention grid; they held CU slots and registers and delayed the attention workgroups behind them by 3-6 us per launch
+// (profiles/r03_attn_timeline_v2.txt).  Here every wavefront of the attention grid itself requests a few KB of those weights by LDS-DMA into a
+// 1 KB dump area right after its operands have landed: no registers, no extra workgroups, the requests drain while the wave computes.  Wave w
+// of W takes the 1 KB pieces w, w + W, ... (neighbouring waves read neighbouring KB).
+TOC3D_DEV void prefetch_weights(const AttnRotArgs& a, char* dump, int64_t wave_id, int64_t nwaves, int lane) {
+    for (int j = 0; j < a.pf_instr; ++j) {
+        int64_t c = ((int64_t)j * nwaves + wave_id) * 64 + lane;      // 16-byte piece of the concatenated buffers
+        const char* src = nullptr;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            if (!src && c < a.pf_n16[sg]) src = a.pf_ptr[sg] + c * 16;
+            c -= a.pf_n16[sg];
+        }
+        if (!src) src = a.pf_ptr[0];                                  // past the end: any valid line
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dump, 16, 0, 0);
+    }
+}
+
+TOC3D_DEV float g4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+TOC3D_DEV int v_swz(int r) { return ((r >> 1) & 3) << 1; }
+
+// One instantiation serves every window size up to 416 keys.  The softmax is exact and single-pass in effect, but the scores are computed
+// TWICE instead of being held: pass 1 = running max of S^T = K.Q^T over all keys, pass 2 = the same scores again, 32 keys at a time,
+// exp(S - max) straight into the P fragment of O^T = V^T.P^T.  The first version of this kernel kept every score of a query tile in
+// registers (94-176 VGPRs, 3-4 waves per SIMD, fully unrolled per-tile guards): its compute phase was latency-bound at 9-25 us per
+// workgroup (profiles/r03_attn_timeline_v1.txt) although the MFMA work is < 1 us -- dependent ds_read -> MFMA chains with nothing to
+// overlap them.  Recomputing costs 2 extra MFMAs per 16 keys and buys a 72-register kernel: 7 waves per SIMD, ONE query tile per
+// wavefront (the workgroup has as many waves as the window has 16-query tiles, up to 16), so the chains of 16-32 waves per CU overlap.
+constexpr int MAXPC = 8;                         // DMA pieces (8 keys x 128 B) per wave and operand: the host launches >= ceil(keys / 64) waves
+
+__global__ __launch_bounds__(1024, 7) void attn_rot_kernel(AttnRotArgs a) {      // 72 VGPRs: 7 waves per SIMD, 28 per CU
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NW = blockDim.x >> 6;
+    const int head = blockIdx.x, win = (int)blockIdx.y;
+    ATTN_TRACE(0);
+    const int n = a.count[win];
+    if (n == 0) return;
+    const int nkeys = a.count_k ? a.count_k[win] : n;
+    const int NK32 = ((nkeys + 31) >> 5) << 5;   // keys padded to the 32-wide P.V step
+    char* Ks = smem;                             // [NK32][128 B]
+    char* Vs = smem + NK32 * 128;                // [NK32][128 B]
+    const int32_t* rows = a.rows + (int64_t)win * a.stride;
+    const int32_t* slots = a.slots + (int64_t)win * a.stride;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r16 = lane & 15, g = lane >> 4;
+
+    // ---- 1. the one dependent index round trip: rows of this lane's DMA pieces and of its (at most two) query tiles ----
+    const int nmt = (n + 15) >> 4;
+    int krow[MAXPC];                             // >= 0: row of the q|k|v buffer; < 0: virtual pad key, -1 - (window slot)
+#pragma unroll
+    for (int i = 0; i < MAXPC; ++i) {
+        const int piece = i * NW + wave;         // wave-uniform; one piece = 8 keys x 8 chunks = 1 KB per operand
+        krow[i] = 0;
+        if (piece * 8 < NK32) {
+            int key = piece * 8 + (lane >> 3);
+            key = key < nkeys ? key : 0;         // rows past the list alias key 0: finite values, their scores are masked
+            int row = rows[key];
+            if (a.pad_rot) { const int sl = slots[key]; row = row >= 0 ? row : -1 - sl; }
+            krow[i] = row;
+        }
+    }
+    int qrow[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qi = (wave + NW * u) * 16 + r16;
+        qrow[u] = rows[qi < n ? qi : 0];         // the first `count` entries are real rows
+    }
+#ifdef TOC3D_ATTN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_TRACE(1);
+#endif
+    // ---- 2. everything in flight at once: Q fragments to registers, K and V rows to LDS by DMA ----
+    Frag<bf16_t> qf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+            if (wave + NW * u < nmt) qf[u][s2] = read_frag(a.qkv + (int64_t)qrow[u] * a.ldqkv + head * HD + s2 * 32 + g * 8);
+#pragma unroll
+    for (int i = 0; i < MAXPC; ++i) {
+        const int piece = i * NW + wave;
+        if (piece * 8 < NK32) {
+            const int r = piece * 8 + (lane >> 3), p = lane & 7;
+            const bf16_t* src = krow[i] >= 0 ? a.qkv + (int64_t)krow[i] * a.ldqkv : a.pad_rot + (int64_t)(-1 - krow[i]) * a.ldqkv;
+            const char* kb = reinterpret_cast<const char*>(src + a.C + head * HD);
+            const char* vb = reinterpret_cast<const char*>(src + 2 * a.C + head * HD);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kb + ((p ^ (r & 7)) << 4)), (lptr_t)(Ks + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + ((p ^ v_swz(r)) << 4)), (lptr_t)(Vs + piece * 1024), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ATTN_TRACE(2);
+    if (a.pf_instr > 0)                          // dump area: 1 KB behind the V image
+        prefetch_weights(a, Vs + NK32 * 128, ((int64_t)win * gridDim.x + head) * NW + wave, (int64_t)gridDim.y * gridDim.x * NW, lane);
+
+    const int np = a.npad ? a.npad[win] : 0;
+    const int nt16 = NK32 >> 4;
+    // K fragment of 16-key tile t, 32-dim half s2: row t*16 + r16, chunk s2*4 + g (permuted by row & 7 = r16 & 7)
+    const char* kf0 = Ks + r16 * 128 + ((g ^ (r16 & 7)) << 4);
+    const char* kf1 = Ks + r16 * 128 + (((4 + g) ^ (r16 & 7)) << 4);
+    // V^T fragment: this lane addresses 4 dims of key row g*4 + (r16 >> 2) (+ 16 for the second half) of each 32-key chunk; the
+    // chunk permutation depends on that row only, not on the chunk
+    const int vr = g * 4 + (r16 >> 2);
+    const char* vbase = Vs + vr * 128 + (r16 & 1) * 8;
+    const int vsw = v_swz(vr), vch = (r16 & 3) >> 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int mt = wave + NW * u;
+        if (mt >= nmt) break;
+        // ---- pass 1: max over the keys of S^T = K Q^T; lane holds S[q = r16][key = t*16 + g*4 + r] ----
+        float mx = np > 0 ? 0.f : NEG_BIG;
+#pragma unroll 4
+        for (int t = 0; t < nt16; ++t) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<bf16_t> k0, k1;
+            k0.v = *reinterpret_cast<const bf16x8*>(kf0 + t * 2048);
+            k1.v = *reinterpret_cast<const bf16x8*>(kf1 + t * 2048);
+            mma_step(acc, k0, qf[u][0]);
+            mma_step(acc, k1, qf[u][1]);
+            if (t * 16 + 16 > nkeys) {           // only the tail can reach past the key list (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = t * 16 + g * 4 + r < nkeys ? acc[r] : NEG_BIG;
+            }
+            mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
+        }
+        mx = g4_max(mx);
+        // ---- pass 2: the same scores again, 32 keys at a time: P = exp(S - max) feeds O^T = V^T P^T from registers.  Key slot (g, j < 4) =
+        // key c*32 + g*4 + j, (g, j >= 4) = key c*32 + 16 + g*4 + (j - 4) for both operands ----
+        f32x4 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float sum = 0.f;
+#pragma unroll 2
+        for (int c = 0; c < (NK32 >> 5); ++c) {
+            f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            Frag<bf16_t> k00, k01, k10, k11;
+            k00.v = *reinterpret_cast<const bf16x8*>(kf0 + c * 4096);
+            k01.v = *reinterpret_cast<const bf16x8*>(kf1 + c * 4096);
+            k10.v = *reinterpret_cast<const bf16x8*>(kf0 + c * 4096 + 2048);
+            k11.v = *reinterpret_cast<const bf16x8*>(kf1 + c * 4096 + 2048);
+            mma_step(s0, k00, qf[u][0]);
+            mma_step(s1, k10, qf[u][0]);
+            mma_step(s0, k01, qf[u][1]);
+            mma_step(s1, k11, qf[u][1]);
+            if (c * 32 + 32 > nkeys) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s0[r] = c * 32 + g * 4 + r < nkeys ? s0[r] : NEG_BIG;
+                    s1[r] = c * 32 + 16 + g * 4 + r < nkeys ? s1[r] : NEG_BIG;
+                }
+            }
+            float pv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pv[r] = __expf(s0[r] - mx); pv[4 + r] = __expf(s1[r] - mx); }
+            const Frag<bf16_t> pf = make_frag(pv, bf16_t());
+            sum += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const char* p0 = vbase + c * 4096 + (((d * 2 + vch) ^ vsw) << 4);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lptr_t)p0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lptr_t)(p0 + 2048));
+                Frag<bf16_t> vf;
+                vf.v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                mma_step(o[d], vf, pf);          // rows = head dims d*16 + .., columns = queries
+            }
+        }
+        sum = g4_sum(sum);
+        float padw = 0.f;
+        if (np > 0) { padw = (float)np * __expf(-mx); sum += padw; }
+        const float inv = 1.f / sum;
+        const int qi = mt * 16 + r16;
+        if (qi < n) {
+            bf16_t* dst = a.out + (int64_t)qrow[u] * a.ldo + head * HD + g * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {        // o[d][r] = O[q = r16][dim d*16 + g*4 + r]
+                bf16_t o4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = o[d][r];
+                    if (np > 0) v += padw * a.v_bias[head * HD + d * 16 + g * 4 + r];
+                    o4[r] = to_act<bf16_t>(v * inv);
+                }
+                store4(dst + d * 16, o4);
+            }
+        }
+    }
+    ATTN_TRACE(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prefetch DMAs target this workgroup's LDS: they must have landed before it is released
+    ATTN_TRACE(4);
+}
+
+// Wavefronts per workgroup: one 16-query tile per wave where the chip can hold the whole grid at once, two otherwise.  Always a multiple of
+// four: a workgroup's waves are dealt to the four SIMDs in turn, and the kernel's 72 VGPRs admit 7 waves per SIMD -- with 9 waves per
+// workgroup the third workgroup of a CU found no SIMD-balanced home and the launch ran in 1.5 rounds (profiles/r03_attn_timeline_v2.txt).
+void launch_rot(const AttnRotArgs& a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
+    const size_t lds = (size_t)((a.stride + 31) / 32 * 32) * 256 + 1024;      // K image, V image, 1 KB prefetch dump
+    static Toc3dLdsAttr attr;
+    attr.ensure(reinterpret_cast<const void*>(&attn_rot_kernel), 112 * 1024);
+    const int nqt = (int)((max_count + 15) / 16);
+    const int64_t wgs = nwin * num_heads;
+    const int by_lds = (int)(160 * 1024 / (lds > 0 ? lds : 1));
+    int per_cu = (int)((wgs + 255) / 256);                   // workgroups per CU if the whole grid is to be resident
+    per_cu = per_cu < 1 ? 1 : (per_cu > by_lds ? by_lds : per_cu);
+    int quads = 7 / per_cu;                                   // waves per SIMD and workgroup
+    quads = quads < 1 ? 1 : (quads > 4 ? 4 : quads);
+    const int want = (nqt + 3) / 4;                           // one query tile per wave
+    quads = quads > want ? want : quads;
+    int least = ((nqt + 1) / 2 + 3) / 4;                      // two query tiles per wave at most ...
+    const int by_keys = (int)((a.stride + 255) / 256);        // ... and at most MAXPC = 8 DMA pieces of 8 keys per wave
+    least = least < by_keys ? by_keys : least;
+    quads = quads < least ? least : quads;
+    AttnRotArgs b = a;
+    if (b.pf_instr > 0) {                                     // KB per wavefront so that the grid covers the buffers once (at most 8)
+        int64_t kb = 0;
+        for (int i = 0; i < 4; ++i) kb += (b.pf_n16[i] + 63) / 64;
+        const int64_t waves = wgs * 4 * quads;
+        const int64_t per = (kb + waves - 1) / waves;
+        b.pf_instr = (int)(per > 8 ? 8 : per);
+    }
+    toc3d_launch(attn_rot_kernel, dim3((unsigned)num_heads, (unsigned)nwin), dim3(256 * quads), lds, s, b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int toc3d_window_attention_rot(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows, const int32_t* slots,
+                               const int32_t* count, const int32_t* count_k, const int32_t* npad, const void* pad_rot, int64_t stride,
+                               int64_t nwin, int64_t max_count, int64_t num_heads, const float* v_bias,
+                               int64_t n_prefetch, const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int64_t prefetch_workgroups,
+                               toc3d_stream_t stream) {
+    TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_window_attention_rot: bf16 only (the f32 path is toc3d_window_attention)");
+    TOC3D_REQUIRE(qkv && out && rows && count, "toc3d_window_attention_rot: null buffer");
+    TOC3D_REQUIRE(!npad || v_bias, "toc3d_window_attention_rot: npad given without v_bias");
+    TOC3D_REQUIRE(!count_k || (pad_rot && slots), "toc3d_window_attention_rot: count_k given without pad_rot / slots");
+    TOC3D_REQUIRE(num_heads > 0 && nwin >= 0 && max_count >= 0 && stride >= max_count, "toc3d_window_attention_rot: bad dims");
+    TOC3D_REQUIRE(stride <= 416 && max_count <= 512, "toc3d_window_attention_rot: windows of up to 416 keys / 512 queries (use toc3d_window_attention)");
+    const int64_t C = num_heads * HD;
+    TOC3D_REQUIRE(ldqkv >= 3 * C && ldo >= C, "toc3d_window_attention_rot: leading dims too small for head_dim 64");
+    TOC3D_REQUIRE((ldqkv * 2) % 16 == 0 && ((uintptr_t)qkv % 16) == 0 && (!pad_rot || ((uintptr_t)pad_rot % 16) == 0), "toc3d_window_attention_rot: q|k|v rows must be 16-byte aligned");
+    TOC3D_REQUIRE(ldo % 4 == 0 && ((uintptr_t)out % 8) == 0, "toc3d_window_attention_rot: out must be 8-byte aligned with ldo a multiple of 4");
+    TOC3D_REQUIRE(num_heads <= 65535 && nwin <= 65535, "toc3d_window_attention_rot: grid too large");
+    if (nwin == 0 || max_count == 0) return TOC3D_OK;
+    TOC3D_REQUIRE(n_prefetch >= 0 && n_prefetch <= 4 && (n_prefetch == 0 || (prefetch_ptrs && prefetch_bytes)), "toc3d_window_attention_rot: at most 4 prefetch buffers (host arrays)");
+    AttnRotArgs a{(const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, rows, slots ? slots : rows, count, count_k, npad, (const bf16_t*)pad_rot, stride, (int)C, v_bias,
+                  {nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, 0};
+    int64_t pf_total = 0;
+    for (int64_t i = 0; i < n_prefetch; ++i) {
+        TOC3D_REQUIRE(prefetch_bytes[i] >= 0 && ((uintptr_t)prefetch_ptrs[i] % 16) == 0, "toc3d_window_attention_rot: prefetch buffers must be 16-byte aligned");
+        a.pf_ptr[i] = (const char*)prefetch_ptrs[i];
+        a.pf_n16[i] = prefetch_bytes[i] / 16;
+        pf_total += a.pf_n16[i];
+    }
+    a.pf_instr = (pf_total > 0 && prefetch_workgroups != 0) ? 1 : 0;        // launch_rot sizes it
+    launch_rot(a, max_count, num_heads, nwin, as_stream(stream));
+    TOC3D_LAUNCH_CHECK("toc3d_window_attention_rot");
+    return TOC3D_OK;
+}
+
+}  // extern "C"

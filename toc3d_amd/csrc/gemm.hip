@@ -30,6 +30,7 @@ int launch_gemm(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_
         case TOC3D_EPI_BIAS: case TOC3D_EPI_GELU: case TOC3D_EPI_CONV3X3: return toc3d_gemm_launch_plain(is_bf16, epi, variant, a, s);
         case TOC3D_EPI_RESIDUAL: case TOC3D_EPI_RESIDUAL_LN: case TOC3D_EPI_RESIDUAL_STATS: return toc3d_gemm_launch_residual(is_bf16, epi, variant, a, s);
         case TOC3D_EPI_SWIGLU: case TOC3D_EPI_SWIGLU_STATS: case TOC3D_EPI_SWIGLU_STATS_LN: return toc3d_gemm_launch_swiglu(is_bf16, epi, variant, a, s);
+        case TOC3D_EPI_QKV_ROPE: return toc3d_gemm_launch_rope(is_bf16, epi, variant, a, s);
         default: return TOC3D_ERR_ARG;
     }
 }
@@ -283,7 +284,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0,
                stats_out, (int)stats_out_cap, stats_in, (int)(stats_in_cap & 0xffffffff), (int)(stats_in_cap >> 32), col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
-               0, 0, nullptr};
+               0, 0, nullptr, nullptr, nullptr, 0, 1.0f};
     if (epilogue == TOC3D_EPI_CONV3X3) {
         // A = NHWC act tensor [V, h, w, lda]; ld_act carries h << 32 | w and out_act the zero line (toc3d_conv3x3_nhwc fills them in)
         a.conv_h = (int)(ld_act >> 32); a.conv_w = (int)(ld_act & 0xffffffff); a.zeros = out_act;
@@ -304,6 +305,27 @@ int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const v
     TOC3D_REQUIRE(C % 64 == 0, "toc3d_conv3x3_nhwc: the channel count must be a multiple of 64 (one K-tile never straddles two taps)");
     return toc3d_linear_fused(dtype, TOC3D_EPI_CONV3X3, variant, x, C, W, ldw, bias, out, ldo, nullptr, 0, 0, nullptr, nullptr, V * h * w, Cout, 9 * C, 0,
                               nullptr, 0, nullptr, 0, nullptr, 0, 0.f, const_cast<void*>(zeros), (h << 32) | w, nullptr, stream);
+}
+
+int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                          int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
+                          float q_scale, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear_qkv_rope: bf16 only (the f32 path rotates inside toc3d_window_attention)");
+    TOC3D_REQUIRE(A && W && out && rope_rc && rope_tab, "toc3d_linear_qkv_rope: null buffer");
+    TOC3D_REQUIRE(M >= 0 && N > 0 && N % 192 == 0 && K > 0 && K % 64 == 0, "toc3d_linear_qkv_rope: N = 3C with C a multiple of 64, K a multiple of 64");
+    TOC3D_REQUIRE(lda >= K && ldw >= K && ldo >= N && (lda * 2) % 16 == 0 && (ldw * 2) % 16 == 0, "toc3d_linear_qkv_rope: bad leading dims");
+    TOC3D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)rope_tab % 16) == 0, "toc3d_linear_qkv_rope: misaligned buffer");
+    TOC3D_REQUIRE(rope_side > 0 && rope_side <= 64, "toc3d_linear_qkv_rope: rope_side out of range (the tables live in LDS: <= 64)");
+    if (M == 0) return TOC3D_OK;
+    const bool vec = ldo % 4 == 0 && (uintptr_t)out % 8 == 0;
+    GemmArgs a{A, lda, W, ldw, bias, out, ldo, nullptr, 0, 0, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K, 0, 0, vec ? 1 : 0,
+               nullptr, 0, nullptr, 0, 0, nullptr, 0.f, 0.f, nullptr, 0, 0, 0, nullptr, rope_rc, rope_tab, (int)rope_side, q_scale};
+    g_bad_variant = false;
+    const int rc = launch_gemm(1, TOC3D_EPI_QKV_ROPE, variant, a, as_stream(stream));
+    if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear_qkv_rope: bad variant %d", variant); return rc; }
+    if (g_bad_variant) { toc3d_set_error("toc3d_linear_qkv_rope: variant %d cannot serve this epilogue", variant); return TOC3D_ERR_UNSUPPORTED; }
+    TOC3D_LAUNCH_CHECK("toc3d_linear_qkv_rope");
+    return TOC3D_OK;
 }
 
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

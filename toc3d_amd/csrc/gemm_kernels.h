@@ -42,6 +42,10 @@ struct GemmArgs {
     void* out_act; int64_t ld_act;                       // EPI_RESIDUAL_STATS: act-dtype copy of the f32 output rows (the next GEMM's A operand)
     // EPI_CONV3X3: A is an NHWC act tensor [V, conv_h, conv_w, lda]; the kernel gathers the 3x3 (pad 1) patches itself, K = 9 * lda in (ky, kx, c) order
     int conv_h, conv_w; const void* zeros;               // zeros: >= 128 bytes of zeros (the out-of-image taps)
+    // EPI_QKV_ROPE: N = 3C, columns [q | k | v]; q and k are rotated by the row's RoPE position, q scaled (include/toc3d.h, toc3d_linear_qkv_rope)
+    const int32_t* rope_rc;                              // [M] (table row of dims 0..31) << 16 | (table row of dims 32..63)
+    const float* rope_tab;                               // compact axial tables [cos | sin][2][rope_L][16]
+    int rope_L; float rope_scale;
 };
 
 extern thread_local bool g_bad_variant;                // set by a launch_cfg whose tile variant cannot serve the requested epilogue (gemm.hip)
@@ -50,6 +54,28 @@ extern thread_local bool g_bad_variant;                // set by a launch_cfg wh
 int toc3d_gemm_launch_plain(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);      // EPI_BIAS, EPI_GELU, EPI_CONV3X3
 int toc3d_gemm_launch_residual(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);   // EPI_RESIDUAL, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS
 int toc3d_gemm_launch_swiglu(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);     // EPI_SWIGLU, EPI_SWIGLU_STATS, EPI_SWIGLU_STATS_LN
+int toc3d_gemm_launch_rope(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);       // EPI_QKV_ROPE (bf16)
+
+// Development instrumentation (tools/ubench/gemm_timeline.hip builds its own copy of these kernels with -DTOC3D_GEMM_TRACE; the library
+// never defines it): every workgroup leaves the 100 MHz real-time counter at entry, after its K loop and after its epilogue stores have
+// been acknowledged, plus the hardware id of the CU it ran on.
+#ifdef TOC3D_GEMM_TRACE
+__device__ unsigned long long* toc3d_trace_buf;       // [grid][4]
+#define TOC3D_TRACE(slot)                                                                                                   \
+    do {                                                                                                                    \
+        if (threadIdx.x == 0 && toc3d_trace_buf) toc3d_trace_buf[(size_t)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define TOC3D_TRACE_END()                                                                                                   \
+    do {                                                                                                                    \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                    \
+        TOC3D_TRACE(2);                                                                                                     \
+        if (threadIdx.x == 0 && toc3d_trace_buf)                                                                            \
+            toc3d_trace_buf[(size_t)blockIdx.x * 4 + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+    } while (0)
+#else
+#define TOC3D_TRACE(slot) do {} while (0)
+#define TOC3D_TRACE_END() do {} while (0)
+#endif
 
 namespace {
 
@@ -165,7 +191,7 @@ TOC3D_DEV void epi_store4(float* p, const float (&v)[4]) { store4(p, v); }
 // LayerNorm-consuming epilogues: lnrow = (mean, rstd) per tile row, prepared in LDS by the kernel.
 template <typename T, int EPI, int MT, int NT>
 TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, int col0, int r16, int g, float* gs = nullptr,
-                             float* gq = nullptr, const f32x2* lnrow = nullptr) {
+                             float* gq = nullptr, const f32x2* lnrow = nullptr, const int* rope_rcs = nullptr, const float* rope_tab = nullptr) {
     constexpr int G = epi_stat_groups(EPI, NT);
     if (epi_is_swiglu(EPI)) {
         // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
@@ -288,15 +314,41 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
             }
         } else {
             T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
+            int rope_rc = 0;
+            if constexpr (EPI == TOC3D_EPI_QKV_ROPE) rope_rc = rope_rcs[i];          // loaded before the K loop (no dependent global round trip here)
+            (void)rope_rc;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if (nok[j] == 0) continue;
                 const int col = col0 + j * 16 + g * 4;
                 T o4[4];
+                if constexpr (EPI == TOC3D_EPI_QKV_ROPE) {
+                    // RoPE of the q and k columns on the f32 accumulators (eva_utils.py:378-379: out[2t] = x[2t] cos - x[2t+1] sin,
+                    // out[2t+1] = x[2t+1] cos + x[2t] sin, the pair sharing one frequency), q scaled afterwards (eva_vit.py:104-109): the
+                    // attention kernel then stages K and V by DMA with no arithmetic at all.  A lane's 4 columns are two whole pairs of one
+                    // head; a 16-column MFMA tile lies inside one of q / k / v (C is a multiple of 64), so the branch is wave-uniform.
+                    const int Cq = a.N / 3;
+                    float x[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = acc[i][j][r] + bcol[j][r];
+                    if (col < 2 * Cq) {
+                        const int d0 = col & 63, part = d0 >> 5;
+                        const int coord = part ? (rope_rc & 0xffff) : (rope_rc >> 16);
+                        const int off = (part * a.rope_L + coord) * 16 + ((d0 & 31) >> 1);       // tables in LDS: [cos | sin], each [2][L][16]
+                        const f32x2 c2 = *reinterpret_cast<const f32x2*>(rope_tab + off), s2 = *reinterpret_cast<const f32x2*>(rope_tab + 2 * a.rope_L * 16 + off);
+                        const float y0 = x[0] * c2[0] - x[1] * s2[0], y1 = x[1] * c2[0] + x[0] * s2[0];
+                        const float y2 = x[2] * c2[1] - x[3] * s2[1], y3 = x[3] * c2[1] + x[2] * s2[1];
+                        const float sc = col < Cq ? a.rope_scale : 1.0f;
+                        x[0] = y0 * sc; x[1] = y1 * sc; x[2] = y2 * sc; x[3] = y3 * sc;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o4[r] = to_act<T>(x[r]);
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float raw = acc[i][j][r] + bcol[j][r];
                     o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
+                }
                 }
                 if (a.vec && nok[j] == 4) epi_store4(orow + col, o4);
                 else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
@@ -322,6 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, g = lane >> 4;
+    TOC3D_TRACE(0);
 
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tiles_m = (a.M + BM - 1) / BM;
@@ -436,11 +489,35 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // table rows written before this wave reaches the K loop's first barrier
     };
+    // EPI_QKV_ROPE: every lane fetches the RoPE positions of its MT output rows at kernel start, and the compact tables ([cos | sin], 4-5 KB)
+    // come to LDS by DMA while the K loop runs, so that the epilogue has no dependent global round trip (the first version read both from
+    // global memory inside the epilogue: +7 us per q|k|v launch).  Single-buffer tiles: a region behind the operand stage, requested with the
+    // first K-tile (those tiles leave LDS to spare).  Rings: the slot that the last K-tile's iteration would otherwise refill -- no extra LDS,
+    // a second 80 KB workgroup still fits the CU -- requested in front of the last multiply.
+    const float* rope_tab = nullptr;
+    int rope_rcs[EPI == TOC3D_EPI_QKV_ROPE ? MT : 1];
+    auto rope_stage = [&](char* dst) {
+        const int nchunk = a.rope_L * 16;                // 16-byte pieces of [cos | sin]
+        for (int c0 = wave * 64; c0 < nchunk; c0 += NTHR) {
+            int c = c0 + lane;
+            c = c < nchunk ? c : 0;                      // the last instruction's surplus lanes re-read piece 0 into the slack behind the table
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.rope_tab) + c * 16), (lptr_t)(dst + c0 * 16), 16, 0, 0);
+        }
+        rope_tab = reinterpret_cast<const float*>(dst);
+    };
+    if constexpr (EPI == TOC3D_EPI_QKV_ROPE) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = m0 + wm * TM + i * 16 + r16;
+            rope_rcs[i] = a.rope_rc[row < a.M ? row : a.M - 1];
+        }
+    }
     if (STAGES == 1) {
         // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
         for (int kt = 0; kt < nk; ++kt) {
             request(kt);
             if constexpr (epi_ln_in(EPI)) { if (kt == 0) ln_rows_prepare(); }
+            if constexpr (EPI == TOC3D_EPI_QKV_ROPE) { if (kt == 0) rope_stage(smem + STAGE_BYTES); }
             wait_vmcnt<0>();
             tile_barrier();                              // every wave's pieces of tile kt have landed
             multiply(kt);
@@ -456,9 +533,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             else wait_vmcnt<0>();                                                                   // pipeline tail
             tile_barrier();
             if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);
+            if constexpr (EPI == TOC3D_EPI_QKV_ROPE) { if (kt == nk - 1) rope_stage(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES); }   // the slot tile kt - 1 left
             multiply(kt);
         }
+        if constexpr (EPI == TOC3D_EPI_QKV_ROPE) { wait_vmcnt<0>(); tile_barrier(); }
     }
+    TOC3D_TRACE(1);
 
     if constexpr (epi_stats_out(EPI)) {
         // Row statistics of the act-dtype values this launch wrote, for the LayerNorm folded into the next GEMM (include/toc3d.h).  A slot is
@@ -492,9 +572,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + SLOT - 1) / SLOT;
     } else if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) {
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM);
+    } else if constexpr (EPI == TOC3D_EPI_QKV_ROPE) {
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, nullptr, rope_rcs, rope_tab);
     } else {
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
     }
+    TOC3D_TRACE_END();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -553,6 +636,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, g = lane >> 4;
     const bool late = wave >= 4;                          // the group that runs one barrier behind
+    TOC3D_TRACE(0);
 
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
     int m0, n0;
@@ -648,8 +732,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
         tile_barrier();
     }
     if (!late) tile_barrier();                            // every wave executes the same number of barriers
+    TOC3D_TRACE(1);
 
     gemm_epilogue<bf16_t, EPI, 2 * MT2, 2 * NT2>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
+    TOC3D_TRACE_END();
 }
 
 
@@ -661,9 +747,10 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
     if constexpr (unsupported) {
         g_bad_variant = true;
     } else {
-        constexpr int lds = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);   // + the (mean, rstd) row table
+        constexpr int lds_fixed = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);   // + the (mean, rstd) row table
+        const int lds = lds_fixed + (EPI == TOC3D_EPI_QKV_ROPE && STAGES == 1 ? (a.rope_L * 256 + 1023) / 1024 * 1024 : 0);   // single buffer: + the RoPE tables (cos | sin), whole DMA instructions
         static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
-        if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds);
+        if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds_fixed + (EPI == TOC3D_EPI_QKV_ROPE ? 64 * 256 : 0));
         if (a.K % (RB / (int)sizeof(T)) != 0 || (EPI == TOC3D_EPI_CONV3X3 && a.lda % (RB / (int)sizeof(T)) != 0)) {    // K-tile must divide K (conv: the channel count)
             if (RB == 128) { g_bad_variant = true; return; }
             launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s);
@@ -677,7 +764,7 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 template <int EPI, int BM, int BN, int WM, int WN>
 void launch_phased(const GemmArgs& a, hipStream_t s) {
-    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || EPI >= TOC3D_EPI_SWIGLU_STATS) {   // the phased kernel carries neither the folded-LayerNorm epilogues nor the conv gather
+    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || EPI >= TOC3D_EPI_SWIGLU_STATS) {   // the phased kernel carries neither the folded-LayerNorm epilogues, the conv gather nor the RoPE tables
         g_bad_variant = true;
     } else {
         constexpr int lds = 2 * (BM + BN) * 128;              // two K-tiles of 64 bf16
@@ -755,8 +842,9 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 48: launch_cfg<T, EPI, 128, 192, 3, 128, 2, 4, 1>(a, s); break;      // 128x192, 3-deep ring, 120 KiB
         case 49: launch_cfg<T, EPI, 192, 128, 2, 128, 2, 4, 1>(a, s); break;      // 192x128 double buffered, 96x32 per wave (serves SwiGLU), 80 KiB
         case 50: launch_cfg<T, EPI, 192, 128, 1, 128, 2, 4, 1>(a, s); break;      // 192x128 single buffer, 40 KiB
-        case 52: launch_cfg<T, EPI, 192, 192, 1, 128, 2, 4, 1>(a, s); break;      // 192x192 single buffer, 96x48 per wave, 48 KiB: 512 tiles for q|k|v at M = 6000 (one per slot at two per CU)
-        case 53: launch_cfg<T, EPI, 192, 192, 2, 128, 2, 4, 1>(a, s); break;      // 192x192 double buffered, 96 KiB
+        // (the rotating q|k|v epilogue is held to 128 registers -- two workgroups per CU like the other epilogues: unconstrained it took 138, ONE workgroup per CU and 83 instead of 51 us at M = 6000)
+        case 52: launch_cfg<T, EPI, 192, 192, 1, 128, 2, 4, (EPI == TOC3D_EPI_QKV_ROPE ? 4 : 1)>(a, s); break;      // 192x192 single buffer, 96x48 per wave, 48 KiB: 512 tiles for q|k|v at M = 6000 (one per slot at two per CU)
+        case 53: launch_cfg<T, EPI, 192, 192, 2, 128, 2, 4, (EPI == TOC3D_EPI_QKV_ROPE ? 4 : 1)>(a, s); break;      // 192x192 double buffered, 96 KiB
         case 51: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 8 : 1)>(a, s); break;   // variant 16 held to 64 registers (bf16): FOUR workgroups per CU -- the loop is bound by operand bytes in flight per CU
         // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
         case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(1024) void window_topk_kernel(const float* __restri
                                                            int32_t* __restrict__ prow, int32_t* __restrict__ crow_tok,
                                                            int32_t* __restrict__ rep_index, int32_t* __restrict__ rep_row,
                                                            int32_t* __restrict__ arows, int32_t* __restrict__ aslots,
-                                                           int32_t* __restrict__ acount_q, int32_t* __restrict__ acount_k) {
+                                                           int32_t* __restrict__ acount_q, int32_t* __restrict__ acount_k,
+                                                           int32_t* __restrict__ crow_rc) {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     constexpr int WORKERS = 256;
     const int N = L * L;
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(1024) void window_topk_kernel(const float* __restri
                 pr = off + j;
                 crow_tok[pr] = t;
                 rep_index[pr] = -1;
+                if (crow_rc) crow_rc[pr] = ((slot / L) << 16) | (slot % L);     // RoPE position of the compact row (toc3d_linear_qkv_rope)
             }
             arows[(int64_t)win * kk + j] = pr;
             aslots[(int64_t)win * kk + j] = slot;
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(1024) void window_topk_kernel(const float* __restri
         crow_tok[rr] = -2;
         rep_index[rr] = win;
         rep_row[win] = rr;
+        if (crow_rc) crow_rc[rr] = ((k / L) << 16) | (k % L);
         arows[(int64_t)win * kk + cap - 1] = rr;
         aslots[(int64_t)win * kk + cap - 1] = k;                 // toc3d_eva_vit.py:434
         acount_q[win] = cap;
@@ -639,7 +642,7 @@ int64_t toc3d_window_topk_rows(int64_t V, int64_t h, int64_t w, int64_t L, int64
 
 int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int64_t L, int64_t k, int32_t* order,
                       int32_t* tok, float* wgt, int32_t* prow, int32_t* crow_tok, int32_t* rep_index, int32_t* rep_row,
-                      int32_t* arows, int32_t* aslots, int32_t* acount_q, int32_t* acount_k, toc3d_stream_t stream) {
+                      int32_t* arows, int32_t* aslots, int32_t* acount_q, int32_t* acount_k, int32_t* crow_rc, toc3d_stream_t stream) {
     TOC3D_REQUIRE(scores && order && tok && wgt && prow && crow_tok && rep_index && rep_row && arows && aslots && acount_q && acount_k,
                   "toc3d_window_topk: null buffer");
     TOC3D_REQUIRE(V > 0 && h > 0 && w > 0 && L > 0 && L <= 64, "toc3d_window_topk: bad dims");
@@ -650,7 +653,7 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
     static Toc3dLdsAttr topk_attr;
     if (lds > 64 * 1024) topk_attr.ensure(reinterpret_cast<const void*>(&window_topk_kernel), 96 * 1024);
     toc3d_launch(window_topk_kernel, dim3(nW), dim3(1024), lds, as_stream(stream), scores, (int)V, (int)h, (int)w,
-                       (int)L, (int)k, order, tok, wgt, prow, crow_tok, rep_index, rep_row, arows, aslots, acount_q, acount_k);
+                       (int)L, (int)k, order, tok, wgt, prow, crow_tok, rep_index, rep_row, arows, aslots, acount_q, acount_k, crow_rc);
     TOC3D_LAUNCH_CHECK("toc3d_window_topk");
     return TOC3D_OK;
 }

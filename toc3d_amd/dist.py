@@ -113,6 +113,33 @@ class FeatureGather:
             self._finish(s)
 
 
+def exchange_census(feat: torch.Tensor, device, dtype=torch.bfloat16) -> dict:
+    """One VERIFIED feature exchange, so that a multi-GPU run proves by itself that the collective saw every rank: each rank all-gathers
+    (rank id, bytes sent, checksum of the bits it sent) with the same collective that moves the features, then recomputes the checksum of
+    every slice of the gathered tensor and compares it with what that slice's sender announced.  Returns ``ranks_seen`` (the rank ids found
+    in the gathered records, in slot order), ``gather_bytes`` (bytes every rank receives per exchange) and ``verified`` (AND over all ranks)."""
+    world = _world()
+    rank = dist.get_rank() if world > 1 else 0
+    send = feat.to(dtype).contiguous()
+    got = all_gather_features(feat, dtype=dtype)
+
+    def checksum(t):                                     # order-independent, exact: the 16-bit patterns summed as integers
+        return int(t.contiguous().view(torch.int16).to(torch.int64).sum().item())
+    mine = torch.tensor([rank, send.numel() * send.element_size(), checksum(send)], dtype=torch.int64, device=send.device)
+    rec = torch.empty(world, 3, dtype=torch.int64, device=send.device)
+    if world > 1:
+        dist.all_gather_into_tensor(rec.flatten(), mine)
+    else:
+        rec[0].copy_(mine)
+    rec = rec.cpu()
+    ok = rec[:, 0].tolist() == list(range(world)) and all(checksum(got[r]) == int(rec[r, 2]) for r in range(world)) \
+        and all(int(rec[r, 1]) == send.numel() * send.element_size() for r in range(world))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=send.device)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return {"ranks_seen": [int(v) for v in rec[:, 0].tolist()], "gather_bytes": int(rec[:, 1].sum()), "verified": bool(int(flag.item()) == 1)}
+
+
 def pin_rank_to_cores(local_rank: int, local_world: int) -> Optional[List[int]]:
     """Give every rank of a node its own contiguous slice of the host cores this process may use (the launch path is one
     host thread per rank; without pinning the eight ranks' threads migrate across sockets).  Returns the slice, or None

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
 ABI_VERSION = 3                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
 
 _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
@@ -41,7 +41,9 @@ _SIGS = {
     "toc3d_window_attention": "iplplppppppllllpplpfp",
     "toc3d_window_attention_pf": "iplplppppppllllpplpf" + "lppl" + "p",
     "toc3d_rank_desc": "pllpp",
-    "toc3d_window_topk": "plllllpppppppppppp",
+    "toc3d_window_topk": "plllllppppppppppppp",
+    "toc3d_linear_qkv_rope": "iiplplppllllpplfp",
+    "toc3d_window_attention_rot": "iplplppppppllllp" + "lppl" + "p",
     "toc3d_gather_merge_ln": "iplppppllllppfpplp",
     "toc3d_gather_merge_ln_ex": "iplppppllllppfppllp",
     "toc3d_scatter_update": "plpplllpppppp",
