@@ -534,6 +534,29 @@ def main():
             res["parity_path"] = {"precision": "fp32 (v_mfma_f32_16x16x4_f32, exact f32 products)", "value": frames_per_step * k32 / e32, "unit": "frames/s",
                                   "ms_per_step": 1e3 * e32 / k32, "steps": k32,
                                   "parity": "rel. max err 5e-6 vs the reference's fp32 features, kept-token IoU 1.0 (tests/test_gpu_e2e.py, tests/golden/vitl_*.npz)"}
+        if not args.no_parity_path and args.precision == "bf16" and world == 1:
+            # ... and the parity-grade FAST path: the same f32 buffers and kernels, the linear layers' products as three bf16 MFMAs on (hi, lo)
+            # operand splits (precision="fp32x3"; <= 1e-3 vs the reference on every golden case, tests/test_gpu_e2e.py / test_gpu_parity_bf16.py)
+            mx3 = toc3d_amd.build_backbone(dict(cfg, precision="fp32x3"))
+            mx3.load_state_dict(sd_cpu)
+            mx3 = mx3.to(dev).eval()
+            mx3.alias_outputs, mx3.launch_mode = True, args.launch
+            nx3 = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision="fp32x3"))
+            nx3.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG))
+            nx3 = nx3.to(dev).eval()
+            nx3.alias_outputs, nx3.launch_mode = True, args.launch
+            tx3 = os.path.join(ROOT, "toc3d_amd", "tuned", f"{args.config}_{H}x{W}_fp32x3.json")
+            if os.path.exists(tx3):
+                mx3.load_tuning(tx3)
+                nx3._tuned.update(mx3._tuned)
+            model, neck = mx3, nx3
+            step()
+            torch.cuda.synchronize()
+            kx3 = max(3, min(args.steps, 10))
+            ex3 = tdist.timed_steps(step, kx3, 2, dev)
+            res["parity_path_fast"] = {"precision": "fp32x3 (f32 buffers; a.w = hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16, f32 accumulate)",
+                                       "value": frames_per_step * kx3 / ex3, "unit": "frames/s", "ms_per_step": 1e3 * ex3 / kx3, "steps": kx3,
+                                       "parity": "<= 1e-3 rel. max err vs the reference's fp32 features on every full-size golden case (tests/test_gpu_e2e.py::test_vitl_fp32_matches_reference[fp32x3])"}
         if not args.no_other_configs and world == 1 and args.config == "toc3d_faster" and (H, W) == (320, 800) and not args.frames_total:
             # BASELINE.json configs 3 and 4, driver-timed in the same line: the dense EVA_ViT baseline (keep ratio 1.0) and ToC3D_faster at 6 x 1600 x 640
             res["other_configs"] = [side_leg("eva_dense", 320, 800, args, dev, sd_cpu, tdist), side_leg("toc3d_faster", 640, 1600, args, dev, sd_cpu, tdist)]

@@ -40,6 +40,14 @@ extern "C" {
 /* dtype */
 #define TOC3D_DTYPE_F32 0
 #define TOC3D_DTYPE_BF16 1
+/* Linear layers only (toc3d_linear*, toc3d_conv3x3_nhwc): buffers and packed weights exactly as for TOC3D_DTYPE_F32, but every product a.w is
+ * formed on the bf16 matrix cores as hi.hi + hi.lo + lo.hi of the operands' (hi, lo) bf16 splits, f32 accumulate -- relative error of a product
+ * <= ~2^-16 instead of exact, 3 bf16 MFMAs instead of 8 f32 ones per 16x16x32 step.  The "parity-grade fast" precision (precision="fp32x3" of the
+ * host modules): every other kernel runs its f32 form. */
+#define TOC3D_DTYPE_F32X3 2
+/* ... and with a THREE-way split (hi, mid, lo = all 24 mantissa bits) and six products hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi: f32-grade
+ * products (dropped terms <= 2^-26) from 6 bf16 MFMAs instead of 8 f32 ones (precision="fp32x6"). */
+#define TOC3D_DTYPE_F32X6 3
 
 /* toc3d_linear epilogues */
 #define TOC3D_EPI_BIAS 0      /* out(act)  = A.W^T + bias                                            */
@@ -345,6 +353,12 @@ int toc3d_collapse_query_scorer(const float* mq, const float* w_in, const float*
 int toc3d_score_tokens(const float* x, int64_t C, const float* mask, const float* wc, const float* bc, const float* gumbel,
                        int64_t V, int64_t T, int64_t views_per_frame, float* pred, float* score, float* mask_out,
                        toc3d_stream_t stream);
+
+/* Gumbel noise for the soft masks when the caller injects none (backbones/toc3d_utils.py:145-147: F.gumbel_softmax draws -log(E), E ~ Exp(1), in
+ * eval too): out f32 [n] = -log(-log(U)), U from Philox4x32-10 keyed by `seed` with counter (state[0], element / 4).  state = uint64 [2] in device
+ * memory, zero-initialised by the caller: state[0] is the frame counter, advanced by ONE per launch by the kernel itself (state[1] is its
+ * ticket), so a recorded launch plan draws fresh, reproducible noise on every replay without any host-side argument changing. */
+int toc3d_gumbel_noise(float* out, int64_t n, uint64_t seed, uint64_t* state, toc3d_stream_t stream);
 
 /* First-frame scorer pieces (ScoreBasedTokenSelector.score, backbones/toc3d_utils.py:114-129): the two big
  * Linear layers run through toc3d_linear (GELU epilogue); these cover the rest.

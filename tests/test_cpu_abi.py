@@ -40,6 +40,8 @@ def test_ctypes_signatures_match_header():
                 sig += "p"
             elif a.startswith("int64_t"):
                 sig += "l"
+            elif a.startswith("uint64_t"):
+                sig += "L"
             elif a.startswith("int "):
                 sig += "i"
             elif a.startswith("float "):
@@ -234,3 +236,19 @@ def test_recording_lane_is_thread_local():
     finally:
         lib.set_rec_lane(None)
     assert not lib.recording()
+
+
+def test_product_forward_has_no_test_switches():
+    """forced_scores / block_hook live in toc3d_amd.testing (a test-only subclass), not in the product forward."""
+    import inspect
+
+    from toc3d_amd.backbone import ToC3DEVAViT
+    from toc3d_amd.testing import InstrumentedToC3DEVAViT, instrument
+    sig = inspect.signature(ToC3DEVAViT.forward)
+    assert "forced_scores" not in sig.parameters and "gumbel_noise" in sig.parameters
+    m = toc3d_amd.build_backbone(configs.get("toc3d_tiny"))
+    assert not hasattr(m, "block_hook") and m._instrumented is False
+    with pytest.raises(TypeError, match="test instrument"):
+        ToC3DEVAViT.forward(m, torch.zeros(2, 3, 320, 800), forced_scores=[])
+    im = instrument(m)
+    assert im is m and isinstance(m, InstrumentedToC3DEVAViT) and m._instrumented is True and "forced_scores" in inspect.signature(type(m).forward).parameters

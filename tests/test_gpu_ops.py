@@ -957,3 +957,41 @@ def test_gathered_residual_equals_the_shortcut_copy():
         outs[kept_copy] = (short.clone(), rep.clone(), a.clone())
     for t0, t1 in zip(outs[1], outs[0]):
         assert bool(torch.isfinite(t1.float()).all()) and torch.equal(t0, t1)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1000, 384, 192), (6000, 1024, 768), (37, 3072, 1024), (3276, 1024, 2752)])
+def test_linear_bf16x3_products_on_f32_operands(M, N, K):
+    """TOC3D_DTYPE_F32X3: f32 buffers, every product formed as hi.hi + hi.lo + lo.hi on the bf16 matrix cores.  Against an f64 reference the
+    error must sit at the 2^-16 class (1e-5 relative to the output scale), 100x below plain bf16 and within ~10x of the exact-f32 MFMA path;
+    all epilogues it serves, all its tile variants bit-identical."""
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = A.double() @ W.double().T + b.double()
+    a_d, w_d = as_act(A, torch.float32), pack(W, lib.F32, torch.float32)
+    Kp = a_d.shape[1]
+    outs = {}
+    for dt in (lib.F32, lib.F32X3, lib.F32X6):
+        out = torch.empty(M, N, device=DEV)
+        lib.call("toc3d_linear", dt, lib.EPI_BIAS, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, S())
+        outs[dt] = out
+    e32, ex3, ex6 = relerr(outs[lib.F32], ref), relerr(outs[lib.F32X3], ref), relerr(outs[lib.F32X6], ref)
+    print(f"[bf16x3 {M}x{N}x{K}] rel max err: exact f32 MFMA {e32:.2e}   bf16 x 3 {ex3:.2e}   bf16 x 6 {ex6:.2e}")
+    assert ex3 < 2e-5 and e32 < 1e-5 and ex6 < 2 * e32 + 1e-7      # the three-way split is f32-grade
+    for v in (1, 8, 16, 17, 22, 26, 49, 117, 122):
+        o6 = torch.empty(M, N, device=DEV)
+        lib.call("toc3d_linear_ex", lib.F32X6, lib.EPI_BIAS, v, a_d, Kp, w_d, Kp, b.to(DEV), o6, N, None, 0, 0, None, None, M, N, Kp, 0, S())
+        assert torch.equal(o6, outs[lib.F32X6]), f"x6 variant {v} differs"
+    res = rnd(M, N, seed=4).to(DEV)
+    base = None
+    for v in (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 116, 117, 122, 126):
+        out = torch.empty(M, N, device=DEV)
+        lib.call("toc3d_linear_ex", lib.F32X3, lib.EPI_BIAS, v, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, S())
+        assert torch.equal(out, outs[lib.F32X3]), f"variant {v} differs"
+        o32 = res.clone()
+        lib.call("toc3d_linear_ex", lib.F32X3, lib.EPI_RESIDUAL, v, a_d, Kp, w_d, Kp, b.to(DEV), o32, N, o32, N, 0, None, None, M, N, Kp, 0, S())
+        base = o32.clone() if base is None else base
+        assert torch.equal(o32, base)
+    assert relerr(base, ref + res.cpu().double()) < 2e-5
+    lib.call("toc3d_linear", lib.F32X3, lib.EPI_GELU, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, S())
+    assert relerr(out, torch.nn.functional.gelu(ref)) < 2e-5
+    with pytest.raises(RuntimeError, match="bf16 x 3"):
+        lib.call("toc3d_linear_fused", lib.F32X3, lib.EPI_SWIGLU_STATS, 0, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, *lib.NO_FUSED, S())

@@ -66,7 +66,8 @@ def test_scorer_variants_get_their_own_recordings():
     for inp, prev in seq:
         assert same(run(eager, cfg, inp, prev), run(replay, cfg, inp, prev))
     st = next(iter(replay._plans.values()))["launch"]
-    assert set(st) == {(False, "ts32"), (True, "ts64"), (True, "ts32")} and all(v["cplan"] is not None for v in st.values())
+    # (prev_exists, timestamp staging buffer, Gumbel noise drawn on the device): the injected-noise runs of this test record the three below
+    assert set(st) == {(False, "ts32", False), (True, "ts64", False), (True, "ts32", False)} and all(v["cplan"] is not None for v in st.values())
 
 
 @pytest.mark.parametrize("mode", ["plan", "graph"])
@@ -128,3 +129,50 @@ def test_recording_refuses_real_streams():
     lib.call("toc3d_copy_bytes", y, x, 4096, torch.cuda.current_stream().cuda_stream)
     with pytest.raises(RuntimeError, match="lane handle"):
         lib.call("toc3d_plan_end", p.handle, 0)
+
+
+def test_device_side_gumbel_draw_is_part_of_the_plan_and_has_gumbel_statistics():
+    """Production calls inject no noise: the draw (toc3d_utils.py:145-147, -log of Exp(1) samples) is a kernel INSIDE the recorded frame, keyed by a
+    device-side frame counter -- every replay draws fresh noise, the same (seed, frame) reproduces, and the samples follow Gumbel(0, 1)."""
+    import math
+    n = 1 << 20
+    out = torch.empty(n, device=DEV)
+    state = torch.zeros(2, dtype=torch.int64, device=DEV)
+    lib.call("toc3d_gumbel_noise", out, n, 1234, state, lib.stream_ptr())
+    a = out.clone()
+    assert state.tolist() == [1, 0]                                   # the launch advanced the frame counter and reset its ticket
+    lib.call("toc3d_gumbel_noise", out, n, 1234, state, lib.stream_ptr())
+    b = out.clone()
+    assert state.tolist() == [2, 0] and not torch.equal(a, b)
+    state.zero_()
+    lib.call("toc3d_gumbel_noise", out, n, 1234, state, lib.stream_ptr())
+    assert torch.equal(out, a), "same (seed, frame counter) -> same noise"
+    state.zero_()
+    lib.call("toc3d_gumbel_noise", out, n, 99, state, lib.stream_ptr())
+    assert not torch.equal(out, a)
+    for x in (a, b):
+        x = x.double().cpu()
+        assert bool(torch.isfinite(x).all())
+        assert abs(x.mean().item() - 0.5772156649) < 5e-3 and abs(x.var().item() - math.pi ** 2 / 6) < 1.5e-2
+        xs, _ = torch.sort(x)
+        cdf = torch.exp(-torch.exp(-xs))                               # Gumbel(0, 1)
+        ks = (cdf - (torch.arange(n, dtype=torch.float64) + 0.5) / n).abs().max().item()
+        assert ks < 3e-3, ks                                           # Kolmogorov-Smirnov distance at n = 2^20: ~1.4e-3 at the 5 % level
+    assert abs(torch.corrcoef(torch.stack([a[:-1], a[1:]]))[0, 1].item()) < 5e-3
+    # inside the model: un-injected calls replay the recorded frame and still see new masks every frame
+    cfg = configs.get("toc3d_tiny")
+    m = toc3d_amd.build_backbone(dict(cfg, precision="fp32"))
+    m.load_state_dict(synth.make_state_dict(cfg))
+    m = m.to(DEV).eval()
+    inp = synth.make_inputs(cfg, views_per_frame=2)
+    d = lambda t: t.to(DEV)
+    masks = []
+    for _ in range(5):
+        o = m(d(inp["x"]), temp_queries=d(inp["temp_queries"]), prev_exists=True, temp_ref_points=d(inp["temp_ref_points"]), temp_vel=d(inp["temp_vel"]),
+              temp_timestamp=d(inp["temp_timestamp"]), temp_ego_pose=d(inp["temp_ego_pose"]), ego_pose_inv=d(inp["ego_pose_inv"]))
+        masks.append(o.token_masks[0].clone())
+    key = next(iter(m._plans))
+    st = m._plans[key]["launch"][(True, "ts64" if inp["temp_timestamp"].dtype == torch.float64 else "ts32", True)]
+    assert st.get("cplan") is not None, "frames 3-5 were replayed from the recorded plan"
+    assert all(not torch.equal(masks[i], masks[j]) for i in range(5) for j in range(i))
+    assert int(m._plans[key]["stage"]["rng"][0].item()) == 5

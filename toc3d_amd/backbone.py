@@ -12,7 +12,8 @@ C ABI (``include/toc3d.h``); no torch op touches activations on the hot path.  P
 memory, streams and parameter bookkeeping only.  There is no CPU fallback: a non-CUDA input raises.
 
 Extra (non-reference) constructor kwarg: ``precision`` = ``"bf16"`` (bf16 MFMA operands, f32 accumulate,
-f32 residual stream) or ``"fp32"`` (exact-f32 MFMA, the strict-parity path).
+f32 residual stream), ``"fp32"`` (exact-f32 MFMA, the strict-parity path) or ``"fp32x3"`` (f32 buffers everywhere, the linear
+layers' products as three bf16 MFMAs on (hi, lo) operand splits: parity-grade at several times the fp32 path's speed).
 Extra forward kwarg: ``gumbel_noise`` (list of 3 tensors (B*Nv, T, 2)) to make the stochastic soft mask
 (``toc3d_utils.py:147``) reproducible; when omitted the noise is drawn on the device like the reference does.
 """
@@ -160,7 +161,9 @@ _flush = None                   # 256 MB scratch shared by all models: evicts L2
 
 
 _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 152, 163),
-             lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126)}
+             lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126),
+             lib.F32X3: (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 114, 116, 117, 122, 126, 149)}
+_VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3]
 
 def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED):
     """toc3d_linear_fused with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
@@ -168,6 +171,8 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
     ``self`` = the owner of the table: anything with ``_tuned`` (dict), ``autotune`` (bool) and ``_dt`` (the backbones, the neck).
     All variants accumulate K in the same order, so the choice does not change results."""
     global _flush
+    dtg = getattr(self, "_dt_gemm", None)
+    dtg = self._dt if dtg is None else dtg                 # the linear layers' arithmetic: _dt, or F32X3 on the "fp32x3" precision
     key = (epi, M, N, K)
     var = self._tuned.get(key)
     s = lib.stream_ptr()
@@ -178,20 +183,20 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
             var = self._tuned.get((lib.EPI_BIAS, M, N, K), 0)
         if var % 100 in (60, 61, 62, 63):                        # the phased tiles do not carry the RoPE tables
             var = 0
-        lib.call("toc3d_linear_qkv_rope", self._dt, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
+        lib.call("toc3d_linear_qkv_rope", dtg, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
         return
     if var is None:
         var = 0
         if lib.recording():
             # a shape first seen while recording (the eager warm-up forward normally tunes every shape): heuristic tile, no timing
-            lib.call("toc3d_linear_fused", self._dt, epi, 0, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
+            lib.call("toc3d_linear_fused", dtg, epi, 0, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
             return
         if self.autotune and not torch.cuda.is_current_stream_capturing():
             o = out
             if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # in-place residual add: tune into scratch
                 o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
             rep_s = torch.empty_like(rep_out) if rep_out is not None else None
-            cands = _VARIANTS[self._dt]
+            cands = _VARIANTS[dtg]
             if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):
                 cands = [v for v in cands if v not in (33, 45, 145, 52, 53, 152)]   # wave slabs that are not whole (w1, w2) 32-column groups
             if epi in (lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):  # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
@@ -205,7 +210,7 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
                 _flush = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=out.device)
 
             def cold_time(v, reps):
-                args = (self._dt, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, *fused, s)
+                args = (dtg, epi, v, A, lda, W, ldw, bias, o, ldo, res, ldr, res_mod, rep_s, rep_index, M, N, K, n_valid, *fused, s)
                 try:
                     lib.call("toc3d_linear_fused", *args)
                 except RuntimeError:                             # a tile variant that cannot serve this epilogue
@@ -225,7 +230,7 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
             short = sorted((cold_time(v, 3), v) for v in cands)[:4]
             var = min((cold_time(v, 9), v) for _, v in short)[1]
         self._tuned[key] = var
-    lib.call("toc3d_linear_fused", self._dt, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
+    lib.call("toc3d_linear_fused", dtg, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
 
 
 class _BackboneBase(nn.Module):
@@ -235,7 +240,7 @@ class _BackboneBase(nn.Module):
     def _setup_common(self, img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias,
                       use_abs_pos, pt_hw_seq_len, window_size, global_window_size, global_attn_indexes,
                       pretrain_img_size, pretrain_use_cls_token, out_feature, precision, img_norm_cfg=None, pad_size_divisor=32):
-        assert precision in ("bf16", "fp32"), precision
+        assert precision in ("bf16", "fp32", "fp32x3", "fp32x6"), precision
         # uint8 boundary: with img_norm_cfg (the config's dict(mean, std, to_rgb), ToC3D_faster.py:13-14)
         # forward() also accepts raw uint8 HWC camera images and applies NormalizeMultiviewImage + PadMultiViewImage
         # (datasets/pipelines/transform_3d.py:87-100,38-50) inside the patch-embedding im2col
@@ -303,7 +308,6 @@ class _BackboneBase(nn.Module):
         self.launch_mode = os.environ.get("TOC3D_LAUNCH", "plan")
         assert self.launch_mode in MODES, self.launch_mode
         self._stream_pool = []
-        self.block_hook = None          # tests: callable(i, group_plan, carried) after block i of a view group (forces eager launches)
 
     # -- state-dict hook: re-pack after new weights arrive ------------------------------------------
     def _load_from_state_dict(self, *a, **k):
@@ -342,6 +346,12 @@ class _BackboneBase(nn.Module):
     @property
     def _dt(self):
         return lib.BF16 if self.precision == "bf16" else lib.F32
+
+    @property
+    def _dt_gemm(self):
+        """Arithmetic of the linear layers: "fp32x3" keeps every buffer in f32 and forms the GEMM products as three bf16 MFMAs on the operands'
+        (hi, lo) splits (include/toc3d.h TOC3D_DTYPE_F32X3) -- the parity-grade path at a third of the bf16 MFMA rate instead of a sixteenth."""
+        return {"fp32x3": lib.F32X3, "fp32x6": lib.F32X6}.get(self.precision, self._dt)
 
     @property
     def _tdt(self):
@@ -705,7 +715,11 @@ class EVA_ViT(_BackboneBase):
             self._plans = {}
         key = (tuple(x.shape), x.dtype, self.view_groups)
         V = x.shape[0]
+        if key in self._plans:
+            self._plans[key] = self._plans.pop(key)              # most recently used last
         if key not in self._plans:
+            while len(self._plans) >= 8:                         # each plan holds ~1 GB of workspaces at full size: keep the 8 most recently used
+                self._plans.pop(next(iter(self._plans)))
             layout = self._group_layout(V, V)
             master = self._base_plan(V, H, W, x.device, 0) if len(layout) == 1 else None
             groups = []
@@ -778,6 +792,7 @@ class ToC3DEVAViT(_BackboneBase):
         self.token_ratio = list(token_ratio)
         self.use_represent_tokens = use_represent_tokens
         self.token_selection_loss = None                 # training-only (TokenSelectionLoss); inference build
+        self.gumbel_seed = int(torch.initial_seed()) & 0x7fffffffffffffff   # key of the device-side Gumbel draw (toc3d_gumbel_noise) when no noise is injected
         half = embed_dim // num_heads // 2
         self.score_predictor = nn.ModuleList([_Scorer(embed_dim, pruning_num_queries, token_ratio[i], pc_range)
                                               for i in range(len(pruning_loc))])
@@ -817,7 +832,7 @@ class ToC3DEVAViT(_BackboneBase):
             a_row = torch.empty(1, C, dtype=self._tdt, device=dev)
             bp["pad_qkv"] = torch.empty(1, 3 * C, dtype=self._tdt, device=dev)
             lib.call("toc3d_layernorm_rows", self._dt, bp["ln1_w"], C, minus1, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, a_row, C, 1, C, s)
-            lib.call("toc3d_linear", self._dt, lib.EPI_BIAS, a_row, C, bp["wqkv"], C, bp["bqkv"], bp["pad_qkv"], 3 * C, None, 0, 0, None, None,
+            lib.call("toc3d_linear", self._dt_gemm, lib.EPI_BIAS, a_row, C, bp["wqkv"], C, bp["bqkv"], bp["pad_qkv"], 3 * C, None, 0, 0, None, None,
                      1, 3 * C, C, 0, s)
             if self.attn_rot:
                 # ... and, for the pre-rotated attention, that row rotated for EVERY window slot by the same GEMM epilogue that rotates real rows
@@ -922,7 +937,8 @@ class ToC3DEVAViT(_BackboneBase):
         m["stage"] = dict(tq=torch.empty(B, Q, QUERY_DIM, **f32), rp=torch.empty(B, Q, 3, **f32), vel=torch.empty(B, Q, 2, **f32),
                           ts32=torch.empty(B, Q, 1, **f32), ts64=torch.empty(B, Q, 1, dtype=torch.float64, device=dev),
                           pose=torch.empty(B, Q, 4, 4, **f32), inv=torch.empty(B, 4, 4, **f32),
-                          gumbel=[torch.empty(V * T, 2, **f32) for _ in range(ns)])
+                          gumbel_all=torch.empty(ns, V * T, 2, **f32), rng=torch.zeros(2, dtype=torch.int64, device=dev))
+        m["stage"]["gumbel"] = [m["stage"]["gumbel_all"][s_] for s_ in range(ns)]      # one buffer: the device-side draw fills all stages in one launch
         m["groups"] = []
         layout = self._group_layout(V, B)
         for (v0, nv, f0, nf) in layout:
@@ -943,7 +959,16 @@ class ToC3DEVAViT(_BackboneBase):
         return m
 
     # -- scorer stage (toc3d_eva_vit.py:264-285) -------------------------------------------------------
-    def _score_stage(self, ex, lane, side, prep_lane, st, plan, P, prev_exists, gumbel, forced=None):
+    # -- extension points of the test-only subclass (toc3d_amd/testing.py); the product forward carries no test switches -----------------
+    _instrumented = False            # True: every frame launches eagerly (the subclass reads intermediate buffers between launches)
+
+    def _stage_override(self, st, plan, score, mask):
+        """After scorer stage ``st`` of one view group wrote its image-level scores / soft mask.  No-op here."""
+
+    def _block_done(self, i, plan, carried):
+        """After block ``i`` of one view group was issued (``carried``: its update of x is still pending in the compact rows).  No-op here."""
+
+    def _score_stage(self, ex, lane, side, prep_lane, st, plan, P, prev_exists, gumbel):
         """One scorer stage of one view group (toc3d_eva_vit.py:264-285) on ``lane``; work that does not gate the block chain
         (image-level ranking, the selection of the window type the next block does not use) goes to the group's ``side`` lane."""
         s = lib.stream_ptr()
@@ -971,11 +996,7 @@ class ToC3DEVAViT(_BackboneBase):
             self._linear(lib.EPI_GELU, u1, u1.shape[1], q["w_o2"], q["w_o2"].shape[1], q["b_o2"], u2, u2.shape[1], None, 0, 0, None, None,
                          M, C // 4, q["w_o2"].shape[1], 0)
             lib.call("toc3d_score_head", dt, u2, u2.shape[1], C // 4, q["w_o4"], q["b_o4"], g, M, pred, score, mask, s)
-        if forced is not None:
-            # test-only (eager): the reference's own image-level scores / soft mask replace this stage's, so every later block
-            # selects exactly the reference's tokens (bf16 parity with forced selection)
-            score.copy_(forced[st][0])
-            mask.copy_(forced[st][1])
+        self._stage_override(st, plan, score, mask)
 
         def topk(L):
             sel = plan["sel"][(st, L)]
@@ -1059,10 +1080,9 @@ class ToC3DEVAViT(_BackboneBase):
 
     @torch.no_grad()
     def forward(self, x, temp_queries=None, prev_exists=None, temp_ref_points=None, temp_vel=None, temp_timestamp=None,
-                temp_ego_pose=None, ego_pose_inv=None, *args, gumbel_noise=None, forced_scores=None, **kwargs):
-        """``forced_scores`` (tests only): per scorer stage ``(score (B*Nv, T), mask (B*Nv, T))`` that replace the stage's image-level
-        log-probs and soft mask -- e.g. the reference's own, from a golden fixture -- so that every block selects the reference's
-        tokens (forces the eager launch mode)."""
+                temp_ego_pose=None, ego_pose_inv=None, *args, gumbel_noise=None, **kwargs):
+        if "forced_scores" in kwargs:
+            raise TypeError("forced_scores is a test instrument: wrap the model with toc3d_amd.testing.instrument(model)")
         x, H, W = self._check_input(x)
         if self._packed is None:
             self._packed = self._pack()
@@ -1076,8 +1096,10 @@ class ToC3DEVAViT(_BackboneBase):
         assert V % B == 0
         ns = len(self.pruning_loc)
         key = (tuple(x.shape), x.dtype, B, self.view_groups)
-        if key not in self._plans:
-            while len(self._plans) >= 8:                         # each plan holds ~1 GB of workspaces at full size: keep the 8 newest
+        if key in self._plans:
+            self._plans[key] = self._plans.pop(key)              # most recently used last
+        else:
+            while len(self._plans) >= 8:                         # each plan holds ~1 GB of workspaces at full size: keep the 8 most recently used
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = self._master_plan(V, H, W, B, dev)
         plan = self._plans[key]
@@ -1102,17 +1124,11 @@ class ToC3DEVAViT(_BackboneBase):
                 put(sg["ts64"], temp_timestamp, torch.float64)
             else:
                 put(sg["ts32"], temp_timestamp)
+        draw = gumbel_noise is None and ns > 0               # F.gumbel_softmax's own sampling (toc3d_utils.py:147), drawn inside the frame: toc3d_gumbel_noise
         for st in range(ns):
-            if gumbel_noise is None:
-                # F.gumbel_softmax's own sampling (-log of Exp(1) draws), toc3d_utils.py:147
-                sg["gumbel"][st].exponential_().log_().neg_()
-            else:
+            if not draw:
                 staged.append((sg["gumbel"][st], gumbel_noise[st].to(device=dev, dtype=torch.float32).reshape(V * T, 2).contiguous()))
         lib.copy_segments(staged, s0)
-        forced = None
-        if forced_scores is not None:
-            forced = [(f[0].to(device=dev, dtype=torch.float32).reshape(V * T), f[1].to(device=dev, dtype=torch.float32).reshape(V * T))
-                      for f in forced_scores]
         if not prev:
             for gp in groups:                                    # first-frame scorer scratch
                 if gp["u1"] is None:
@@ -1129,6 +1145,9 @@ class ToC3DEVAViT(_BackboneBase):
         def frame(ex):
             for gp in groups:
                 gp["side_pending"], gp["side_L"] = False, None
+            if draw:
+                # part of the recorded frame: the frame counter lives in device memory, so every replay draws fresh noise (one launch for all stages)
+                lib.call("toc3d_gumbel_noise", sg["gumbel_all"], sg["gumbel_all"].numel(), self.gumbel_seed, sg["rng"], lib.stream_ptr())
             if prev and ns:
                 self._query_prep(ex, prep_lane, plan, P, ts_key)
             for g in range(1, G):
@@ -1148,14 +1167,12 @@ class ToC3DEVAViT(_BackboneBase):
                     with ex.lane(g):
                         if i in self.pruning_loc:
                             r0, r1 = gp["v0"] * T, (gp["v0"] + gp["nv"]) * T
-                            self._score_stage(ex, g, G + g, prep_lane, st, gp, P, prev, [gm[r0:r1] for gm in sg["gumbel"]],
-                                              None if forced is None else [(f[0][r0:r1], f[1][r0:r1]) for f in forced])
+                            self._score_stage(ex, g, G + g, prep_lane, st, gp, P, prev, [gm[r0:r1] for gm in sg["gumbel"]])
                         if self._accelerated(i):
                             self._accel_block(ex, g, G + g, i, st, gp, P, carry_in=cin, carry_out=cout)
                         else:
                             self._dense_block(i, gp, P)
-                        if self.block_hook is not None:
-                            self.block_hook(i, gp, cout)         # cout: block i's update of x is still pending in the compact rows
+                        self._block_done(i, gp, cout)
             for g, gp in enumerate(groups):
                 with ex.lane(g):
                     self._join_side(ex, g, G + g, gp)
@@ -1169,10 +1186,10 @@ class ToC3DEVAViT(_BackboneBase):
             for l in range(1, 2 * G + 1):
                 ex.wait(0, l)
 
-        if forced is not None or self.block_hook is not None:
+        if self._instrumented:
             frame(EagerExec(2 * G + 1, self._stream_pool))
         else:
-            self._run_frame(plan, 2 * G + 1, frame, variant=(prev, ts_key))
+            self._run_frame(plan, 2 * G + 1, frame, variant=(prev, ts_key, draw))
         h, w = plan["h"], plan["w"]
         cl = (lambda t: t) if self.alias_outputs else (lambda t: t.clone())
         masks = [cl(plan["mask"][s]).view(V, h, w, 1) for s in range(ns)]

@@ -19,6 +19,8 @@
 //
 // This file: the C ABI of the linear layers, weight packing and the im2col / image kernels.  The GEMM kernels live in gemm_kernels.h and are
 // instantiated by gemm_epi_{plain,residual,swiglu}.hip.
+#include <cstdlib>
+
 #include "gemm_kernels.h"
 
 thread_local bool g_bad_variant = false;               // variant cannot serve the requested epilogue
@@ -238,7 +240,8 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                        float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
                        void* out_act, int64_t ld_act, const int32_t* residual_index, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_linear: bad dtype %d", dtype);
+    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3 || dtype == TOC3D_F32X6, "toc3d_linear: bad dtype %d", dtype);
+    TOC3D_REQUIRE((dtype != TOC3D_F32X3 && dtype != TOC3D_F32X6) || epilogue <= TOC3D_EPI_GELU || epilogue == TOC3D_EPI_CONV3X3, "toc3d_linear: the bf16 x 3 / x 6 product forms serve epilogues 0-3 and the 3x3 conv");
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && K > 0, "toc3d_linear: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     const int bk = 64;
@@ -281,8 +284,11 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     const int64_t osz = e_residual ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
     const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * osz) == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
                      (!rep_out || (N % 4 == 0 && (uintptr_t)rep_out % 16 == 0));
+    // wide (16-byte) bf16 stores need 16-byte aligned rows in the output's own element size (TOC3D_WIDE_STORES=0 disables them: A/B runs)
+    static const bool wide_ok = [] { const char* e = getenv("TOC3D_WIDE_STORES"); return !(e && e[0] == '0'); }();
+    const bool vec8 = wide_ok && vec && dtype == TOC3D_BF16 && !e_residual && epilogue != TOC3D_EPI_CONV3X3 && ldo % 8 == 0 && (uintptr_t)out % 16 == 0;
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
-               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0,
+               (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, vec8 ? 1 : 0,
                stats_out, (int)stats_out_cap, stats_in, (int)(stats_in_cap & 0xffffffff), (int)(stats_in_cap >> 32), col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
                0, 0, nullptr, nullptr, nullptr, 0, 1.0f};
     if (epilogue == TOC3D_EPI_CONV3X3) {
@@ -292,7 +298,8 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
         a.out_act = nullptr; a.ld_act = 0;
     }
     g_bad_variant = false;
-    int rc = launch_gemm(dtype == TOC3D_BF16, epilogue, variant, a, as_stream(stream));
+    int rc = dtype == TOC3D_F32X3 ? toc3d_gemm_launch_x3(epilogue, variant, a, as_stream(stream))
+             : dtype == TOC3D_F32X6 ? toc3d_gemm_launch_x6(epilogue, variant, a, as_stream(stream)) : launch_gemm(dtype == TOC3D_BF16, epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
     if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab not a multiple of 32, or N-tile not a multiple of 128 for the statistics)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
@@ -318,7 +325,9 @@ int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, co
     TOC3D_REQUIRE(rope_side > 0 && rope_side <= 64, "toc3d_linear_qkv_rope: rope_side out of range (the tables live in LDS: <= 64)");
     if (M == 0) return TOC3D_OK;
     const bool vec = ldo % 4 == 0 && (uintptr_t)out % 8 == 0;
-    GemmArgs a{A, lda, W, ldw, bias, out, ldo, nullptr, 0, 0, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K, 0, 0, vec ? 1 : 0,
+    static const bool wide_ok = [] { const char* e = getenv("TOC3D_WIDE_STORES"); return !(e && e[0] == '0'); }();
+    const bool vec8 = wide_ok && vec && ldo % 8 == 0 && (uintptr_t)out % 16 == 0;
+    GemmArgs a{A, lda, W, ldw, bias, out, ldo, nullptr, 0, 0, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K, 0, 0, vec ? 1 : 0, vec8 ? 1 : 0,
                nullptr, 0, nullptr, 0, 0, nullptr, 0.f, 0.f, nullptr, 0, 0, 0, nullptr, rope_rc, rope_tab, (int)rope_side, q_scale};
     g_bad_variant = false;
     const int rc = launch_gemm(1, TOC3D_EPI_QKV_ROPE, variant, a, as_stream(stream));

@@ -1,0 +1,14 @@
+// "bf16 x 6" products on f32 operands (TOC3D_DTYPE_F32X6): instantiations of the GEMM kernels of gemm_kernels.h for the epilogues the parity-grade
+// paths launch (own translation unit so that the groups build in parallel).
+#include "gemm_kernels.h"
+
+int toc3d_gemm_launch_x6(int epi, int variant, const GemmArgs& a, hipStream_t s) {
+    switch (epi) {
+        case TOC3D_EPI_BIAS: return launch_epi_x<TOC3D_EPI_BIAS, 6>(variant, a, s);
+        case TOC3D_EPI_GELU: return launch_epi_x<TOC3D_EPI_GELU, 6>(variant, a, s);
+        case TOC3D_EPI_RESIDUAL: return launch_epi_x<TOC3D_EPI_RESIDUAL, 6>(variant, a, s);
+        case TOC3D_EPI_SWIGLU: return launch_epi_x<TOC3D_EPI_SWIGLU, 6>(variant, a, s);
+        case TOC3D_EPI_CONV3X3: return launch_epi_x<TOC3D_EPI_CONV3X3, 6>(variant, a, s);
+        default: return TOC3D_ERR_ARG;
+    }
+}

@@ -34,6 +34,7 @@ struct GemmArgs {
     int M, N, K, n_valid;
     int order;                                           // 0: XCD chunks of row-major tiles; 1: per-XCD row band, m fastest
     int vec;                                             // epilogue may use 4-element vector accesses (alignment checked on the host)
+    int vec8;                                            // bf16 outputs: rows are 16-byte aligned, so two row tiles may leave as one 16-byte store per lane
     // LayerNorms folded across GEMM boundaries (include/toc3d.h, toc3d_linear_fused): statistics this launch leaves / consumes
     float* stats; int stats_cap;                         // written:  int32 header [4] + f32 [M, stats_cap, 2]
     const float* stats_in; int stats_in_cap;             // consumed: same layout, written by the launch that produced A
@@ -55,6 +56,8 @@ int toc3d_gemm_launch_plain(int is_bf16, int epi, int variant, const GemmArgs& a
 int toc3d_gemm_launch_residual(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);   // EPI_RESIDUAL, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS
 int toc3d_gemm_launch_swiglu(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);     // EPI_SWIGLU, EPI_SWIGLU_STATS, EPI_SWIGLU_STATS_LN
 int toc3d_gemm_launch_rope(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);       // EPI_QKV_ROPE (bf16)
+int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 3 products on f32 operands: epilogues 0-3, 8
+int toc3d_gemm_launch_x6(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 6 (three-way split): f32-grade products
 
 // Development instrumentation (tools/ubench/gemm_timeline.hip builds its own copy of these kernels with -DTOC3D_GEMM_TRACE; the library
 // never defines it): every workgroup leaves the 100 MHz real-time counter at entry, after its K loop and after its epilogue stores have
@@ -182,6 +185,32 @@ TOC3D_DEV void epi_store4(bf16_t* p, const bf16_t (&v)[4]) { store4(p, v); }
 TOC3D_DEV void epi_store4(float* p, const float (&v)[4]) { store4(p, v); }
 #endif
 
+// Wide bf16 epilogue stores (cdna_hip_programming.md T21, re-derived for the 16x16 C^T layout).  The epilogues of the single-round launches
+// are store-ISSUE bound (all workgroups store at once; ~7 B/clk/CU whatever the byte count, profiles/r03_gemm_timeline_*.txt), and a bf16
+// tile leaves as 8 bytes per lane.  Two row tiles i, i + 1 of the same columns are therefore merged into ONE 16-byte store per lane:
+// v_permlane16_swap exchanges the odd 16-lane rows of `a` (tile i) with the even rows of `b` (tile i + 1); afterwards a lane of an even lane
+// group g holds [own tile-i columns g*4.. | its right neighbour's], i.e. 8 consecutive columns of row i*16 + r16, and a lane of an odd group
+// holds [left neighbour's | own] tile-(i+1) columns (g-1)*4.. of row (i+1)*16 + r16.  Same bytes, same addresses, half the instructions.
+struct Pack4 { unsigned x, y; };
+TOC3D_DEV Pack4 pack4(const bf16_t (&v)[4]) {
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    const bf16x4_t q = bf16x4_t{v[0], v[1], v[2], v[3]};
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, q);
+    return Pack4{(unsigned)u, (unsigned)(u >> 32)};
+}
+TOC3D_DEV Pack4 pack4(const float (&)[4]) { return Pack4{0u, 0u}; }     // f32 outputs already leave as 16 bytes per lane
+// pa = this lane's 4 columns of row tile i, pb = of row tile i + 1 (both computed by every lane); dst_a / dst_b = the addresses this lane would
+// have stored them to (8-byte stores); ok_a / ok_b = row inside the matrix
+TOC3D_DEV void store_pair_wide(bf16_t* dst_a, bf16_t* dst_b, Pack4 pa, Pack4 pb, bool ok_a, bool ok_b, int g) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const auto rx = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+    // even group: row tile i, columns start at its own; odd group: row tile i + 1, columns start 4 to the left (the left neighbour's)
+    bf16_t* dst = (g & 1) ? dst_b - 4 : dst_a;
+    if ((g & 1) ? ok_b : ok_a) *reinterpret_cast<u32x4*>(dst) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+}
+TOC3D_DEV void store_pair_wide(float*, float*, Pack4, Pack4, bool, bool, int) {}
+
 // ---- epilogue of one wavefront's (MT*16) x (NT*16) accumulator block whose first row / column are row0 / col0.  The MFMA is issued
 // with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
 // .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
@@ -196,36 +225,71 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
     if (epi_is_swiglu(EPI)) {
         // packed columns: per 32-column group, cols 0-15 = w1 units, cols 16-31 = w2 of the same units
         T* out = reinterpret_cast<T*>(a.out);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        // hidden units (i, jp) of this lane -> hs; returns whether the lane's row / columns lie inside the matrix
+        auto units = [&](int i, int jp, T (&hs)[4], float& ssum, float& sq) -> bool {
             const int row = row0 + i * 16 + r16;
             float mu = 0.f, rs = 1.f;
             if (epi_ln_in(EPI)) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
+            const int pc = col0 + jp * 32 + g * 4;        // packed col of the w1 half, first of 4
+            const int unit0 = (pc >> 5) * 16 + g * 4;
+            ssum = 0.f; sq = 0.f;
+            const bool in = pc < a.N && row < a.M;
 #pragma unroll
-            for (int jp = 0; jp < NT / 2; ++jp) {
-                const int pc = col0 + jp * 32 + g * 4;    // packed col of the w1 half, first of 4
-                const int unit0 = (pc >> 5) * 16 + g * 4;
-                float ssum = 0.f, sq = 0.f;
-                if (pc < a.N && row < a.M) {
-                    T hs[4];
+            for (int r = 0; r < 4; ++r) hs[r] = to_act<T>(0.f);
+            if (in) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x1, x2;
-                        if (epi_ln_in(EPI)) {               // bias = c2 (beta . W + b), c1 = column sums of the gamma-scaled packed weights
-                            x1 = rs * (acc[i][2 * jp][r] - mu * a.c1[pc + r]) + a.bias[pc + r];
-                            x2 = rs * (acc[i][2 * jp + 1][r] - mu * a.c1[pc + 16 + r]) + a.bias[pc + 16 + r];
+                for (int r = 0; r < 4; ++r) {
+                    float x1, x2;
+                    if (epi_ln_in(EPI)) {               // bias = c2 (beta . W + b), c1 = column sums of the gamma-scaled packed weights
+                        x1 = rs * (acc[i][2 * jp][r] - mu * a.c1[pc + r]) + a.bias[pc + r];
+                        x2 = rs * (acc[i][2 * jp + 1][r] - mu * a.c1[pc + 16 + r]) + a.bias[pc + 16 + r];
+                    } else {
+                        x1 = acc[i][2 * jp][r] + a.bias[pc + r];
+                        x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
+                    }
+                    hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu<T>(x1) * x2 : 0.f);
+                    if (epi_stats_out(EPI)) {
+                        const float hv = from_act(hs[r]);       // what the next GEMM multiplies: the rounded value
+                        ssum += hv;
+                        sq = __builtin_fmaf(hv, hv, sq);
+                    }
+                }
+            }
+            return in;
+        };
+        if constexpr (sizeof(T) == 2 && MT % 2 == 0) {
+            if (a.vec8) {                                // pairs of row tiles leave as one 16-byte store per lane
+#pragma unroll
+                for (int i = 0; i < MT; i += 2)
+#pragma unroll
+                    for (int jp = 0; jp < NT / 2; ++jp) {
+                        T ha[4], hb[4];
+                        float s1, q1, s2, q2;
+                        const bool ia = units(i, jp, ha, s1, q1), ib = units(i + 1, jp, hb, s2, q2);
+                        if (epi_stats_out(EPI)) { gs[i * G + jp] = s1; gq[i * G + jp] = q1; gs[(i + 1) * G + jp] = s2; gq[(i + 1) * G + jp] = q2; }
+                        const int unit0 = ((col0 + jp * 32 + g * 4) >> 5) * 16 + g * 4;
+                        T* da = out + (int64_t)(row0 + i * 16 + r16) * a.ldo + unit0;
+                        if (col0 + jp * 32 + 32 <= a.N) {                        // the whole 32-column group lies inside (wave-uniform): wide stores
+                            // a lane's own in-flag stands for its neighbour's too: both share the row, and the columns are all inside
+                            store_pair_wide(da, da + 16 * a.ldo, pack4(ha), pack4(hb), ia, ib, g);
                         } else {
-                            x1 = acc[i][2 * jp][r] + a.bias[pc + r];
-                            x2 = acc[i][2 * jp + 1][r] + a.bias[pc + 16 + r];
-                        }
-                        hs[r] = to_act<T>(unit0 + r < a.n_valid ? silu<T>(x1) * x2 : 0.f);
-                        if (epi_stats_out(EPI)) {
-                            const float hv = from_act(hs[r]);       // what the next GEMM multiplies: the rounded value
-                            ssum += hv;
-                            sq = __builtin_fmaf(hv, hv, sq);
+                            if (ia) epi_store4(da, ha);
+                            if (ib) epi_store4(da + 16 * a.ldo, hb);
                         }
                     }
-                    T* dst = out + (int64_t)row * a.ldo + unit0;
+                return;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int jp = 0; jp < NT / 2; ++jp) {
+                T hs[4];
+                float ssum, sq;
+                const bool in = units(i, jp, hs, ssum, sq);
+                if (in) {
+                    const int unit0 = ((col0 + jp * 32 + g * 4) >> 5) * 16 + g * 4;
+                    T* dst = out + (int64_t)(row0 + i * 16 + r16) * a.ldo + unit0;
                     if (a.vec) epi_store4(dst, hs);
                     else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
                 }
@@ -249,6 +313,75 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
         for (int r = 0; r < 4; ++r) {
             bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
             if (EPI == TOC3D_EPI_RESIDUAL_LN) ccol[j][r] = r < nok[j] ? a.c1[col + r] : 0.f;
+        }
+    }
+    // act-dtype outputs (bias / GELU / rotated q|k|v): the 4 values of row tile i, column tile j
+    auto act4 = [&](int i, int j, T (&o4)[4]) {
+        const int col = col0 + j * 16 + g * 4;
+        if constexpr (EPI == TOC3D_EPI_QKV_ROPE) {
+            // RoPE of the q and k columns on the f32 accumulators (eva_utils.py:378-379: out[2t] = x[2t] cos - x[2t+1] sin,
+            // out[2t+1] = x[2t+1] cos + x[2t] sin, the pair sharing one frequency), q scaled afterwards (eva_vit.py:104-109): the
+            // attention kernel then stages K and V by DMA with no arithmetic at all.  A lane's 4 columns are two whole pairs of one
+            // head; a 16-column MFMA tile lies inside one of q / k / v (C is a multiple of 64), so the branch is wave-uniform.
+            const int Cq = a.N / 3;
+            const int rope_rc = rope_rcs[i];             // loaded before the K loop (no dependent global round trip here)
+            float x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = acc[i][j][r] + bcol[j][r];
+            if (col < 2 * Cq) {
+                const int d0 = col & 63, part = d0 >> 5;
+                const int coord = part ? (rope_rc & 0xffff) : (rope_rc >> 16);
+                const int off = (part * a.rope_L + coord) * 16 + ((d0 & 31) >> 1);       // tables in LDS: [cos | sin], each [2][L][16]
+                const f32x2 c2 = *reinterpret_cast<const f32x2*>(rope_tab + off), s2 = *reinterpret_cast<const f32x2*>(rope_tab + 2 * a.rope_L * 16 + off);
+                const float y0 = x[0] * c2[0] - x[1] * s2[0], y1 = x[1] * c2[0] + x[0] * s2[0];
+                const float y2 = x[2] * c2[1] - x[3] * s2[1], y3 = x[3] * c2[1] + x[2] * s2[1];
+                const float sc = col < Cq ? a.rope_scale : 1.0f;
+                x[0] = y0 * sc; x[1] = y1 * sc; x[2] = y2 * sc; x[3] = y3 * sc;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = to_act<T>(x[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float raw = acc[i][j][r] + bcol[j][r];
+                o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
+            }
+        }
+    };
+    auto act_row = [&](int i, int row) {                 // one row tile, 8-byte (bf16) / 16-byte (f32) stores
+        T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (nok[j] == 0) continue;
+            const int col = col0 + j * 16 + g * 4;
+            T o4[4];
+            act4(i, j, o4);
+            if (a.vec && nok[j] == 4) epi_store4(orow + col, o4);
+            else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
+        }
+    };
+    if constexpr (!epi_is_residual(EPI) && sizeof(T) == 2 && MT % 2 == 0) {
+        if (a.vec8) {                                    // bf16 outputs: pairs of row tiles leave as one 16-byte store per lane (store_pair_wide)
+#pragma unroll
+            for (int i = 0; i < MT; i += 2) {
+                const int ra = row0 + i * 16 + r16, rb = ra + 16;
+                T* oa = reinterpret_cast<T*>(a.out) + (int64_t)ra * a.ldo;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = col0 + j * 16 + g * 4;
+                    if (col0 + j * 16 + 16 <= a.N) {     // the whole 16-column tile lies inside (wave-uniform)
+                        T va[4], vb[4];
+                        act4(i, j, va);
+                        act4(i + 1, j, vb);
+                        store_pair_wide(oa + col, oa + 16 * a.ldo + col, pack4(va), pack4(vb), ra < a.M, rb < a.M, g);
+                    } else if (nok[j] > 0) {
+                        T o4[4];
+                        if (ra < a.M) { act4(i, j, o4); for (int r = 0; r < nok[j]; ++r) oa[col + r] = o4[r]; }
+                        if (rb < a.M) { act4(i + 1, j, o4); for (int r = 0; r < nok[j]; ++r) oa[16 * a.ldo + col + r] = o4[r]; }
+                    }
+                }
+            }
+            return;
         }
     }
 #pragma unroll
@@ -313,46 +446,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                 }
             }
         } else {
-            T* orow = reinterpret_cast<T*>(a.out) + (int64_t)row * a.ldo;
-            int rope_rc = 0;
-            if constexpr (EPI == TOC3D_EPI_QKV_ROPE) rope_rc = rope_rcs[i];          // loaded before the K loop (no dependent global round trip here)
-            (void)rope_rc;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (nok[j] == 0) continue;
-                const int col = col0 + j * 16 + g * 4;
-                T o4[4];
-                if constexpr (EPI == TOC3D_EPI_QKV_ROPE) {
-                    // RoPE of the q and k columns on the f32 accumulators (eva_utils.py:378-379: out[2t] = x[2t] cos - x[2t+1] sin,
-                    // out[2t+1] = x[2t+1] cos + x[2t] sin, the pair sharing one frequency), q scaled afterwards (eva_vit.py:104-109): the
-                    // attention kernel then stages K and V by DMA with no arithmetic at all.  A lane's 4 columns are two whole pairs of one
-                    // head; a 16-column MFMA tile lies inside one of q / k / v (C is a multiple of 64), so the branch is wave-uniform.
-                    const int Cq = a.N / 3;
-                    float x[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[r] = acc[i][j][r] + bcol[j][r];
-                    if (col < 2 * Cq) {
-                        const int d0 = col & 63, part = d0 >> 5;
-                        const int coord = part ? (rope_rc & 0xffff) : (rope_rc >> 16);
-                        const int off = (part * a.rope_L + coord) * 16 + ((d0 & 31) >> 1);       // tables in LDS: [cos | sin], each [2][L][16]
-                        const f32x2 c2 = *reinterpret_cast<const f32x2*>(rope_tab + off), s2 = *reinterpret_cast<const f32x2*>(rope_tab + 2 * a.rope_L * 16 + off);
-                        const float y0 = x[0] * c2[0] - x[1] * s2[0], y1 = x[1] * c2[0] + x[0] * s2[0];
-                        const float y2 = x[2] * c2[1] - x[3] * s2[1], y3 = x[3] * c2[1] + x[2] * s2[1];
-                        const float sc = col < Cq ? a.rope_scale : 1.0f;
-                        x[0] = y0 * sc; x[1] = y1 * sc; x[2] = y2 * sc; x[3] = y3 * sc;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o4[r] = to_act<T>(x[r]);
-                } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float raw = acc[i][j][r] + bcol[j][r];
-                    o4[r] = to_act<T>(EPI == TOC3D_EPI_GELU ? gelu_erf(raw) : raw);
-                }
-                }
-                if (a.vec && nok[j] == 4) epi_store4(orow + col, o4);
-                else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
-            }
+            act_row(i, row);
         }
     }
 }
@@ -362,8 +456,39 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
 // tracked with a *counted* s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain them to
 // vmcnt(0), cdna_hip_programming.md "Pipelining across barriers").  One barrier per K-tile:
 //   wait(tile t landed) -> s_barrier -> request tile t+STAGES-1 into the slot tile t-1 just left -> MFMAs on tile t
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int OCC>
+// X3 (T = float only): "bf16 x 3" products on f32 operands -- the parity-grade path at bf16 MFMA speed (include/toc3d.h, TOC3D_DTYPE_F32X3).
+// Every f32 operand fragment is split in registers into hi = bf16(x) and lo = bf16(x - hi) (x - hi is exact; |x - hi - lo| <= 2^-18 |x|) and
+// a . w is accumulated in f32 as hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16: 3 bf16 MFMAs (48 cycles) instead of 8 exact-f32 ones
+// (256 cycles) per 16x16x32 step, relative error of a product <= ~2^-16 (the dropped lo.lo term and the roundings of lo).  Memory layout,
+// loaders, LDS images and epilogues are those of the f32 instantiation.
+TOC3D_DEV void split_bf16x3(const Frag<float>& f, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bf16_t h = (bf16_t)x[e];
+        hi[e] = h;
+        lo[e] = (bf16_t)(x[e] - (float)h);
+    }
+}
+// X = 6: three-way split x = hi + mid + lo (3 x 8 mantissa bits = all 24 of an f32; both subtractions are exact), products
+// hi.hi + (hi.mid + mid.hi) + (mid.mid + hi.lo + lo.hi): the dropped terms are <= 2^-26 of the product -- f32-grade results from 6 bf16
+// MFMAs (96 cycles) instead of 8 f32 ones (256).
+TOC3D_DEV void split_bf16x6(const Frag<float>& f, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    const float x[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bf16_t h = (bf16_t)x[e];
+        const float r1 = x[e] - (float)h;
+        const bf16_t m = (bf16_t)r1;
+        hi[e] = h;
+        mid[e] = m;
+        lo[e] = (bf16_t)(r1 - (float)m);
+    }
+}
+
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int OCC, int X3 = 0>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
+    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4), "the bf16 x 3 / x 6 product forms run on f32 operands");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
     constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
@@ -455,10 +580,44 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
             for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, s, g, T());
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, s, g, T());
+            if constexpr (X3 == 6) {
+                bf16x8 ah[MT], am[MT], al[MT], bh[NT], bm[NT], bl[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) split_bf16x6(fa[i], ah[i], am[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) split_bf16x6(fb[j], bh[j], bm[j], bl[j]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {           // smallest terms first
+                        f32x4 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[j], am[i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[j], ah[i], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], am[i], c, 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], c, 0, 0, 0);
+                    }
+            } else if constexpr (X3 == 3) {
+                bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) split_bf16x3(fa[i], ah[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) split_bf16x3(fb[j], bh[j], bl[j]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {           // small terms first; operands swapped like mma_step below
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+            } else {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) mma_step(acc[i][j], fb[j], fa[i]);   // swapped: C^T tile layout, see the epilogue
+            }
         }
     };
     // EPI_RESIDUAL_LN -- folded LayerNorm of the A rows: (mean, rstd) per tile row from the partial sums the producing GEMM left (include/toc3d.h),
@@ -739,7 +898,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
 }
 
 
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1>
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1, int X3 = 0>
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
     // a wave must own whole (w1, w2) 32-column groups; the folded-LayerNorm statistics need N-tiles of whole 128-column slots; the fold is bf16 only
     constexpr bool unsupported = (epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) ||
@@ -750,15 +909,15 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
         constexpr int lds_fixed = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);   // + the (mean, rstd) row table
         const int lds = lds_fixed + (EPI == TOC3D_EPI_QKV_ROPE && STAGES == 1 ? (a.rope_L * 256 + 1023) / 1024 * 1024 : 0);   // single buffer: + the RoPE tables (cos | sin), whole DMA instructions
         static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
-        if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), lds_fixed + (EPI == TOC3D_EPI_QKV_ROPE ? 64 * 256 : 0));
+        if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC, X3>), lds_fixed + (EPI == TOC3D_EPI_QKV_ROPE ? 64 * 256 : 0));
         if (a.K % (RB / (int)sizeof(T)) != 0 || (EPI == TOC3D_EPI_CONV3X3 && a.lda % (RB / (int)sizeof(T)) != 0)) {    // K-tile must divide K (conv: the channel count)
             if (RB == 128) { g_bad_variant = true; return; }
-            launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC>(a, s);
+            launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC, X3>(a, s);
             return;
         }
         const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
         const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
-        toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
+        toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC, X3>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
     }
 }
 
@@ -851,6 +1010,31 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
         case 62: if (sizeof(T) == 2) launch_phased<EPI, 128, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
         case 63: if (sizeof(T) == 2) launch_phased<EPI, 128, 128, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x32 per wave, 64 KiB: two per CU
+        default: return TOC3D_ERR_ARG;
+    }
+    return TOC3D_OK;
+}
+
+// bf16 x 3 / x 6 products on f32 operands (TOC3D_DTYPE_F32X3 / F32X6): a set of tile variants (same numbering as launch_epi)
+template <int EPI, int X>
+int launch_epi_x(int variant, GemmArgs a, hipStream_t s) {
+    if (variant >= 100) { a.order = 1; variant -= 100; }
+    if (variant == 0) {
+        const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+        variant = t128 < 700 ? 17 : 16;
+    }
+    switch (variant) {
+        case 1: launch_cfg<float, EPI, 128, 128, 2, 128, 2, 2, 1, X>(a, s); break;
+        case 8: launch_cfg<float, EPI, 128, 128, 1, 128, 2, 2, 1, X>(a, s); break;
+        case 10: launch_cfg<float, EPI, 64, 128, 2, 128, 2, 2, 1, X>(a, s); break;
+        case 14: launch_cfg<float, EPI, 64, 64, 2, 128, 2, 2, 1, X>(a, s); break;
+        case 16: launch_cfg<float, EPI, 128, 128, 1, 128, 2, 4, 1, X>(a, s); break;
+        case 17: launch_cfg<float, EPI, 128, 128, 2, 128, 2, 4, 1, X>(a, s); break;
+        case 19: launch_cfg<float, EPI, 256, 128, 1, 128, 4, 2, 1, X>(a, s); break;
+        case 22: launch_cfg<float, EPI, 128, 128, 1, 256, 2, 4, 1, X>(a, s); break;      // K-tile of 64 f32: half the barriers per K
+        case 26: launch_cfg<float, EPI, 64, 128, 1, 256, 2, 4, 1, X>(a, s); break;
+        case 28: launch_cfg<float, EPI, 128, 128, 3, 128, 2, 4, 1, X>(a, s); break;
+        case 49: launch_cfg<float, EPI, 192, 128, 2, 128, 2, 4, 1, X>(a, s); break;
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;

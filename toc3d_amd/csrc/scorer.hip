@@ -437,6 +437,44 @@ __global__ __launch_bounds__(256) void im2col_3x3_kernel(const float* __restrict
     }
 }
 
+// ---- Gumbel noise of the soft masks, drawn on the device INSIDE the recorded frame (toc3d_utils.py:145-147: F.gumbel_softmax samples
+// -log(E), E ~ Exp(1), i.e. -log(-log(U))).  Counter-based: Philox4x32-10 keyed by the model's seed, counter = (frame counter, element / 4), so a
+// replayed launch plan draws fresh noise every frame although its launch arguments never change: the frame counter lives in device memory
+// (state[0]) and is advanced by the last workgroup of the launch (ticket in state[1], self-resetting).
+TOC3D_DEV void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void gumbel_noise_kernel(float* __restrict__ out, int64_t n, unsigned long long seed, unsigned long long* __restrict__ state) {
+    const unsigned long long frame = state[0];
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one Philox block = 4 values
+    if (q * 4 < n) {
+        unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), (unsigned)frame, (unsigned)(frame >> 32)};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        float gv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = ((float)(c[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1) strictly: 24 random bits
+            gv[e] = -logf(-logf(u));
+        }
+        if (q * 4 + 4 <= n) *reinterpret_cast<f32x4*>(out + q * 4) = f32x4{gv[0], gv[1], gv[2], gv[3]};
+        else for (int e = 0; q * 4 + e < n; ++e) out[q * 4 + e] = gv[e];
+    }
+    // every workgroup has read state[0] before it takes its ticket; the last one to arrive advances the frame counter
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long t = atomicAdd(&state[1], 1ull);
+        if (t == (unsigned long long)gridDim.x - 1) { state[1] = 0; state[0] = frame + 1; __threadfence(); }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -503,6 +541,17 @@ int toc3d_score_tokens(const float* x, int64_t C, const float* mask, const float
     toc3d_launch(score_tokens_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), x, (int)C, mask, wc, bc, gumbel, M, (int)T,
                        (int)views_per_frame, pred, score, mask_out);
     TOC3D_LAUNCH_CHECK("toc3d_score_tokens");
+    return TOC3D_OK;
+}
+
+int toc3d_gumbel_noise(float* out, int64_t n, uint64_t seed, uint64_t* state, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(out && state && n >= 0, "toc3d_gumbel_noise: bad arguments");
+    TOC3D_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)state % 8) == 0, "toc3d_gumbel_noise: out must be 16-byte, state 8-byte aligned");
+    if (n == 0) return TOC3D_OK;
+    const int64_t blocks = (n + 1023) / 1024;
+    TOC3D_REQUIRE(blocks <= 0x7fffffff, "toc3d_gumbel_noise: n too large");
+    toc3d_launch(gumbel_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out, n, (unsigned long long)seed, (unsigned long long*)state);
+    TOC3D_LAUNCH_CHECK("toc3d_gumbel_noise");
     return TOC3D_OK;
 }
 

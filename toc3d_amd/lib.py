@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
 ABI_VERSION = 3                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
-F32, BF16 = 0, 1
+F32, BF16, F32X3, F32X6 = 0, 1, 2, 3          # F32X3: linear layers only -- f32 buffers, products as three bf16 MFMAs (include/toc3d.h)
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
 
@@ -52,6 +52,7 @@ _SIGS = {
     "toc3d_motion_queries": "pllppppippllpp",
     "toc3d_collapse_query_scorer": "ppppplllfppp",
     "toc3d_score_tokens": "plpppplllpppp",
+    "toc3d_gumbel_noise": "plLpp",
     "toc3d_global_mean_half": "ipllllp",
     "toc3d_score_head": "ipllppplpppp",
     "toc3d_nhwc_to_nchw": "pplllp",
@@ -74,7 +75,7 @@ _SIGS = {
     "toc3d_plan_end": "pi",
     "toc3d_plan_run": "pp",
 }
-_CT = {"p": _P, "l": _I64, "i": _I, "f": _F}
+_CT = {"p": _P, "l": _I64, "i": _I, "f": _F, "L": ctypes.c_uint64}
 
 _lib = None
 

@@ -34,7 +34,7 @@ class CPFPN(nn.Module):
         if (len(in_channels) != 1 or start_level != 0 or end_level != -1 or add_extra_convs or norm_cfg is not None
                 or act_cfg is not None or conv_cfg is not None or num_outs not in (1, 2)):
             raise NotImplementedError("CPFPN is built for the shipped single-level configuration (in_channels=[C], num_outs<=2)")
-        assert precision in ("bf16", "fp32")
+        assert precision in ("bf16", "fp32", "fp32x3", "fp32x6")
         self.in_channels, self.out_channels, self.num_outs = in_channels, out_channels, num_outs
         self.precision = precision
         self.fp16_enabled = False
@@ -56,6 +56,10 @@ class CPFPN(nn.Module):
     @property
     def _dt(self):
         return lib.BF16 if self.precision == "bf16" else lib.F32
+
+    @property
+    def _dt_gemm(self):
+        return {"fp32x3": lib.F32X3, "fp32x6": lib.F32X6}.get(self.precision, self._dt)
 
     def load_state_dict(self, *a, **k):
         self._packed = None
