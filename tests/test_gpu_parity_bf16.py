@@ -244,7 +244,7 @@ def _tuned_tables():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "toc3d_amd", "tuned")
     out = []
     for p in sorted(glob.glob(os.path.join(root, "*.json"))):
-        m = re.match(r"(.+)_(\d+)x(\d+)_(bf16|fp32)\.json$", os.path.basename(p))
+        m = re.match(r"(.+)_(\d+)x(\d+)_(bf16|fp32|fp32x3|fp32x6)\.json$", os.path.basename(p))
         out.append((p, m.group(1), (int(m.group(2)), int(m.group(3))), m.group(4)))
     return out
 
