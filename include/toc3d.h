@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TOC3D_ABI_VERSION 3   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
+#define TOC3D_ABI_VERSION 4   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
 
 #define TOC3D_OK 0
 #define TOC3D_ERR_ARG (-1)
@@ -136,6 +136,32 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
                        float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap,
                        const float* col_sums, int64_t ln_n, float ln_eps, void* out_act, int64_t ld_act, const int32_t* residual_index,
                        toc3d_stream_t stream);
+
+/* Several dependent linear layers of one transformer-block half in ONE persistent launch (bf16): attn.proj + residual -> [norm2] -> mlp.w1 | mlp.w2
+ * -> [ffn_ln] -> mlp.w3 + residual (eva_vit.py:44-51,115,262-263; toc3d_eva_vit.py:366-386), the LayerNorms folded as in toc3d_linear_fused.
+ * Each op is one toc3d_linear_fused call (same argument meaning; variant, residual_row_mod are not taken); op i reads rows that op i - 1 wrote
+ * (A operand, residual, statistics), all ops have the same M.  Results are bit-identical to the same ops issued as separate toc3d_linear_fused
+ * launches in order.  `config` = 10 * family + tiling: family 0 = {EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_RESIDUAL_LN}, family 1 =
+ * {EPI_SWIGLU_STATS, EPI_RESIDUAL_LN}; toc3d_linear_chain_info returns the number of ops and fills info[4 * op + {0, 1, 2, 3}] = epilogue, tile rows,
+ * tile columns, threads (< 0: unknown config).  `schedule` (device int32): [2 * n_bands] = (index of the band's first entry, entries) per band, then
+ * the entries op << 28 | M-tile << 16 | N-tile -- every tile of every op exactly once, a tile's producers (the N-tiles of op - 1 that cover its rows)
+ * earlier in the SAME band; n_bands <= 64, M-tiles per op <= 256.  A band is processed by the workgroups of one XCD (whichever claims it), tiles are
+ * handed from op to op through that XCD's L2; flags & 1 adds an agent-scope release before every hand-off.  `state`: TOC3D_CHAIN_STATE_BYTES of
+ * device memory, zeroed by the caller once (the launch re-arms it); one buffer per stream that may run a chain; word 1 is a sticky error code
+ * (1: a bounded wait gave up, 2: bad schedule entry).  grid = workgroups of 512 threads (about 2-3 per CU). */
+#define TOC3D_CHAIN_STATE_BYTES 3616
+typedef struct toc3d_chain_op {
+    int64_t epilogue;
+    const void* A; int64_t lda; const void* W; int64_t ldw; const float* bias;
+    void* out; int64_t ldo; const float* residual; int64_t ldr;
+    float* rep_out; const int32_t* rep_index;
+    int64_t M, N, K, n_valid;
+    float* stats_out; int64_t stats_out_cap; const float* stats_in; int64_t stats_in_cap; const float* col_sums; int64_t ln_n; double ln_eps;
+    void* out_act; int64_t ld_act; const int32_t* residual_index;
+} toc3d_chain_op_t;
+int toc3d_linear_chain(int dtype, int config, int64_t n_ops, const toc3d_chain_op_t* ops, const int32_t* schedule, int64_t n_bands, void* state,
+                       int64_t grid, int64_t flags, toc3d_stream_t stream);
+int toc3d_linear_chain_info(int config, int32_t* info);
 /* mlp.w1 / mlp.w2 interleaved as toc3d_pack_swiglu, scaled by norm2's gamma per input channel; c1 [2*Hp] = row sums of the ROUNDED scaled
  * weights, c2 [2*Hp] = beta . w + b, both in packed row order. */
 int toc3d_pack_swiglu_lnfold(int dtype, const float* w1, const float* w2, const float* b1, const float* b2, const float* gamma, const float* beta,

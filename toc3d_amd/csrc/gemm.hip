@@ -235,11 +235,12 @@ int toc3d_im2col_patches_u8(int dtype, const uint8_t* img, int64_t V, int64_t H,
     return TOC3D_OK;
 }
 
-int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                       void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
-                       float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
-                       float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
-                       void* out_act, int64_t ld_act, const int32_t* residual_index, toc3d_stream_t stream) {
+// argument checks of toc3d_linear_fused / of one op of toc3d_linear_chain; fills the kernel's argument block (M == 0 is accepted: a.M = 0)
+static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                      void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                      float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                      float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
+                      void* out_act, int64_t ld_act, const int32_t* residual_index) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3 || dtype == TOC3D_F32X6, "toc3d_linear: bad dtype %d", dtype);
     TOC3D_REQUIRE((dtype != TOC3D_F32X3 && dtype != TOC3D_F32X6) || epilogue <= TOC3D_EPI_GELU || epilogue == TOC3D_EPI_CONV3X3, "toc3d_linear: the bf16 x 3 / x 6 product forms serve epilogues 0-3 and the 3x3 conv");
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
@@ -279,7 +280,6 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
         TOC3D_REQUIRE(!residual || ldr >= N, "toc3d_linear: ldr < N");
         TOC3D_REQUIRE(!rep_index || rep_out, "toc3d_linear: rep_index set without rep_out");
     }
-    if (M == 0) return TOC3D_OK;
     // 4-wide epilogue accesses: every row start and column group must be 16-byte aligned in its own element size
     const int64_t osz = e_residual ? 4 : (dtype == TOC3D_BF16 ? 2 : 4);
     const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * osz) == 0 && (!residual || (ldr % 4 == 0 && (uintptr_t)residual % 16 == 0)) &&
@@ -287,7 +287,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     // wide (16-byte) bf16 stores need 16-byte aligned rows in the output's own element size (TOC3D_WIDE_STORES=0 disables them: A/B runs)
     static const bool wide_ok = [] { const char* e = getenv("TOC3D_WIDE_STORES"); return !(e && e[0] == '0'); }();
     const bool vec8 = wide_ok && vec && dtype == TOC3D_BF16 && !e_residual && epilogue != TOC3D_EPI_CONV3X3 && ldo % 8 == 0 && (uintptr_t)out % 16 == 0;
-    GemmArgs a{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
+    a = GemmArgs{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, vec8 ? 1 : 0,
                stats_out, (int)stats_out_cap, stats_in, (int)(stats_in_cap & 0xffffffff), (int)(stats_in_cap >> 32), col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
                0, 0, nullptr, nullptr, nullptr, 0, 1.0f};
@@ -297,6 +297,19 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
         TOC3D_REQUIRE(a.conv_h > 0 && a.conv_w > 0 && a.zeros && M % ((int64_t)a.conv_h * a.conv_w) == 0 && K == 9 * lda, "toc3d_linear: EPI_CONV3X3 goes through toc3d_conv3x3_nhwc");
         a.out_act = nullptr; a.ld_act = 0;
     }
+    return TOC3D_OK;
+}
+
+int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                       void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                       float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                       float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
+                       void* out_act, int64_t ld_act, const int32_t* residual_index, toc3d_stream_t stream) {
+    GemmArgs a;
+    const int rc_args = fused_args(a, dtype, epilogue, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index, M, N, K, n_valid,
+                                   stats_out, stats_out_cap, stats_in, stats_in_cap, col_sums, ln_n, ln_eps, out_act, ld_act, residual_index);
+    if (rc_args != TOC3D_OK) return rc_args;
+    if (M == 0) return TOC3D_OK;
     g_bad_variant = false;
     int rc = dtype == TOC3D_F32X3 ? toc3d_gemm_launch_x3(epilogue, variant, a, as_stream(stream))
              : dtype == TOC3D_F32X6 ? toc3d_gemm_launch_x6(epilogue, variant, a, as_stream(stream)) : launch_gemm(dtype == TOC3D_BF16, epilogue, variant, a, as_stream(stream));
@@ -304,6 +317,45 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab not a multiple of 32, or N-tile not a multiple of 128 for the statistics)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
     TOC3D_LAUNCH_CHECK("toc3d_linear");
     return TOC3D_OK;
+}
+
+int toc3d_linear_chain(int dtype, int config, int64_t n_ops, const toc3d_chain_op_t* ops, const int32_t* schedule, int64_t n_bands, void* state,
+                       int64_t grid, int64_t flags, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear_chain: bf16 only");
+    TOC3D_REQUIRE(ops && schedule && state && n_ops >= 2 && n_ops <= TOC3D_CHAIN_MAX_OPS, "toc3d_linear_chain: bad arguments");
+    TOC3D_REQUIRE(n_bands > 0 && n_bands <= TOC3D_CHAIN_MAX_BANDS && grid > 0 && grid <= 65535, "toc3d_linear_chain: n_bands in 1..%d, grid > 0", TOC3D_CHAIN_MAX_BANDS);
+    TOC3D_REQUIRE(((uintptr_t)state % 16) == 0 && ((uintptr_t)schedule % 4) == 0, "toc3d_linear_chain: misaligned state / schedule");
+    static_assert(TOC3D_CHAIN_STATE_BYTES == 4 * TOC3D_CHAIN_STATE_WORDS, "TOC3D_CHAIN_STATE_BYTES of include/toc3d.h");
+    int info[4 * TOC3D_CHAIN_MAX_OPS];
+    const int cfg_ops = toc3d_gemm_chain_info(config, info);
+    TOC3D_REQUIRE(cfg_ops == n_ops, "toc3d_linear_chain: config %d has %d ops, %lld given", config, cfg_ops, (long long)n_ops);
+    ChainArgs c{};
+    for (int i = 0; i < n_ops; ++i) {
+        const toc3d_chain_op_t& o = ops[i];
+        TOC3D_REQUIRE(o.epilogue == info[4 * i], "toc3d_linear_chain: op %d of config %d has epilogue %d, %lld given", i, config, info[4 * i], (long long)o.epilogue);
+        TOC3D_REQUIRE(o.M == ops[0].M && o.M > 0, "toc3d_linear_chain: every op works on the same M > 0 rows");
+        const int rc = fused_args(c.op[i].a, dtype, (int)o.epilogue, o.A, o.lda, o.W, o.ldw, o.bias, o.out, o.ldo, o.residual, o.ldr, 0, o.rep_out, o.rep_index,
+                                  o.M, o.N, o.K, o.n_valid, o.stats_out, o.stats_out_cap, o.stats_in, o.stats_in_cap, o.col_sums, o.ln_n, (float)o.ln_eps,
+                                  o.out_act, o.ld_act, o.residual_index);
+        if (rc != TOC3D_OK) return rc;
+        c.op[i].dep = i - 1;
+        c.op[i].publish = i + 1 < n_ops;
+    }
+    c.n_ops = (int)n_ops;
+    c.n_bands = (int)n_bands;
+    c.sched = schedule;
+    c.state = reinterpret_cast<unsigned*>(state);
+    c.max_polls = 1u << 22;                              // x ~0.3 us per poll: about a second, then the launch gives up instead of hanging
+    c.full_release = (int)(flags & 1);
+    const int rc = toc3d_gemm_chain_launch(config, c, (int)grid, as_stream(stream));
+    if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear_chain: config %d cannot run these ops (M-tiles per op <= %d, K a multiple of 64)", config, TOC3D_CHAIN_MAX_MT); return rc; }
+    TOC3D_LAUNCH_CHECK("toc3d_linear_chain");
+    return TOC3D_OK;
+}
+
+int toc3d_linear_chain_info(int config, int32_t* info) {
+    TOC3D_REQUIRE(info, "toc3d_linear_chain_info: null buffer");
+    return toc3d_gemm_chain_info(config, info);
 }
 
 int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const void* W, int64_t ldw, const float* bias, float* out, int64_t ldo,

@@ -59,6 +59,31 @@ int toc3d_gemm_launch_rope(int is_bf16, int epi, int variant, const GemmArgs& a,
 int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 3 products on f32 operands: epilogues 0-3, 8
 int toc3d_gemm_launch_x6(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 6 (three-way split): f32-grade products
 
+// ---- GEMM chains (gemm_chain.hip; include/toc3d.h, toc3d_linear_chain): several dependent GEMMs of one block half in ONE persistent launch ----
+constexpr int TOC3D_CHAIN_MAX_OPS = 3;
+constexpr int TOC3D_CHAIN_MAX_MT = 256;                 // M-tiles per op
+constexpr int TOC3D_CHAIN_MAX_BANDS = 64;
+// state words (unsigned, zero before the first launch; the last workgroup of every launch zeroes them again, word 1 excepted):
+//   [0] workgroups that left   [1] sticky error code   [8 + b] owner of band b (0 = free, XCC id + 1)   [8 + 64 + b] queue head of band b
+//   [8 + 128 + op * 256 + mt] finished tiles of (op, M-tile mt)
+constexpr int TOC3D_CHAIN_STATE_WORDS = 8 + 2 * TOC3D_CHAIN_MAX_BANDS + TOC3D_CHAIN_MAX_OPS * TOC3D_CHAIN_MAX_MT;
+struct ChainOp {
+    GemmArgs a;
+    int dep;                                             // op whose row panels this op's A operand / residual / statistics come from (-1: inputs of the launch)
+    int dep_need, dep_bm;                                // N-tiles per M-tile of that op, its M-tile height
+    int publish;                                         // a later op waits for this op's row panels
+};
+struct ChainArgs {
+    ChainOp op[TOC3D_CHAIN_MAX_OPS];
+    int n_ops, n_bands;
+    const int32_t* sched;                                // [2 * n_bands] (first entry, entries) per band, then the entries: op << 28 | M-tile << 16 | N-tile
+    unsigned* state;
+    unsigned max_polls;                                  // bound of every spin (then: error code in state[1], the launch finishes with wrong data instead of hanging)
+    int full_release;                                    // 1: agent-scope release before every publish (placement-independent even if a band's tiles ran on two XCDs)
+};
+int toc3d_gemm_chain_launch(int config, ChainArgs& c, int grid, hipStream_t s);     // fills dep_need / dep_bm from the config's tile shapes
+int toc3d_gemm_chain_info(int config, int* info);                                  // info[4 * op + {0,1,2,3}] = epilogue, BM, BN, threads; returns the number of ops (< 0: unknown config)
+
 // Development instrumentation (tools/ubench/gemm_timeline.hip builds its own copy of these kernels with -DTOC3D_GEMM_TRACE; the library
 // never defines it): every workgroup leaves the 100 MHz real-time counter at entry, after its K loop and after its epilogue stores have
 // been acknowledged, plus the hardware id of the CU it ran on.
@@ -486,10 +511,11 @@ TOC3D_DEV void split_bf16x6(const Frag<float>& f, bf16x8& hi, bf16x8& mid, bf16x
     }
 }
 
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int OCC, int X3 = 0>
-__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
+// One BM x BN output tile (rows m0.., columns n0..) by the calling workgroup of 64 * WM * WN threads: K loop + fused epilogue.  `smem` = the
+// workgroup's dynamic LDS.  gemm_kernel below runs one tile per workgroup; gemm_chain_kernel walks a queue of tiles of several GEMMs.
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int X3 = 0>
+TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* smem) {
     static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4), "the bf16 x 3 / x 6 product forms run on f32 operands");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
     constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
     constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
@@ -499,26 +525,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, g = lane >> 4;
-    TOC3D_TRACE(0);
-
-    const int tiles_n = (a.N + BN - 1) / BN;
-    const int tiles_m = (a.M + BM - 1) / BM;
-    int m0, n0;
-    if (a.order == 0) {
-        const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-        m0 = (tile / tiles_n) * BM;
-        n0 = (tile % tiles_n) * BN;
-    } else {
-        // Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Each XCD owns a band of M-tile rows
-        // whose A panels (band * K bytes, ~1.5 MB) stay resident in its 4 MB L2, and walks the W panels one after the
-        // other (m fastest), so every W panel is fetched from memory once per XCD instead of once per A row-panel.
-        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-        const int r0 = (xcd * tiles_m) >> 3, r1 = ((xcd + 1) * tiles_m) >> 3;
-        const int band = r1 - r0;
-        if (band <= 0 || l >= band * tiles_n) return;
-        m0 = (r0 + l % band) * BM;
-        n0 = (l / band) * BN;
-    }
 
     const T* A = reinterpret_cast<const T*>(a.A);
     const T* W = reinterpret_cast<const T*>(a.W);
@@ -736,6 +742,31 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     } else {
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
     }
+}
+
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int OCC, int X3 = 0>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TOC3D_TRACE(0);
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    int m0, n0;
+    if (a.order == 0) {
+        const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        m0 = (tile / tiles_n) * BM;
+        n0 = (tile % tiles_n) * BN;
+    } else {
+        // Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Each XCD owns a band of M-tile rows
+        // whose A panels (band * K bytes, ~1.5 MB) stay resident in its 4 MB L2, and walks the W panels one after the
+        // other (m fastest), so every W panel is fetched from memory once per XCD instead of once per A row-panel.
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int r0 = (xcd * tiles_m) >> 3, r1 = ((xcd + 1) * tiles_m) >> 3;
+        const int band = r1 - r0;
+        if (band <= 0 || l >= band * tiles_n) return;
+        m0 = (r0 + l % band) * BM;
+        n0 = (l / band) * BN;
+    }
+    gemm_tile<T, EPI, BM, BN, STAGES, RB, WM, WN, X3>(a, m0, n0, smem);
     TOC3D_TRACE_END();
 }
 

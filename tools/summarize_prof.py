@@ -13,7 +13,7 @@ cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 10 --warmup
 
 
 def family(name):
-    for key in ("gemm_phased_kernel", "gemm_kernel", "attn_small_kernel", "attn_kernel", "ln_rows_kernel", "ln_act_kernel", "ln_rebase_kernel", "gather_merge_ln_kernel", "scatter_update_kernel",
+    for key in ("gemm_chain_kernel", "gemm_phased_kernel", "gemm_kernel", "attn_rot_kernel", "attn_small_kernel", "attn_kernel", "ln_rows_kernel", "ln_act_kernel", "ln_rebase_kernel", "gather_merge_ln_kernel", "scatter_update_kernel",
                 "window_topk_kernel", "rank_desc_kernel", "motion_queries_kernel", "collapse_kernel", "score_tokens_kernel", "im2col", "nhwc_to_nchw",
                 "abs_pos", "pack_", "window_map_dense", "score_head", "global_mean_half", "copy_segments", "copy_bytes", "prefetch"):
         if key in name:
@@ -36,9 +36,9 @@ with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"), "w") as fo:
         fo.write(f"\"{k}\",{v[0]},{v[1] / 1e3:.1f},{v[1] / v[0] / 1e3:.2f},{100 * v[1] / tot:.2f}\n")
     fo.write("\nname,calls,total_us,avg_us\n")
     for r in rows:
-        if "gemm_kernel" in r["Name"] or "gemm_phased_kernel" in r["Name"]:
+        if "gemm_kernel" in r["Name"] or "gemm_phased_kernel" in r["Name"] or "gemm_chain_kernel" in r["Name"]:
             fo.write(f"\"{r['Name'][:160]}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.1f},{float(r['AverageNs']) / 1e3:.2f}\n")
-g = [fam["gemm_kernel"][0] + fam["gemm_phased_kernel"][0], fam["gemm_kernel"][1] + fam["gemm_phased_kernel"][1]]
+g = [sum(fam[k][0] for k in ("gemm_kernel", "gemm_phased_kernel", "gemm_chain_kernel")), sum(fam[k][1] for k in ("gemm_kernel", "gemm_phased_kernel", "gemm_chain_kernel"))]
 print(f"GEMM: {g[0]} launches, avg {g[1] / g[0] / 1e3:.2f} us, {100 * g[1] / tot:.1f}% of kernel time")
 
 
@@ -51,6 +51,8 @@ def pmc(dirname, prefix, counter):
     return n, s / max(n, 1)
 
 
+if not os.path.exists(os.path.join(out, "fs", "fs_counter_collection.csv")):
+    sys.exit(0)                                           # kernel trace only: no PMC passes in this directory
 nf, fetch = pmc("fs", "fs", "FETCH_SIZE")
 nw, write = pmc("wsz", "wsz", "WRITE_SIZE")
 js = {"kernel": "gemm_kernel<*> (all toc3d_linear launches of the step)", "launches_in_trace": nf,
