@@ -59,6 +59,10 @@ extern "C" {
 #define TOC3D_EPI_RESIDUAL_STATS 6    /* RESIDUAL + act-dtype copy of the output rows + their per-row statistics (toc3d_linear_fused) */
 #define TOC3D_EPI_SWIGLU_STATS_LN 7   /* SWIGLU_STATS with a LayerNorm of the A rows folded into the epilogue   (toc3d_linear_fused) */
 #define TOC3D_EPI_CONV3X3 8           /* out(f32) = conv3x3(NHWC act tensor) + bias as an implicit GEMM          (toc3d_conv3x3_nhwc) */
+#define TOC3D_EPI_RESIDUAL_ACT 10         /* RESIDUAL + act-dtype copy of the output rows (no statistics)                 (toc3d_linear_fused) */
+#define TOC3D_EPI_SWIGLU_LNSELF 11        /* SWIGLU of LayerNorm(A rows), the row statistics taken by this GEMM's own K loop (toc3d_linear_fused) */
+#define TOC3D_EPI_RESIDUAL_LNSELF 12      /* RESIDUAL of LayerNorm(A rows) the same way (+ optional act-dtype copy)          (toc3d_linear_fused) */
+#define TOC3D_EPI_QKV_ROPE_LNSELF 13      /* QKV_ROPE of LayerNorm(A rows) the same way                                      (toc3d_linear_qkv_rope_ln) */
 #define TOC3D_EPI_QKV_ROPE 9          /* out(act) = [rope(q) * scale | rope(k) | v] of the fused q|k|v projection  (toc3d_linear_qkv_rope) */
 
 typedef void* toc3d_stream_t;
@@ -122,6 +126,12 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
  *                          columns (N-tiles must be multiples of 64); stats_out_cap >= ceil(N / 64).
  *   EPI_SWIGLU_STATS_LN  = EPI_SWIGLU_STATS on A = out_act with W = gamma-scaled interleaved weights, bias = c2, col_sums = c1 in packed column
  *                          order (toc3d_pack_swiglu_lnfold); reads stats_in, writes stats_out (different buffers).
+ *   EPI_RESIDUAL_ACT     = EPI_RESIDUAL + out_act [M, ld_act] (the act-dtype copy only, no statistics).
+ *   EPI_SWIGLU_LNSELF / EPI_RESIDUAL_LNSELF = the LayerNorm-folding forms above (same W, bias = c2, col_sums = c1, ln_n, ln_eps) WITHOUT a
+ *                          statistics hand-off: K spans the whole normalised row (norm2 in front of w1|w2: K = C; ffn_ln in front of w3: K = padded
+ *                          hidden width, pad columns zero), so the kernel takes (sum, sum of squares) of every A row from the operand fragments its
+ *                          MFMAs consume -- stats_in / stats_out are not used, no LayerNorm launch and no statistics buffer anywhere.  Per row the
+ *                          sums are formed in one fixed order for every tile variant.  EPI_RESIDUAL_LNSELF also writes out_act when it is non-NULL.
  * stats_out / stats_in: int32 header [4] + f32 [M, cap, 2] each; stats_in_cap may carry the number of slots per row the producer wrote in its
  * upper 32 bits (cap | slots << 32) when the host knows it, which saves the consumer the dependent read of the header; ln_n = width of the normalised rows (valid hidden units for EPI_RESIDUAL_LN,
  * K for EPI_SWIGLU_STATS_LN).  residual_index (int32 [M] or NULL, residual epilogues): output row m takes its residual from row
@@ -162,6 +172,10 @@ typedef struct toc3d_chain_op {
 int toc3d_linear_chain(int dtype, int config, int64_t n_ops, const toc3d_chain_op_t* ops, const int32_t* schedule, int64_t n_bands, void* state,
                        int64_t grid, int64_t flags, toc3d_stream_t stream);
 int toc3d_linear_chain_info(int config, int32_t* info);
+/* Development instrumentation: chains launched afterwards (by any thread) leave per-tile time stamps in `buf` (device, zeroed by the caller):
+ * uint64 [0] = tiles recorded, then per tile 8 words: XCC+1 << 56 | workgroup << 32 | schedule entry; the 100 MHz real-time counter before the
+ * dequeue, after it, after the dependency wait, after the tile, after the publish; HW_ID; 0.  (NULL, 0) switches it off (the default). */
+int toc3d_linear_chain_trace(void* buf, int64_t entries);
 /* mlp.w1 / mlp.w2 interleaved as toc3d_pack_swiglu, scaled by norm2's gamma per input channel; c1 [2*Hp] = row sums of the ROUNDED scaled
  * weights, c2 [2*Hp] = beta . w + b, both in packed row order. */
 int toc3d_pack_swiglu_lnfold(int dtype, const float* w1, const float* w2, const float* b1, const float* b2, const float* gamma, const float* beta,
@@ -307,6 +321,12 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
 int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
                           int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
                           float q_scale, toc3d_stream_t stream);
+/* The same with norm1 folded in (EPI_QKV_ROPE_LNSELF; eva_vit.py:258-262): A = the act-dtype copy of the residual-stream rows (left by the previous
+ * block's w3 GEMM, EPI_RESIDUAL_LNSELF out_act), W = gamma1-scaled q|k|v weights, bias = c2 = W.beta1 + b, col_sums = c1 = row sums of the rounded
+ * scaled W (toc3d_pack_weight_lnfold), ln_n = C; the row statistics come from the kernel's own K loop (K = C spans the row). */
+int toc3d_linear_qkv_rope_ln(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                             int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
+                             float q_scale, const float* col_sums, int64_t ln_n, float ln_eps, toc3d_stream_t stream);
 int toc3d_window_attention_rot(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows, const int32_t* slots,
                                const int32_t* count, const int32_t* count_k, const int32_t* npad, const void* pad_rot, int64_t stride,
                                int64_t nwin, int64_t max_count, int64_t num_heads, const float* v_bias,

@@ -165,6 +165,9 @@ _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28,
              lib.F32X3: (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 114, 116, 117, 122, 126, 149)}
 _VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3]
 
+_TABLE_ALIAS = {lib.EPI_RESIDUAL_ACT: lib.EPI_RESIDUAL, lib.EPI_SWIGLU_LNSELF: lib.EPI_SWIGLU_STATS, lib.EPI_RESIDUAL_LNSELF: lib.EPI_RESIDUAL_LN}
+
+
 def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED):
     """toc3d_linear_fused with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
     real operands the first time the shape is seen (never while a launch plan is being recorded: shapes are warmed up eagerly).
@@ -176,15 +179,21 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
     key = (epi, M, N, K)
     var = self._tuned.get(key)
     s = lib.stream_ptr()
-    if epi == lib.EPI_QKV_ROPE:
+    if epi in (lib.EPI_QKV_ROPE, lib.EPI_QKV_ROPE_LNSELF):
         # the rotating epilogue costs what the bias epilogue costs: it shares that epilogue's tile table (no second tuning sweep)
         rope = fused
         if var is None:
             var = self._tuned.get((lib.EPI_BIAS, M, N, K), 0)
         if var % 100 in (60, 61, 62, 63):                        # the phased tiles do not carry the RoPE tables
             var = 0
-        lib.call("toc3d_linear_qkv_rope", dtg, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
+        lib.call("toc3d_linear_qkv_rope" if epi == lib.EPI_QKV_ROPE else "toc3d_linear_qkv_rope_ln", dtg, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
         return
+    if var is None and epi in _TABLE_ALIAS:
+        # the self-normalising epilogues run the K loop and the tile shapes of the statistics-passing forms: a shipped table's entry for
+        # those serves them until this shape is tuned under its own key
+        var = self._tuned.get((_TABLE_ALIAS[epi], M, N, K))
+        if var is not None and var % 100 in (60, 61, 62, 63):
+            var = None
     if var is None:
         var = 0
         if lib.recording():
@@ -193,15 +202,15 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
             return
         if self.autotune and not torch.cuda.is_current_stream_capturing():
             o = out
-            if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # in-place residual add: tune into scratch
+            if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS, lib.EPI_RESIDUAL_ACT, lib.EPI_RESIDUAL_LNSELF):   # in-place residual add: tune into scratch
                 o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
             rep_s = torch.empty_like(rep_out) if rep_out is not None else None
             cands = _VARIANTS[dtg]
-            if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):
+            if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN, lib.EPI_SWIGLU_LNSELF):
                 cands = [v for v in cands if v not in (33, 45, 145, 52, 53, 152)]   # wave slabs that are not whole (w1, w2) 32-column groups
             if epi in (lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):  # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
                 cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47, 60, 63)]
-            if epi in (lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # the phased tiles do not carry the folded-LayerNorm epilogues
+            if epi in (lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS, lib.EPI_RESIDUAL_ACT, lib.EPI_RESIDUAL_LNSELF, lib.EPI_SWIGLU_LNSELF):   # the phased tiles do not carry the folded-LayerNorm epilogues
                 cands = [v for v in cands if v % 100 not in (60, 63)]
             # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
             # L2 / Infinity Cache): time single launches behind a cache-sized memset, not a warm back-to-back loop, or the
@@ -292,6 +301,14 @@ class _BackboneBase(nn.Module):
         # Measured neutral (same-box A/B 191.1 vs 189.2 frames/s: the 6-8 us LayerNorm launches it removes cost what the extra epilogue phases of the
         # latency-bound N = 1024 projection GEMMs cost), so it is OFF by default; TOC3D_FOLD_N2=1 enables it (7 launches per accelerated block).
         self.fold_norm2 = self.fold_ffn_ln and os.environ.get("TOC3D_FOLD_N2", "0") != "0"
+        # round 3, measured and OFF by default (TOC3D_LN_SELF=1 / 2 enables it): the LayerNorms folded into the CONSUMING GEMM alone -- its K loop
+        # spans the whole normalised row (norm1 / norm2: K = C, ffn_ln: K = the hidden width), so it takes the row statistics from the operand tiles it
+        # multiplies anyway (EPI_*_LNSELF, include/toc3d.h): no LayerNorm launch, no statistics buffer; the producer only leaves a bf16 copy of its
+        # rows (EPI_RESIDUAL_ACT).  Correct and slightly more accurate than the explicit launches (tests/test_gpu_lnself.py) but slower: the K loops
+        # do not tolerate the extra LDS read + statistics work per K step (three forms tried, profiles/r03_lnself.txt: -4.5 % ... -7 % frames/s with
+        # norm2 + ffn_ln, -12 % ... -23 % with norm1 of the dense blocks as well, against +0.17 ms of LayerNorm launches saved).
+        self.ln_self = self.fold_ffn_ln and os.environ.get("TOC3D_LN_SELF", "0") != "0"
+        self.ln_self_norm1 = self.ln_self and os.environ.get("TOC3D_LN_SELF", "0") not in ("0", "1")      # TOC3D_LN_SELF=2: norm1 of the dense blocks as well
         # the gather kernel skips the f32 copy of the kept rows (40 % of its bytes); the projection GEMM reads their residual from x through
         # crow_tok instead (toc3d_gather_merge_ln_ex kept_copy = 0 + toc3d_linear_fused residual_index).  Same bits either way.
         self.gathered_residual = os.environ.get("TOC3D_GATHERED_RES", "1") != "0"
@@ -343,6 +360,9 @@ class _BackboneBase(nn.Module):
         return new
 
     # -- helpers ---------------------------------------------------------------------------------------
+    def _accelerated(self, i):
+        return False                                      # dense backbone: every block is Block.forward (ToC3DEVAViT overrides)
+
     @property
     def _dt(self):
         return lib.BF16 if self.precision == "bf16" else lib.F32
@@ -392,7 +412,7 @@ class _BackboneBase(nn.Module):
             lib.call("toc3d_pack_swiglu", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias),
                      self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
             p["w12"], p["b12"] = w12, b12
-            if self.fold_norm2:                                   # gamma2-scaled interleaved weights + (c1, c2) in packed column order; replaces w12 / b12
+            if self.fold_norm2 or self.ln_self:                   # gamma2-scaled interleaved weights + (c1, c2) in packed column order; replaces w12 / b12
                 p["c1_12"], p["c2_12"] = torch.empty(2 * Hp, device=dev), torch.empty(2 * Hp, device=dev)
                 lib.call("toc3d_pack_swiglu_lnfold", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias), self._f32(m.w2.bias),
                          self._f32(blk.norm2.weight), self._f32(blk.norm2.bias), Hd, C, w12, p["c1_12"], p["c2_12"], Hp, C, lib.stream_ptr())
@@ -405,6 +425,13 @@ class _BackboneBase(nn.Module):
                 p["w3"] = w3f                                     # gamma-scaled; c1 / c2 carry the mean and beta / bias terms
             else:
                 p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
+            if self.ln_self_norm1 and self.attn_rot and not self._accelerated(len(blocks)):
+                # norm1 folded into q|k|v the same way (dense blocks): gamma1-scaled weights, c1 = their row sums, c2 = W.beta1 + bias
+                wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)
+                p["wqkv_ln"] = torch.zeros(_round_up(3 * C, 128), C, dtype=self._tdt, device=dev)
+                p["c1_qkv"], p["c2_qkv"] = torch.empty(3 * C, device=dev), torch.empty(3 * C, device=dev)
+                lib.call("toc3d_pack_weight_lnfold", self._dt, self._f32(wq).contiguous(), self._f32(blk.norm1.weight), self._f32(blk.norm1.bias), p["bqkv"],
+                         3 * C, C, p["wqkv_ln"], p["wqkv_ln"].shape[0], C, p["c1_qkv"], p["c2_qkv"], lib.stream_ptr())
             for n, mod in (("ln1", blk.norm1), ("ln2", blk.norm2), ("lnf", m.ffn_ln)):
                 p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
             p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
@@ -550,6 +577,14 @@ class _BackboneBase(nn.Module):
         C = self.embed_dim
         Kp = plan["col"].shape[1]
         pos = P["pos"][(plan["h"], plan["w"])]
+        plan["a_is_x"] = False
+        if self.ln_self_norm1 and self.attn_rot and not self._accelerated(0):
+            # the first block's q|k|v normalises its own rows: the stem leaves them in bf16 as well
+            self._linear(lib.EPI_RESIDUAL_ACT, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
+                         plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, None, plan["M"], C, Kp, 0,
+                         fused=lib.NO_FUSED[:7] + (plan["a"], C, None))
+            plan["a_is_x"] = True
+            return
         self._linear(lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
                      plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, None, plan["M"], C, Kp, 0)
 
@@ -575,13 +610,18 @@ class _BackboneBase(nn.Module):
         nb = (ctypes.c_int64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
         lib.call("toc3d_window_attention_pf", *args, len(ts), ptrs, nb, self.prefetch_weights, s)
 
-    def _qkv_attention(self, P, i, plan, M, rope_rc, arows, aslots, count_q, count_k, npad, pad, stride, nwin, max_count, v_bias):
-        """q|k|v projection + windowed attention of block i on plan["a"] [M, C] -> plan["att"] (eva_vit.py:97-113, toc3d_eva_vit.py:495-512)."""
+    def _qkv_attention(self, P, i, plan, M, rope_rc, arows, aslots, count_q, count_k, npad, pad, stride, nwin, max_count, v_bias, norm1_self=False):
+        """q|k|v projection + windowed attention of block i on plan["a"] [M, C] -> plan["att"] (eva_vit.py:97-113, toc3d_eva_vit.py:495-512).
+        norm1_self: plan["a"] holds the raw bf16 rows of x and the projection normalises them itself (EPI_QKV_ROPE_LNSELF)."""
         bp = P["blocks"][i]
         C, dt = self.embed_dim, self._dt
         if self.attn_rot and stride <= 416:
-            self._linear(lib.EPI_QKV_ROPE, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
-                         fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5))
+            if norm1_self:
+                self._linear(lib.EPI_QKV_ROPE_LNSELF, plan["a"], C, bp["wqkv_ln"], C, bp["c2_qkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
+                             fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5, bp["c1_qkv"], C, self.LN_EPS))
+            else:
+                self._linear(lib.EPI_QKV_ROPE, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
+                             fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5))
             import ctypes
             ts = [bp["wproj"], bp["w12"], bp["w3"]] + ([P["blocks"][i + 1]["wqkv"]] if i + 1 < self.depth else [])
             if not self.prefetch_weights:
@@ -601,19 +641,30 @@ class _BackboneBase(nn.Module):
         norm2 folded the epilogue also leaves the updated rows in bf16 (plan["a"]) and their statistics (plan["stats2"]) for the w1|w2 GEMM."""
         C = self.embed_dim
         res = out if res is None else res
-        if self.fold_norm2:
+        if self.ln_self:
+            self._linear(lib.EPI_RESIDUAL_ACT, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
+                         fused=lib.NO_FUSED[:7] + (plan["a"], C, res_index))
+        elif self.fold_norm2:
             self._linear(lib.EPI_RESIDUAL_STATS, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
                          fused=(plan["stats2"], plan["stats2_cap"], None, 0, None, 0, 0.0, plan["a"], C, res_index))
         else:
             self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
                          fused=lib.NO_FUSED[:9] + (res_index,))
 
-    def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
-        """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
+    def _mlp(self, bp, plan, rows, res, rep_out, rep_index, copy_out=False):
+        """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C].
+        copy_out (ln_self): the w3 GEMM also leaves its rows in bf16 in plan["a"] (the next block's q|k|v normalises them itself)."""
         s = lib.stream_ptr()
         C, Hd = self.embed_dim, self.hidden_dim
         Hp = plan["hid"].shape[1]
         dt = self._dt
+        if self.ln_self:
+            # both LayerNorms inside the consuming GEMMs: plan["a"] = the bf16 rows the projection left (_proj)
+            self._linear(lib.EPI_SWIGLU_LNSELF, plan["a"], C, bp["w12"], C, bp["c2_12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
+                         fused=(None, 0, None, 0, bp["c1_12"], C, self.LN_EPS, None, 0, None))
+            self._linear(lib.EPI_RESIDUAL_LNSELF, plan["hid"], Hp, bp["w3"], bp["w3"].shape[1], bp["c2"], res, C, res, C, 0,
+                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, None, 0, bp["c1"], Hd, self.LN_EPS, plan["a"] if copy_out else None, C if copy_out else 0, None))
+            return
         if self.fold_ffn_ln:
             # ffn_ln folded: the SwiGLU GEMM leaves per-row (sum, sum^2) slots, the w3 GEMM (gamma-scaled weights) normalises in its epilogue;
             # norm2 folded the same way: plan["a"] / plan["stats2"] were left by the projection GEMM (_proj), no LayerNorm launch here
@@ -641,10 +692,17 @@ class _BackboneBase(nn.Module):
         C, M, dt = self.embed_dim, plan["M"], self._dt
         x = plan["x"]
         dm = plan["dense"][self._block_side(i)]
-        lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
-        self._qkv_attention(P, i, plan, M, dm.get("rc"), dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None, dm["N"], dm["nW"], dm["max_count"], bp["v_bias"])
+        # norm1: by the q|k|v GEMM itself when the previous launch left the bf16 rows of x (the stem or the previous dense block's w3), else its own launch
+        n1_self = self.ln_self_norm1 and self.attn_rot and dm["N"] <= 416 and bool(plan.get("a_is_x")) and "wqkv_ln" in bp
+        if not n1_self:
+            lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
+        self._qkv_attention(P, i, plan, M, dm.get("rc"), dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None, dm["N"], dm["nW"], dm["max_count"], bp["v_bias"],
+                            norm1_self=n1_self)
         self._proj(bp, plan, M, x, None, None)
-        self._mlp(bp, plan, M, x, None, None)
+        nxt = i + 1 < self.depth and not self._accelerated(i + 1) and "wqkv_ln" in P["blocks"][i + 1]
+        nxt = nxt and self.ln_self_norm1 and self.attn_rot and plan["dense"][self._block_side(i + 1)]["N"] <= 416
+        self._mlp(bp, plan, M, x, None, None, copy_out=nxt)
+        plan["a_is_x"] = bool(nxt)
 
     # -- view groups: independent views processed concurrently on separate HIP streams ----------
     def _group_layout(self, V, B):
@@ -1048,6 +1106,7 @@ class ToC3DEVAViT(_BackboneBase):
         s = lib.stream_ptr()
         bp = P["blocks"][i]
         C, dt = self.embed_dim, self._dt
+        plan["a_is_x"] = False                            # plan["a"] holds compact rows from here on
         if plan.get("side_L") == self._block_side(i):     # this window type's selection was computed on the side lane
             self._join_side(ex, lane, side, plan)
             plan["side_L"] = None

@@ -66,6 +66,9 @@ TOC3D_DEV Frag<float> read_frag(const float* p) {
     Frag<float> f; f.lo = *reinterpret_cast<const f32x4*>(p); f.hi = *reinterpret_cast<const f32x4*>(p + 4); return f;
 }
 
+TOC3D_DEV bf16_t gemm_frag_elem(const Frag<bf16_t>& f, int e) { return f.v[e]; }
+TOC3D_DEV float gemm_frag_elem(const Frag<float>& f, int e) { return e < 4 ? f.lo[e] : f.hi[e - 4]; }
+
 // one 32-wide K step of a 16x16 output tile
 TOC3D_DEV void mma_step(f32x4& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);

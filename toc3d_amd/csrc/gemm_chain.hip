@@ -64,6 +64,8 @@ __global__ __launch_bounds__(512, OCC) void gemm_chain_kernel(ChainArgs c) {
     int band = -1, scan = 0;                                                       // lane 0's cursor: the band it pulls from, the first band worth looking at
 
     for (;;) {
+        unsigned long long tr[5];
+        if (c.trace && tid == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
         // ---- one lane fetches the next tile: from the XCD's current band, else from the next band this XCD owns or can still claim ----
         if (tid == 0) {
             int entry = -1;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_chain_kernel(ChainArgs c) {
         const int entry = *mbox;
         if (entry < 0) break;
         const int op = (entry >> 28) & 7, mt = (entry >> 16) & 0xfff, nt = entry & 0xffff;
+        if (c.trace && tid == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
         // ---- wait for the row panels this tile reads ----
         const int dep = op == 0 ? c.op[0].dep : (op == 1 ? c.op[1].dep : c.op[2].dep);
         if (dep >= 0) {
@@ -111,10 +114,12 @@ __global__ __launch_bounds__(512, OCC) void gemm_chain_kernel(ChainArgs c) {
             }
             lds_barrier();
         }
+        if (c.trace && tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
         if (op == 0) chain_tile<C0>(c.op[0].a, mt, nt, smem);
         else if (op == 1) chain_tile<C1>(c.op[1].a, mt, nt, smem);
         else if (op == 2) chain_tile<C2>(c.op[2].a, mt, nt, smem);
         else if (tid == 0) __hip_atomic_store(state + 1, (unsigned)CHAIN_ERR_SCHED, TOC3D_RLX_AGENT);
+        if (c.trace && tid == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
         // ---- publish the tile: its stores are acknowledged by the L2 before the counter moves ----
         const int publish = op == 0 ? c.op[0].publish : (op == 1 ? c.op[1].publish : c.op[2].publish);
         if (publish) {
@@ -126,6 +131,16 @@ __global__ __launch_bounds__(512, OCC) void gemm_chain_kernel(ChainArgs c) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the wait hipcc may drop behind buffer_wbl2 (Guideline 16, pitfall 12)
                 }
                 __hip_atomic_fetch_add(done + op * TOC3D_CHAIN_MAX_MT + mt, 1u, TOC3D_RLX_AGENT);
+            }
+        }
+        if (c.trace && tid == 0) {
+            tr[4] = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long slot = __hip_atomic_fetch_add(c.trace, 1ull, TOC3D_RLX_AGENT);
+            if (slot < (unsigned long long)c.trace_cap) {
+                unsigned long long* t = c.trace + 1 + slot * 8;
+                t[0] = ((unsigned long long)me << 56) | ((unsigned long long)blockIdx.x << 32) | (unsigned)entry;
+                for (int q = 0; q < 5; ++q) t[1 + q] = tr[q];
+                t[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
             }
         }
     }
@@ -193,7 +208,15 @@ int chain_dispatch(int config, ChainArgs* c, int grid, hipStream_t s, int* info)
 
 }  // namespace
 
-int toc3d_gemm_chain_launch(int config, ChainArgs& c, int grid, hipStream_t s) { return chain_dispatch(config, &c, grid, s, nullptr); }
+static std::atomic<unsigned long long*> g_chain_trace{nullptr};
+static std::atomic<int> g_chain_trace_cap{0};
+void toc3d_gemm_chain_set_trace(void* buf, int entries) { g_chain_trace_cap.store(entries); g_chain_trace.store(reinterpret_cast<unsigned long long*>(buf)); }
+
+int toc3d_gemm_chain_launch(int config, ChainArgs& c, int grid, hipStream_t s) {
+    c.trace = g_chain_trace.load();
+    c.trace_cap = g_chain_trace_cap.load();
+    return chain_dispatch(config, &c, grid, s, nullptr);
+}
 int toc3d_gemm_chain_info(int config, int* info) {
     const int rc = chain_dispatch(config, nullptr, 0, nullptr, info);
     return rc > 0 ? rc : -1;

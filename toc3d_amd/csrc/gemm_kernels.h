@@ -56,6 +56,7 @@ int toc3d_gemm_launch_plain(int is_bf16, int epi, int variant, const GemmArgs& a
 int toc3d_gemm_launch_residual(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);   // EPI_RESIDUAL, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS
 int toc3d_gemm_launch_swiglu(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);     // EPI_SWIGLU, EPI_SWIGLU_STATS, EPI_SWIGLU_STATS_LN
 int toc3d_gemm_launch_rope(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);       // EPI_QKV_ROPE (bf16)
+int toc3d_gemm_launch_lnself(int epi, int variant, const GemmArgs& a, hipStream_t s);                   // bf16: EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF
 int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 3 products on f32 operands: epilogues 0-3, 8
 int toc3d_gemm_launch_x6(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 6 (three-way split): f32-grade products
 
@@ -80,8 +81,10 @@ struct ChainArgs {
     unsigned* state;
     unsigned max_polls;                                  // bound of every spin (then: error code in state[1], the launch finishes with wrong data instead of hanging)
     int full_release;                                    // 1: agent-scope release before every publish (placement-independent even if a band's tiles ran on two XCDs)
+    unsigned long long* trace; int trace_cap;            // development: [0] = entries used, then [trace_cap][8] per-tile time stamps (toc3d_chain_set_trace); null in production
 };
 int toc3d_gemm_chain_launch(int config, ChainArgs& c, int grid, hipStream_t s);     // fills dep_need / dep_bm from the config's tile shapes
+void toc3d_gemm_chain_set_trace(void* buf, int entries);
 int toc3d_gemm_chain_info(int config, int* info);                                  // info[4 * op + {0,1,2,3}] = epilogue, BM, BN, threads; returns the number of ops (< 0: unknown config)
 
 // Development instrumentation (tools/ubench/gemm_timeline.hip builds its own copy of these kernels with -DTOC3D_GEMM_TRACE; the library
@@ -111,9 +114,16 @@ namespace {
 
 
 
-constexpr bool epi_is_swiglu(int epi) { return epi == TOC3D_EPI_SWIGLU || epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN; }
-constexpr bool epi_is_residual(int epi) { return epi == TOC3D_EPI_RESIDUAL || epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_RESIDUAL_STATS || epi == TOC3D_EPI_CONV3X3; }
-constexpr bool epi_ln_in(int epi) { return epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_SWIGLU_STATS_LN; }        // LayerNorm of the A rows folded in
+constexpr bool epi_is_swiglu(int epi) { return epi == TOC3D_EPI_SWIGLU || epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN || epi == TOC3D_EPI_SWIGLU_LNSELF; }
+constexpr bool epi_is_residual(int epi) {
+    return epi == TOC3D_EPI_RESIDUAL || epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_RESIDUAL_STATS || epi == TOC3D_EPI_CONV3X3 || epi == TOC3D_EPI_RESIDUAL_ACT ||
+           epi == TOC3D_EPI_RESIDUAL_LNSELF;
+}
+constexpr bool epi_ln_self(int epi) { return epi == TOC3D_EPI_SWIGLU_LNSELF || epi == TOC3D_EPI_RESIDUAL_LNSELF || epi == TOC3D_EPI_QKV_ROPE_LNSELF; }   // ... its statistics taken by this GEMM's own K loop
+constexpr bool epi_ln_stats_in(int epi) { return epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_SWIGLU_STATS_LN; }                                      // ... its statistics left by the producing GEMM
+constexpr bool epi_ln_in(int epi) { return epi_ln_stats_in(epi) || epi_ln_self(epi); }        // LayerNorm of the A rows folded into the epilogue
+constexpr bool epi_is_rope(int epi) { return epi == TOC3D_EPI_QKV_ROPE || epi == TOC3D_EPI_QKV_ROPE_LNSELF; }
+constexpr bool epi_act_copy(int epi) { return epi == TOC3D_EPI_RESIDUAL_STATS || epi == TOC3D_EPI_RESIDUAL_ACT || epi == TOC3D_EPI_RESIDUAL_LNSELF; }      // residual epilogues that also leave the rows in the act dtype
 constexpr bool epi_stats_out(int epi) { return epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN || epi == TOC3D_EPI_RESIDUAL_STATS; }
 // statistics groups per wave-tile row: one per 32 packed columns (SwiGLU) or per 16 output columns (residual)
 constexpr int epi_stat_groups(int epi, int NT) { return epi_is_swiglu(epi) ? (NT / 2 > 0 ? NT / 2 : 1) : NT; }
@@ -324,7 +334,8 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
         return;
     }
     float bcol[NT][4];
-    float ccol[EPI == TOC3D_EPI_RESIDUAL_LN ? NT : 1][4];    // c1: column sums of the gamma-scaled weights
+    constexpr bool LN_IN = epi_ln_in(EPI);               // (non-SwiGLU epilogues from here on)
+    float ccol[LN_IN ? NT : 1][4];                       // c1: column sums of the gamma-scaled weights
     if (EPI == TOC3D_EPI_RESIDUAL_STATS) {
 #pragma unroll
         for (int q = 0; q < MT * G; ++q) { gs[q] = 0.f; gq[q] = 0.f; }
@@ -337,13 +348,13 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             bcol[j][r] = (a.bias && r < nok[j]) ? a.bias[col + r] : 0.f;
-            if (EPI == TOC3D_EPI_RESIDUAL_LN) ccol[j][r] = r < nok[j] ? a.c1[col + r] : 0.f;
+            if (LN_IN) ccol[j][r] = r < nok[j] ? a.c1[col + r] : 0.f;
         }
     }
     // act-dtype outputs (bias / GELU / rotated q|k|v): the 4 values of row tile i, column tile j
     auto act4 = [&](int i, int j, T (&o4)[4]) {
         const int col = col0 + j * 16 + g * 4;
-        if constexpr (EPI == TOC3D_EPI_QKV_ROPE) {
+        if constexpr (epi_is_rope(EPI)) {
             // RoPE of the q and k columns on the f32 accumulators (eva_utils.py:378-379: out[2t] = x[2t] cos - x[2t+1] sin,
             // out[2t+1] = x[2t+1] cos + x[2t] sin, the pair sharing one frequency), q scaled afterwards (eva_vit.py:104-109): the
             // attention kernel then stages K and V by DMA with no arithmetic at all.  A lane's 4 columns are two whole pairs of one
@@ -351,8 +362,14 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
             const int Cq = a.N / 3;
             const int rope_rc = rope_rcs[i];             // loaded before the K loop (no dependent global round trip here)
             float x[4];
+            if (LN_IN) {                                   // norm1 folded (EPI_QKV_ROPE_LNSELF): bias = c2, ccol = c1 of the gamma-scaled q|k|v weights
+                const f32x2 v = lnrow[i * 16 + r16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = acc[i][j][r] + bcol[j][r];
+                for (int r = 0; r < 4; ++r) x[r] = v[1] * (acc[i][j][r] - v[0] * ccol[j][r]) + bcol[j][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = acc[i][j][r] + bcol[j][r];
+            }
             if (col < 2 * Cq) {
                 const int d0 = col & 63, part = d0 >> 5;
                 const int coord = part ? (rope_rc & 0xffff) : (rope_rc >> 16);
@@ -414,7 +431,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
         const int row = row0 + i * 16 + r16;
         if (row >= a.M) continue;
         float mu = 0.f, rs = 1.f;                        // EPI_RESIDUAL_LN: (mean, rstd) of this A row, prepared in LDS by the kernel
-        if (EPI == TOC3D_EPI_RESIDUAL_LN) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
+        if (LN_IN && epi_is_residual(EPI)) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
         (void)mu; (void)rs;
         if (epi_is_residual(EPI)) {
             // the modular residual row and the representative-row test cost an integer division / a load each: once per row
@@ -434,7 +451,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                 float raw[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (EPI == TOC3D_EPI_RESIDUAL_LN) raw[r] = rs * (acc[i][j][r] - mu * ccol[j][r]) + bcol[j][r];
+                    if (LN_IN) raw[r] = rs * (acc[i][j][r] - mu * ccol[j][r]) + bcol[j][r];
                     else raw[r] = acc[i][j][r] + bcol[j][r];
                 }
                 float sum4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -451,9 +468,9 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                         if (reprow) reprow[col + r] = raw[r];
                     }
                 }
-                if (EPI == TOC3D_EPI_RESIDUAL_STATS) {
+                if (epi_act_copy(EPI) && (EPI != TOC3D_EPI_RESIDUAL_LNSELF || a.out_act)) {
                     // the updated residual-stream row also leaves in the act dtype (the next GEMM's A operand, its LayerNorm folded into that
-                    // GEMM) together with the sums of those rounded values
+                    // GEMM), RESIDUAL_STATS: together with the sums of those rounded values
                     T* arow = reinterpret_cast<T*>(a.out_act) + (int64_t)row * a.ld_act + col;
                     T o4[4];
                     float ssum = 0.f, sq = 0.f;
@@ -466,8 +483,10 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                     }
                     if (nok[j] == 4) epi_store4(arow, o4);
                     else for (int r = 0; r < nok[j]; ++r) arow[r] = o4[r];
-                    gs[i * G + j] = ssum;
-                    gq[i * G + j] = sq;
+                    if (EPI == TOC3D_EPI_RESIDUAL_STATS) {
+                        gs[i * G + j] = ssum;
+                        gq[i * G + j] = sq;
+                    }
                 }
             }
         } else {
@@ -537,6 +556,22 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // EPI_*_LNSELF: LayerNorm of the A rows folded into the epilogue with the statistics taken by this kernel's own K loop (K spans the whole
+    // normalised row: norm1 / norm2 in front of q|k|v / w1|w2, ffn_ln in front of w3) -- no statistics hand-off, no LayerNorm launch.
+    constexpr bool LNSELF = epi_ln_self(EPI);
+    static_assert(!LNSELF || (sizeof(T) == 2 && X3 == 0), "self-normalising epilogues are bf16 only");
+    constexpr int LN_OWN = LNSELF ? (MT + WN - 1) / WN : 1;
+    f32x4 ln_sum[LN_OWN], ln_sq[LN_OWN];
+#pragma unroll
+    for (int q = 0; q < LN_OWN; ++q) { ln_sum[q] = f32x4{0.f, 0.f, 0.f, 0.f}; ln_sq[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    Frag<T> ln_ones;
+    if constexpr (LNSELF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ln_ones.v[e] = (bf16_t)1.0f;
+    }
+    const int wn_u = __builtin_amdgcn_readfirstlane(wn);     // wave-uniform: the row-tile ownership test is a scalar branch
+    (void)wn_u;
+
     // W rows are padded to a multiple of 128 at pack time, A rows are clamped to M-1
     const int w_max = ((a.N + 127) / 128) * 128 - 1;
     // EPI_CONV3X3 (necks/cp_fpn.py:124-133 as an implicit GEMM): the A tile of K-tile t is the (ky, kx) = tap t*BK / C neighbour of each
@@ -586,6 +621,23 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
             for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, s, g, T());
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, s, g, T());
+            if constexpr (LNSELF) {
+                // LayerNorm statistics of the A rows on the matrix cores (they idle two thirds of this loop; VALU forms -- dot products or converts
+                // and adds on the fragments -- cost 5-10 us per launch, profiles/r03_lnself.txt).  Of the WN wavefronts that multiply the same A
+                // rows, wave wn takes row tiles wn, wn + WN, ...: it reads that fragment X [16 rows x 32 k] once more at its own (wave-uniform) LDS
+                // row and issues two more MFMAs:  X . 1 (every column of the result = the row sums)  and  X . X^T (the Gram matrix: its
+                // diagonal = the row sums of squares; a bf16 product is exact in f32).  Accumulated over K like the GEMM itself, so the bits do
+                // not depend on the tile variant.
+#pragma unroll
+                for (int q = 0; q < LN_OWN; ++q) {
+                    const int oi = wn_u + WN * q;
+                    if (MT % WN == 0 || oi < MT) {
+                        const Frag<T> fo = lds_frag<RB>(sA, wm * TM + oi * 16 + r16, s, g, T());
+                        mma_step(ln_sum[q], fo, ln_ones);
+                        mma_step(ln_sq[q], fo, fo);
+                    }
+                }
+            }
             if constexpr (X3 == 6) {
                 bf16x8 ah[MT], am[MT], al[MT], bh[NT], bm[NT], bl[NT];
 #pragma unroll
@@ -660,7 +712,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     // first K-tile (those tiles leave LDS to spare).  Rings: the slot that the last K-tile's iteration would otherwise refill -- no extra LDS,
     // a second 80 KB workgroup still fits the CU -- requested in front of the last multiply.
     const float* rope_tab = nullptr;
-    int rope_rcs[EPI == TOC3D_EPI_QKV_ROPE ? MT : 1];
+    int rope_rcs[epi_is_rope(EPI) ? MT : 1];
     auto rope_stage = [&](char* dst) {
         const int nchunk = a.rope_L * 16;                // 16-byte pieces of [cos | sin]
         for (int c0 = wave * 64; c0 < nchunk; c0 += NTHR) {
@@ -670,7 +722,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         }
         rope_tab = reinterpret_cast<const float*>(dst);
     };
-    if constexpr (EPI == TOC3D_EPI_QKV_ROPE) {
+    if constexpr (epi_is_rope(EPI)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = m0 + wm * TM + i * 16 + r16;
@@ -681,8 +733,8 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
         for (int kt = 0; kt < nk; ++kt) {
             request(kt);
-            if constexpr (epi_ln_in(EPI)) { if (kt == 0) ln_rows_prepare(); }
-            if constexpr (EPI == TOC3D_EPI_QKV_ROPE) { if (kt == 0) rope_stage(smem + STAGE_BYTES); }
+            if constexpr (epi_ln_stats_in(EPI)) { if (kt == 0) ln_rows_prepare(); }
+            if constexpr (epi_is_rope(EPI)) { if (kt == 0) rope_stage(smem + STAGE_BYTES + (epi_ln_in(EPI) ? BM * 8 : 0)); }
             wait_vmcnt<0>();
             tile_barrier();                              // every wave's pieces of tile kt have landed
             multiply(kt);
@@ -692,19 +744,38 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
             if (t < nk) request(t);
-        if constexpr (epi_ln_in(EPI)) ln_rows_prepare();
+        if constexpr (epi_ln_stats_in(EPI)) ln_rows_prepare();
         for (int kt = 0; kt < nk; ++kt) {
             if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
             else wait_vmcnt<0>();                                                                   // pipeline tail
             tile_barrier();
             if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);
-            if constexpr (EPI == TOC3D_EPI_QKV_ROPE) { if (kt == nk - 1) rope_stage(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES); }   // the slot tile kt - 1 left
+            if constexpr (epi_is_rope(EPI)) { if (kt == nk - 1) rope_stage(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES); }   // the slot tile kt - 1 left
             multiply(kt);
         }
-        if constexpr (EPI == TOC3D_EPI_QKV_ROPE) { wait_vmcnt<0>(); tile_barrier(); }
+        if constexpr (epi_is_rope(EPI)) { wait_vmcnt<0>(); tile_barrier(); }
     }
     TOC3D_TRACE(1);
 
+    if constexpr (LNSELF) {
+        // (mean, rstd) of the tile's rows into the row table behind the operand stages (nothing else lives there).  C layout of the 16x16 MFMA:
+        // a lane holds C[4 g + r][r16], r = 0..3 -- the lanes with g == r16 >> 2 hold the diagonal element of row r16 (and that row's sum) in
+        // element r16 & 3.  f64 for the variance like the statistics-consuming form.
+#pragma unroll
+        for (int q = 0; q < LN_OWN; ++q) {
+            const int oi = wn_u + WN * q;
+            if (MT % WN == 0 || oi < MT) {
+                const int e = r16 & 3;
+                const float s1f = e == 0 ? ln_sum[q][0] : (e == 1 ? ln_sum[q][1] : (e == 2 ? ln_sum[q][2] : ln_sum[q][3]));
+                const float s2f = e == 0 ? ln_sq[q][0] : (e == 1 ? ln_sq[q][1] : (e == 2 ? ln_sq[q][2] : ln_sq[q][3]));
+                const double mean = (double)s1f * (double)a.ln_inv_n;
+                double var = (double)s2f * (double)a.ln_inv_n - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                if ((r16 >> 2) == g) lnrow[wm * TM + oi * 16 + r16] = f32x2{(float)mean, 1.0f / sqrtf((float)var + a.ln_eps)};
+            }
+        }
+        lds_barrier();
+    }
     if constexpr (epi_stats_out(EPI)) {
         // Row statistics of the act-dtype values this launch wrote, for the LayerNorm folded into the next GEMM (include/toc3d.h).  A slot is
         // 128 packed columns (SwiGLU: 64 hidden units) or 64 output columns (residual), i.e. always four column groups of the epilogue, and is
@@ -735,10 +806,10 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
             data[(int64_t)row * a.stats_cap + n0 / SLOT + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
         }
         if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + SLOT - 1) / SLOT;
-    } else if constexpr (EPI == TOC3D_EPI_RESIDUAL_LN) {
+    } else if constexpr (epi_is_rope(EPI)) {
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM, rope_rcs, rope_tab);
+    } else if constexpr (epi_ln_in(EPI)) {
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM);
-    } else if constexpr (EPI == TOC3D_EPI_QKV_ROPE) {
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, nullptr, rope_rcs, rope_tab);
     } else {
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
     }
@@ -938,9 +1009,9 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
         g_bad_variant = true;
     } else {
         constexpr int lds_fixed = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);   // + the (mean, rstd) row table
-        const int lds = lds_fixed + (EPI == TOC3D_EPI_QKV_ROPE && STAGES == 1 ? (a.rope_L * 256 + 1023) / 1024 * 1024 : 0);   // single buffer: + the RoPE tables (cos | sin), whole DMA instructions
+        const int lds = lds_fixed + (epi_is_rope(EPI) && STAGES == 1 ? (a.rope_L * 256 + 1023) / 1024 * 1024 : 0);   // single buffer: + the RoPE tables (cos | sin), whole DMA instructions
         static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
-        if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC, X3>), lds_fixed + (EPI == TOC3D_EPI_QKV_ROPE ? 64 * 256 : 0));
+        if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC, X3>), lds_fixed + (epi_is_rope(EPI) ? 64 * 256 : 0));
         if (a.K % (RB / (int)sizeof(T)) != 0 || (EPI == TOC3D_EPI_CONV3X3 && a.lda % (RB / (int)sizeof(T)) != 0)) {    // K-tile must divide K (conv: the channel count)
             if (RB == 128) { g_bad_variant = true; return; }
             launch_cfg<T, EPI, BM, BN, STAGES, 128, WM, WN, OCC, X3>(a, s);
@@ -1033,8 +1104,8 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 49: launch_cfg<T, EPI, 192, 128, 2, 128, 2, 4, 1>(a, s); break;      // 192x128 double buffered, 96x32 per wave (serves SwiGLU), 80 KiB
         case 50: launch_cfg<T, EPI, 192, 128, 1, 128, 2, 4, 1>(a, s); break;      // 192x128 single buffer, 40 KiB
         // (the rotating q|k|v epilogue is held to 128 registers -- two workgroups per CU like the other epilogues: unconstrained it took 138, ONE workgroup per CU and 83 instead of 51 us at M = 6000)
-        case 52: launch_cfg<T, EPI, 192, 192, 1, 128, 2, 4, (EPI == TOC3D_EPI_QKV_ROPE ? 4 : 1)>(a, s); break;      // 192x192 single buffer, 96x48 per wave, 48 KiB: 512 tiles for q|k|v at M = 6000 (one per slot at two per CU)
-        case 53: launch_cfg<T, EPI, 192, 192, 2, 128, 2, 4, (EPI == TOC3D_EPI_QKV_ROPE ? 4 : 1)>(a, s); break;      // 192x192 double buffered, 96 KiB
+        case 52: launch_cfg<T, EPI, 192, 192, 1, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 single buffer, 96x48 per wave, 48 KiB: 512 tiles for q|k|v at M = 6000 (one per slot at two per CU)
+        case 53: launch_cfg<T, EPI, 192, 192, 2, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 double buffered, 96 KiB
         case 51: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 8 : 1)>(a, s); break;   // variant 16 held to 64 registers (bf16): FOUR workgroups per CU -- the loop is bound by operand bytes in flight per CU
         // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
         case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB
