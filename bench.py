@@ -190,7 +190,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="toc3d_faster")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x3", "fp32x6"])
     ap.add_argument("--hw", default="320x800")
     ap.add_argument("--groups", type=int, default=1, help="concurrent view groups (independent views on separate lanes / HIP streams); "
                     "measured r02: one lane replayed from a launch plan is as fast as two eagerly issued ones and steadier than two replayed ones")
@@ -434,7 +434,7 @@ def main():
         avg_ms = gemm_ms / gemm_n
         per_launch = (alg + neck_flops) / (gemm_n / n_inst)
         roof = {"bound": "mfma", "kernel": "gemm_kernel<bf16|f32, epilogue> (all toc3d_linear launches)",
-                "achieved": per_launch / (avg_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
+                "achieved": per_launch / (avg_ms * 1e-3) / 1e12, "peak": {"bf16": PEAK_BF16_TFLOPS, "fp32x3": PEAK_BF16_TFLOPS / 3, "fp32x6": PEAK_BF16_TFLOPS / 6}.get(args.precision, 157.3),   # x3 / x6: that many bf16 MFMAs per product
                 "unit": "TFLOP/s", "traffic": None,
                 "avg_launch_ms": avg_ms, "launches_per_step": gemm_n / n_inst,
                 "algorithmic_flop_per_step": alg + neck_flops, "issued_flop_per_step": iss + neck_flops,

@@ -316,6 +316,7 @@ class _BackboneBase(nn.Module):
         # (toc3d_window_attention_pf): number of prefetch workgroups, 0 = off
         # (same-box A/B r02: 190.8 frames/s without, 193.8 / 193.4 / 192.8 / 191.6 with 128 / 256 / 512 / 1024 workgroups)
         self.prefetch_weights = int(os.environ.get("TOC3D_PREFETCH", "192" if precision == "bf16" else "0"))
+        self.prefetch_wrap = os.environ.get("TOC3D_PREFETCH_WRAP", "0") != "0"
         # bf16 path, round 3: RoPE + the q scale applied by the q|k|v GEMM's epilogue on the f32 accumulators (toc3d_linear_qkv_rope), attention on the
         # pre-rotated buffer with K / V staged by DMA (toc3d_window_attention_rot).  The strict-parity fp32 path keeps the reference's sequence.
         self.attn_rot = precision == "bf16" and os.environ.get("TOC3D_ATTN_ROT", "1") != "0"
@@ -623,7 +624,10 @@ class _BackboneBase(nn.Module):
                 self._linear(lib.EPI_QKV_ROPE, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
                              fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5))
             import ctypes
-            ts = [bp["wproj"], bp["w12"], bp["w3"]] + ([P["blocks"][i + 1]["wqkv"]] if i + 1 < self.depth else [])
+            # the last block's attention pulls the NEXT FRAME's first q|k|v weights: block 0 otherwise starts every frame on weights that were last
+            # touched a frame ago (its q|k|v launch reads 68 us against 42 for the other dense blocks, profiles/r03_where_time_goes.txt)
+            nxt = P["blocks"][i + 1] if i + 1 < self.depth else (P["blocks"][0] if self.prefetch_wrap else None)
+            ts = [bp["wproj"], bp["w12"], bp["w3"]] + ([nxt["wqkv"]] if nxt is not None else [])
             if not self.prefetch_weights:
                 ts = []
             ptrs = (ctypes.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
