@@ -195,7 +195,7 @@ def test_vitl_1600_fp32_matches_reference(golden_dir, fixture, hw, precision):
         flips.append((md > 5e-3).float().mean().item())
     # the exact-f32 path reproduces every mask; the product forms may break ONE near-tie the other way (below), seen on either hi-res input
     # depending on the product form (r03: x3 / x6 at 1600x800, x6 at 1600x640) -- bounded, never silently accepted for the exact path
-    one_flip = precision != "fp32" and max(flips) > 1e-9
+    one_flip = precision != "fp32" and (max(flips) > 1e-9 or min(ious) < 1.0)      # a soft-mask flip, or a per-window top-k flip (kept-set IoU < 1)
     assert max(flips) < (2e-2 if one_flip else 1e-9), flips
     err = rel_max(feat[:, ::step], ref)
     tl2 = (feat.double().norm(dim=1).cpu() - torch.from_numpy(g["last_feat.token_l2"])).abs().max().item() / g["last_feat.token_l2"].max()

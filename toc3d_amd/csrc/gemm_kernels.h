@@ -617,10 +617,12 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             Frag<T> fa[MT], fb[NT];
+            if constexpr (X3 != 3) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, s, g, T());
+                for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, s, g, T());
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, s, g, T());
+                for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, s, g, T());
+            }
             if constexpr (LNSELF) {
                 // LayerNorm statistics of the A rows on the matrix cores (they idle two thirds of this loop; VALU forms -- dot products or converts
                 // and adds on the fragments -- cost 5-10 us per launch, profiles/r03_lnself.txt).  Of the WN wavefronts that multiply the same A
@@ -657,11 +659,21 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], c, 0, 0, 0);
                     }
             } else if constexpr (X3 == 3) {
+                // the operand tiles were split in place by the wave that staged them (split_rows_x3 below): per 32-k group of a row, chunks 0-3 = hi,
+                // chunks 4-7 = lo of the same 32 elements
                 bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) split_bf16x3(fa[i], ah[i], al[i]);
+                for (int i = 0; i < MT; ++i) {
+                    const int r = wm * TM + i * 16 + r16;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(sA + r * RB + (((s * 8 + g) ^ swz<RB>(r)) << 4));
+                    al[i] = *reinterpret_cast<const bf16x8*>(sA + r * RB + (((s * 8 + 4 + g) ^ swz<RB>(r)) << 4));
+                }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) split_bf16x3(fb[j], bh[j], bl[j]);
+                for (int j = 0; j < NT; ++j) {
+                    const int r = wn * TN + j * 16 + r16;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(sB + r * RB + (((s * 8 + g) ^ swz<RB>(r)) << 4));
+                    bl[j] = *reinterpret_cast<const bf16x8*>(sB + r * RB + (((s * 8 + 4 + g) ^ swz<RB>(r)) << 4));
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -682,6 +694,49 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     // into a row table behind the operand stages.  Done at kernel start, right after the first operand tiles were requested, so its one
     // global round trip overlaps theirs.  Four threads per row; thread part p sums slots p, p + 4, ... in sequence, the parts meet in two
     // butterfly steps; f64.  The order is fixed: the bits do not depend on the tile variant that runs this kernel.
+    // bf16 x 3: the split of the f32 operands into (hi, lo) bf16 planes happens ONCE per element, in LDS, by the wave whose DMA instruction brought the
+    // row (a global_load_lds instruction of stage_tile covers whole rows, all lanes of a row sit in one wavefront): after its own vmcnt wait every lane
+    // converts the 16-byte chunk it staged -- 4 floats -> 4 hi + 4 lo bf16, split_bf16x3's arithmetic -- and stores them into the hi / lo chunk of the
+    // row's 32-k group (8 bytes each; reads precede writes inside the wave, so the conversion is in place).  The first form split every fragment in
+    // registers in every wave that multiplied it: 204 VALU instructions per 24 MFMAs in the K loop (profiles/r03_x3_split.txt).
+    auto split_rows_x3 = [&](int t) {
+        if constexpr (X3 == 3) {
+            char* slot = smem + (t % STAGES) * STAGE_BYTES;
+            constexpr int CPR = RB / 16, PER = (BM + BN) * CPR / NTHR;      // the A tile and the W tile are contiguous: rows 0 .. BM + BN - 1 of RB bytes
+            f32x4 v[PER];
+            int pos[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                // stage_tile's piece order: A pieces first (BM * CPR / NTHR per thread), then W pieces, each t * NTHR + wave * 64 + lane
+                constexpr int PA = BM * CPR / NTHR;
+                const int cidx = (u < PA ? u : u - PA) * NTHR + wave * 64 + lane;
+                pos[u] = (u < PA ? 0 : BM * CPR) + cidx;                    // chunk position in the stage (row * CPR + stored chunk)
+                v[u] = *reinterpret_cast<const f32x4*>(slot + pos[u] * 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int row = pos[u] / CPR, p = pos[u] % CPR;
+                const int rt = row < BM ? row : row - BM;                  // tile-local row: the swizzle of stage_tile
+                const int sw = swz<RB>(rt);
+                const int c = p ^ sw;                                       // logical f32 chunk of the row held at stored position p
+                const int grp = c >> 3, cc = c & 7;                        // 32-k group, chunk inside it (4 floats)
+                typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+                bf16x4_t hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16_t h = (bf16_t)v[u][e];
+                    hi[e] = h;
+                    lo[e] = (bf16_t)(v[u][e] - (float)h);
+                }
+                char* rowp = slot + (pos[u] - p) * 16;
+                *reinterpret_cast<bf16x4_t*>(rowp + (((grp * 8 + (cc >> 1)) ^ sw) << 4) + (cc & 1) * 8) = hi;
+                *reinterpret_cast<bf16x4_t*>(rowp + (((grp * 8 + 4 + (cc >> 1)) ^ sw) << 4) + (cc & 1) * 8) = lo;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
     f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
     auto ln_rows_prepare = [&]() {
         const int nslots = a.stats_in_slots > 0 ? a.stats_in_slots : *reinterpret_cast<const int*>(a.stats_in);
@@ -736,6 +791,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
             if constexpr (epi_ln_stats_in(EPI)) { if (kt == 0) ln_rows_prepare(); }
             if constexpr (epi_is_rope(EPI)) { if (kt == 0) rope_stage(smem + STAGE_BYTES + (epi_ln_in(EPI) ? BM * 8 : 0)); }
             wait_vmcnt<0>();
+            split_rows_x3(kt);
             tile_barrier();                              // every wave's pieces of tile kt have landed
             multiply(kt);
             tile_barrier();                              // every wave is done reading: the buffer may be overwritten
@@ -748,6 +804,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         for (int kt = 0; kt < nk; ++kt) {
             if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
             else wait_vmcnt<0>();                                                                   // pipeline tail
+            split_rows_x3(kt);
             tile_barrier();
             if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);
             if constexpr (epi_is_rope(EPI)) { if (kt == nk - 1) rope_stage(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES); }   // the slot tile kt - 1 left
