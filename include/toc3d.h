@@ -102,7 +102,9 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
  * it serves SWIGLU, 48 = 3-deep); 49/50 = 192x128 double / single buffer; 51 = variant 16 compiled for 64 registers (four workgroups per CU); 52/53 = 192x192 single / double buffer;
  * 60-63 = phased 256x256 / 256x128 / 128x256 / 128x128 tiles (bf16, one or two workgroups per CU, four phases per K-tile).  A variant whose per-wavefront column slab is not a
  * multiple of 32 cannot serve EPI_SWIGLU (error TOC3D_ERR_UNSUPPORTED).  variant + 100 = the same tile with the per-XCD band
- * order (each XCD keeps its A row band in L2 and walks the W panels once).  Every variant accumulates K in the same order: outputs are bit-identical across variants. */
+ * order (each XCD keeps its A row band in L2 and walks the W panels once); variant + 200 / + 300 = a 2-D partition of the tiles over the XCDs (4 row bands x 2 column
+ * halves / 2 row bands x 4 column quarters: an XCD streams half / a quarter of W instead of all of it -- the wide-N and long-K GEMMs are bound by the L2-miss traffic
+ * through the fabric, profiles/r03_xcd_order_sweep.txt).  Every variant accumulates K in the same order: outputs are bit-identical across variants. */
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
                     const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                     float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,

@@ -535,7 +535,7 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
     ref = None
-    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 110, 116, 126, 145, 147, 149, 151, 152] + ([11, 12, 30, 31, 60, 61, 62, 63, 160, 163] if dt == lib.BF16 else [])):
+    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 110, 116, 126, 145, 147, 149, 151, 152, 214, 216, 217, 219, 226, 249, 314, 316, 317, 319, 326, 349] + ([11, 12, 30, 31, 60, 61, 62, 63, 160, 163] if dt == lib.BF16 else [])):
         out = torch.zeros(M, N, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, None, M, N, K, 0, S())
         if ref is None:
@@ -553,7 +553,7 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
     lib.call("toc3d_pack_swiglu", dt, rnd(Hd, K, seed=5, scale=K ** -0.5).to(DEV), rnd(Hd, K, seed=6, scale=K ** -0.5).to(DEV), rnd(Hd, seed=7).to(DEV),
              rnd(Hd, seed=8).to(DEV), Hd, K, w12, b12, Hp, K, S())
     ref_r = ref_s = None
-    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 110, 116, 126, 145, 147, 149, 151, 152] + ([60, 61, 62, 63] if dt == lib.BF16 else [])):
+    for v in (list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 110, 116, 126, 145, 147, 149, 151, 152, 214, 216, 217, 219, 226, 249, 314, 316, 317, 319, 326, 349] + ([60, 61, 62, 63] if dt == lib.BF16 else [])):
         o32 = torch.zeros(M, N, device=DEV)
         lib.call("toc3d_linear_ex", dt, lib.EPI_RESIDUAL, v, a_d, K, w_d, K, b.to(DEV), o32, N, res, N, 0, None, None, M, N, K, 0, S())
         ref_r = o32.clone() if ref_r is None else ref_r
@@ -784,7 +784,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
     assert relerr(c1, (gamma * W3).to(tdt).double().sum(1)) < 1e-5 and relerr(c2, (W3.double() * beta.double()).sum(1) + b3.double()) < 1e-5
     cap = 6
     ref_stats = ref_out = ref_rep = None
-    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 116, 117, 119, 126, 149, 151):      # incl. every variant a shipped table names for this epilogue
+    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 116, 117, 119, 126, 149, 151, 216, 219, 249, 316, 317, 349):      # incl. every variant a shipped table names for this epilogue
         stats = torch.zeros(4 + M * cap * 2, device=DEV)
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd,
@@ -797,7 +797,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
             ref_stats = st.clone()
             assert relerr(st[..., 0].sum(1), hid0.double().sum(1)) < 1e-5 and relerr(st[..., 1].sum(1), (hid0.double() ** 2).sum(1)) < 1e-5
         assert torch.equal(st, ref_stats), f"variant {v}: row statistics depend on the tile variant"
-    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 52, 53, 110, 114, 116, 117, 126, 145, 149, 151, 152):
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 52, 53, 110, 114, 116, 117, 126, 145, 149, 151, 152, 214, 217, 226, 314, 317, 326):
         out = res.clone()
         rep = torch.zeros(nrep, C, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,

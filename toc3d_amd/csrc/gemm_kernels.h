@@ -883,7 +883,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
         m0 = (tile / tiles_n) * BM;
         n0 = (tile % tiles_n) * BN;
-    } else {
+    } else if (a.order == 1) {
         // Workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Each XCD owns a band of M-tile rows
         // whose A panels (band * K bytes, ~1.5 MB) stay resident in its 4 MB L2, and walks the W panels one after the
         // other (m fastest), so every W panel is fetched from memory once per XCD instead of once per A row-panel.
@@ -893,6 +893,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         if (band <= 0 || l >= band * tiles_n) return;
         m0 = (r0 + l % band) * BM;
         n0 = (l / band) * BN;
+    } else {
+        // 2-D XCD partition for wide N (order 2: 4 row bands x 2 column halves, order 3: 2 x 4): with row bands alone every XCD streams ALL of W
+        // (w1|w2: 11 MB x 8 XCDs per launch through the fabric); here an XCD keeps a quarter (half) of the A rows resident and streams half (a
+        // quarter) of W, m fastest inside its block.
+        const int pm = a.order == 2 ? 4 : 2, pn = 8 / pm;
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int bm = xcd / pn, bn = xcd % pn;
+        const int r0 = (bm * tiles_m) / pm, r1 = ((bm + 1) * tiles_m) / pm;
+        const int c0 = (bn * tiles_n) / pn, c1 = ((bn + 1) * tiles_n) / pn;
+        const int hm = r1 - r0, hn = c1 - c0;
+        if (hm <= 0 || hn <= 0 || l >= hm * hn) return;
+        m0 = (r0 + l % hm) * BM;
+        n0 = (c0 + l / hm) * BN;
     }
     gemm_tile<T, EPI, BM, BN, STAGES, RB, WM, WN, X3>(a, m0, n0, smem);
     TOC3D_TRACE_END();
@@ -1075,7 +1088,8 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
             return;
         }
         const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
-        const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;     // order 1: 8 XCD bands of ceil(tm / 8) rows
+        int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;           // order 1: 8 XCD bands of ceil(tm / 8) rows
+        if (a.order >= 2) { const int pm = a.order == 2 ? 4 : 2, pn = 8 / pm; tiles = 8 * ((tm + pm - 1) / pm) * ((tn + pn - 1) / pn); }
         toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC, X3>), dim3(tiles), dim3(64 * WM * WN), lds, s, a);
     }
 }
@@ -1097,7 +1111,9 @@ void launch_phased(const GemmArgs& a, hipStream_t s) {
 // tile / pipeline variants (toc3d_linear_ex `variant`); 0 = heuristic
 template <typename T, int EPI>
 int launch_epi(int variant, GemmArgs a, hipStream_t s) {
-    if (variant >= 100) { a.order = 1; variant -= 100; }      // variant + 100: same tile shape, per-XCD band order
+    if (variant >= 300) { a.order = 3; variant -= 300; }      // variant + 300: 2 row bands x 4 column quarters per XCD
+    else if (variant >= 200) { a.order = 2; variant -= 200; } // variant + 200: 4 row bands x 2 column halves
+    else if (variant >= 100) { a.order = 1; variant -= 100; } // variant + 100: same tile shape, per-XCD band order
     if (variant == 0) {
         // measured on MI355X (tools/gemm_sweep.py): occupancy beats ring depth on these shapes -- single-buffer tiles
         // (24-32 KiB LDS, >= 3 workgroups per CU); the narrower tile when there are few 128x128 tiles
@@ -1177,7 +1193,9 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
 // bf16 x 3 / x 6 products on f32 operands (TOC3D_DTYPE_F32X3 / F32X6): a set of tile variants (same numbering as launch_epi)
 template <int EPI, int X>
 int launch_epi_x(int variant, GemmArgs a, hipStream_t s) {
-    if (variant >= 100) { a.order = 1; variant -= 100; }
+    if (variant >= 300) { a.order = 3; variant -= 300; }
+    else if (variant >= 200) { a.order = 2; variant -= 200; }
+    else if (variant >= 100) { a.order = 1; variant -= 100; }
     if (variant == 0) {
         const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
         variant = t128 < 700 ? 17 : 16;

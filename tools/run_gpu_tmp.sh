@@ -1,2 +1,1 @@
-cd "$GRAFT_REPO_ROOT"
-timeout 1500 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_parity_bf16.py -m gpu -q --tb=short -p no:cacheprovider -k "fp32x3" 2>&1 | tail -30
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; timeout 900 python tools/ubench/xcd_order_sweep.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3_xcd_order.txt
