@@ -501,6 +501,14 @@ class _BackboneBase(nn.Module):
              "count": torch.empty(nW, dtype=torch.int32, device=dev), "npad": torch.empty(nW, dtype=torch.int32, device=dev),
              "nW": nW, "N": N, "max_count": min(N, min(L, h) * min(L, w))}
         lib.call("toc3d_window_map_dense", V, h, w, L, d["rows"], d["slots"], d["count"], d["npad"], lib.stream_ptr())
+        if os.environ.get("TOC3D_BIG_WINDOWS_FIRST", "1") != "0":
+            # Windows are independent, so their order in the lists is free: biggest first.  The attention grid is dispatched in list order and the
+            # edge windows of a 20 x 50 token grid are a fraction of the full ones (16 x 16 windows: 256 / 64 / 32 / 8 keys; 20 x 20: 400 / 200); with
+            # the full windows spread over the dispatch rounds the launch ends on a round of stragglers (profiles/r03_attn_timeline.txt: dense
+            # 20 x 20, 288 workgroups at one per CU: span 36 us for 23 us workgroups).  Done once per plan, on the static maps.
+            perm = torch.argsort(d["count"], descending=True, stable=True)
+            for k in ("rows", "slots", "count", "npad"):
+                d[k] = d[k][perm].contiguous()
         return d
 
     def _base_plan(self, V, H, W, dev, max_rows):
