@@ -361,6 +361,18 @@ int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t
 int toc3d_rebase_layernorm_rows(int dtype, float* slow, int64_t C, const int32_t* rep_index, const int32_t* tok, const float* wgt, int64_t N,
                                 int64_t k, const float* rep_raw1, const float* rep_raw2, const float* gamma, const float* beta, float eps,
                                 void* out, int64_t ldo, int64_t rows, toc3d_stream_t stream);
+/* toc3d_gather_merge_ln_ex with the PREVIOUS block's toc3d_scatter_update folded in (blocks 7 -> 8, 8 -> 9, ...: the window type changes, so the next
+ * block gathers a different token set right after the scatter): x is not scattered first; a token's current value is prev_slow[prev_inverse[token]]
+ * (kept by the previous selection) or x[token] + rep_raw1[w] + rep_raw2[w] (+ rep_raw3[w] + rep_raw4[w]) with w = -1 - prev_inverse[token] (dropped),
+ * exactly what the scatter would have written (toc3d_eva_vit.py:452-456, same order of additions); the wave that gathers a token also writes that value
+ * back to x, so after the launch x is what scatter + gather would have left.  Every real token is gathered exactly once (kept -> copied, dropped -> merged).
+ * prev_slow and shortcut must be different buffers.  toc3d_token_inverse_map builds prev_inverse [V * T] from a selection's tok / prow lists. */
+int toc3d_gather_merge_ln_pending(int dtype, float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
+                                  const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
+                                  const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy,
+                                  const int32_t* prev_inverse, const float* prev_slow, const float* rep_raw1, const float* rep_raw2,
+                                  const float* rep_raw3, const float* rep_raw4, toc3d_stream_t stream);
+int toc3d_token_inverse_map(const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k, int32_t* inverse, toc3d_stream_t stream);
 int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k,
                          const float* slow_out, const float* rep_raw1, const float* rep_raw2, const float* rep_raw3, const float* rep_raw4,
                          toc3d_stream_t stream);

@@ -319,6 +319,11 @@ class _BackboneBase(nn.Module):
         # (same-box A/B r02: 190.8 frames/s without, 193.8 / 193.4 / 192.8 / 191.6 with 128 / 256 / 512 / 1024 workgroups)
         self.prefetch_weights = int(os.environ.get("TOC3D_PREFETCH", "192" if precision == "bf16" else "0"))
         self.prefetch_wrap = os.environ.get("TOC3D_PREFETCH_WRAP", "0") != "0"
+        # round 3, measured and OFF by default (TOC3D_FUSE_SCATTER=1): where the window type changes between two accelerated blocks (7 -> 8, 8 -> 9, ...), the
+        # scatter of block i folded into the gather of block i + 1 (toc3d_gather_merge_ln_pending): one pass over x instead of two, nine launches less per
+        # frame, same bits (tests/test_gpu_e2e.py) -- and 3 % slower (202.7 -> 196.4 frames/s): the merge waves of the gather are latency-critical (18-48
+        # workgroups walk the dropped tokens four at a time) and now wait for three row loads and a store per token instead of one load.
+        self.fuse_scatter = os.environ.get("TOC3D_FUSE_SCATTER", "0") != "0"
         # bf16 path, round 3: RoPE + the q scale applied by the q|k|v GEMM's epilogue on the f32 accumulators (toc3d_linear_qkv_rope), attention on the
         # pre-rotated buffer with K / V staged by DMA (toc3d_window_attention_rot).  The strict-parity fp32 path keeps the reference's sequence.
         self.attn_rot = precision == "bf16" and os.environ.get("TOC3D_ATTN_ROT", "1") != "0"
@@ -974,6 +979,7 @@ class ToC3DEVAViT(_BackboneBase):
         f32 = dict(dtype=torch.float32, device=dev)
         plan["B"] = B
         plan["slow"] = torch.empty(max_rows, C, **f32)
+        plan["slow2"] = torch.empty(max_rows, C, **f32) if self.fuse_scatter else None      # the compact rows of a block whose scatter is pending are read while the next block's are written
         plan["rep1"] = torch.empty(max_nw, C, **f32)
         plan["rep2"] = torch.empty(max_nw, C, **f32)
         plan["rep3"] = torch.empty(max_nw, C, **f32)          # second block of a carried pair (carry_compact)
@@ -986,7 +992,7 @@ class ToC3DEVAViT(_BackboneBase):
                                     prow=torch.empty(nW, N, **i32), crow_tok=torch.empty(ms, **i32), rep_index=torch.empty(ms, **i32),
                                     rep_row=torch.empty(nW, **i32), arows=torch.empty(nW, k + 1, **i32),
                                     aslots=torch.empty(nW, k + 1, **i32), acount_q=torch.empty(nW, **i32), acount_k=torch.empty(nW, **i32),
-                                    crow_rc=torch.zeros(ms, **i32))
+                                    crow_rc=torch.zeros(ms, **i32), inv=torch.empty(M, **i32) if self.fuse_scatter else None)
         ns = len(self.pruning_loc)
         plan["pred"] = [torch.empty(M, 2, **f32) for _ in range(ns)]
         plan["u1"] = plan["u2"] = None                    # first-frame scorer scratch, allocated on demand
@@ -1074,6 +1080,8 @@ class ToC3DEVAViT(_BackboneBase):
             sel = plan["sel"][(st, L)]
             lib.call("toc3d_window_topk", score, V, plan["h"], plan["w"], L, sel["k"], sel["order"], sel["tok"], sel["wgt"], sel["prow"],
                      sel["crow_tok"], sel["rep_index"], sel["rep_row"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], sel["crow_rc"], lib.stream_ptr())
+            if sel["inv"] is not None:                    # token -> slot of this selection, for a scatter folded into the next block's gather
+                lib.call("toc3d_token_inverse_map", sel["tok"], sel["prow"], sel["nW"], sel["N"], sel["k"], sel["inv"], lib.stream_ptr())
         # image-level keep/drop lists are only returned to the caller (vis / loss): rank them beside the blocks
         # ... and so is the selection for the window type the next block does not use (first needed two blocks later)
         first = self._block_side(self.pruning_loc[st])
@@ -1126,13 +1134,26 @@ class ToC3DEVAViT(_BackboneBase):
             plan["side_L"] = None
         sel = plan["sel"][(st, self._block_side(i))]
         nW, N, k, rows = sel["nW"], sel["N"], sel["k"], sel["rows"]
-        slow = plan["slow"]
+        slow = plan.get("slow_cur")
+        slow = plan["slow"] if slow is None else slow
+        pend = plan.get("pending")
         if carry_in:
+            assert pend is None
             lib.call("toc3d_rebase_layernorm_rows", dt, slow, C, sel["rep_index"], sel["tok"], sel["wgt"], N, k, plan["rep1"], plan["rep2"],
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, rows, s)
+        elif pend is not None:
+            # the previous block did not scatter: its update of x is applied by this gather (same values, same order of additions), into the other
+            # compact buffer because the previous block's rows are read while this block's are written
+            slow = plan["slow2"] if pend["slow"] is plan["slow"] else plan["slow"]
+            ps = pend["sel"]
+            lib.call("toc3d_gather_merge_ln_pending", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
+                     bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1,
+                     ps["inv"], pend["slow"], plan["rep1"], plan["rep2"], plan["rep3"] if pend["four"] else None, plan["rep4"] if pend["four"] else None, s)
+            plan["pending"] = None
         else:
             lib.call("toc3d_gather_merge_ln_ex", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1, s)
+        plan["slow_cur"] = slow
         rot = self.attn_rot and k + 1 <= 416
         self._qkv_attention(P, i, plan, rows, sel["crow_rc"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], None,
                             bp["pad_rot"] if rot else bp["pad_qkv"], k + 1, nW, sel["max_q"], None)
@@ -1143,8 +1164,15 @@ class ToC3DEVAViT(_BackboneBase):
             self._proj(bp, plan, rows, slow, ra, sel["rep_index"])
         self._mlp(bp, plan, rows, slow, rb, sel["rep_index"])
         if not carry_out:
-            lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"],
-                     plan["rep3"] if carry_in else None, plan["rep4"] if carry_in else None, s)
+            # the next block gathers right away (accelerated, no scorer stage reading x in between): it applies this scatter itself
+            nxt = i + 1
+            fuse = (self.fuse_scatter and not self._instrumented and sel["inv"] is not None and nxt < self.depth and self._accelerated(nxt)
+                    and nxt not in self.pruning_loc)
+            if fuse:
+                plan["pending"] = dict(sel=sel, slow=slow, four=bool(carry_in))
+            else:
+                lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"],
+                         plan["rep3"] if carry_in else None, plan["rep4"] if carry_in else None, s)
 
     def _carries(self, i):
         """Block i may hand its compact rows to block i + 1 (same stage, same window type, both accelerated)."""
@@ -1218,6 +1246,7 @@ class ToC3DEVAViT(_BackboneBase):
         def frame(ex):
             for gp in groups:
                 gp["side_pending"], gp["side_L"] = False, None
+                gp["pending"], gp["slow_cur"] = None, None
             if draw:
                 # part of the recorded frame: the frame counter lives in device memory, so every replay draws fresh noise (one launch for all stages)
                 lib.call("toc3d_gumbel_noise", sg["gumbel_all"], sg["gumbel_all"].numel(), self.gumbel_seed, sg["rng"], lib.stream_ptr())

@@ -341,12 +341,40 @@ __global__ __launch_bounds__(1024) void window_topk_kernel(const float* __restri
 //                              fast set, LDS tree (fixed order -> deterministic), wave 0 normalises it;
 //   blocks [nW, nW + ceil(nW*k/16)) : one wave per kept row: copy + LayerNorm.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int MAXV>
+// The PREVIOUS block's scatter folded into this gather (toc3d_gather_merge_ln_pending): a token's current value is not in x yet -- it is the
+// previous selection's compact row (kept tokens) or x + the previous representative token's branch outputs (dropped tokens), exactly what
+// toc3d_scatter_update would have written.  inv[token] >= 0: compact row of the previous selection; < 0: -(1 + previous window).  The wave
+// that gathers a token (every real token is gathered exactly once: kept -> copied, dropped -> merged) also writes that value back to x.
+struct PendingScatter {
+    const int32_t* inv; const float* slow; const float* r1; const float* r2; const float* r3; const float* r4; float* xw;
+};
+
+template <bool PENDING>
+TOC3D_DEV f32x4 token_value(const float* __restrict__ x, int C, int src, int pk, int vi, const PendingScatter& pd) {
+    if constexpr (!PENDING) {
+        return *reinterpret_cast<const f32x4*>(x + (int64_t)src * C + 4 * vi);
+    } else {
+        f32x4 v;
+        if (pk >= 0) {
+            v = *reinterpret_cast<const f32x4*>(pd.slow + (int64_t)pk * C + 4 * vi);
+        } else {
+            const int64_t wo = (int64_t)(-1 - pk) * C + 4 * vi;
+            v = *reinterpret_cast<const f32x4*>(pd.xw + (int64_t)src * C + 4 * vi);      // (through the writable alias: x itself is declared __restrict__)
+            v = (v + *reinterpret_cast<const f32x4*>(pd.r1 + wo)) + *reinterpret_cast<const f32x4*>(pd.r2 + wo);       // toc3d_eva_vit.py:454-456, the scatter kernel's order
+            if (pd.r3) v = (v + *reinterpret_cast<const f32x4*>(pd.r3 + wo)) + *reinterpret_cast<const f32x4*>(pd.r4 + wo);
+        }
+        *reinterpret_cast<f32x4*>(pd.xw + (int64_t)src * C + 4 * vi) = v;
+        return v;
+    }
+}
+
+template <typename T, int MAXV, bool PENDING>
 __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __restrict__ x, int C, const int32_t* __restrict__ tok,
                                                                const float* __restrict__ wgt, const int32_t* __restrict__ crow_tok,
                                                                const int32_t* __restrict__ rep_row, int nW, int N, int k, int Ms,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                               float* __restrict__ shortcut, T* __restrict__ a_out, int64_t lda, int kept_copy) {
+                                                               float* __restrict__ shortcut, T* __restrict__ a_out, int64_t lda, int kept_copy,
+                                                               PendingScatter pd) {
     extern __shared__ __attribute__((aligned(16))) float s_part[];        // [16][C]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nvec = C >> 2;
@@ -359,26 +387,28 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
         // this wave owns fast positions p = k + wave + 16 j; lane j prefetches index/weight j, then rows are
         // fetched four at a time so the tok -> x dependency is paid once per four rows, not per row
         const int mine = (N - k - wave + 15) / 16;
-        int my_src = -1;
+        int my_src = -1, my_pk = 0;
         float my_w = 0.f;
         if (lane < mine) {
             my_src = tok[(int64_t)win * N + k + wave + 16 * lane];
             my_w = wgt[(int64_t)win * N + k + wave + 16 * lane];
+            if (PENDING && my_src >= 0) my_pk = pd.inv[my_src];
         }
         for (int j0 = 0; j0 < mine; j0 += 4) {
-            int src[4];
+            int src[4], pk[4];
             float wg[4];
             f32x4 row[4][MAXV];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 src[u] = __shfl(my_src, (j0 + u) & 63, 64);
+                pk[u] = PENDING ? __shfl(my_pk, (j0 + u) & 63, 64) : 0;
                 wg[u] = __shfl(my_w, (j0 + u) & 63, 64);
                 if (j0 + u >= mine) src[u] = -1;         // padded slots (src < 0) contribute x = 0; their weight is in the denominator
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
                     const int vi = lane + 64 * i;
                     row[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (vi < nvec && src[u] >= 0) row[u][i] = *reinterpret_cast<const f32x4*>(x + (int64_t)src[u] * C + 4 * vi);
+                    if (vi < nvec && src[u] >= 0) row[u][i] = token_value<PENDING>(x, C, src[u], pk[u], vi, pd);
                 }
             }
 #pragma unroll
@@ -421,13 +451,14 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
     if (orow >= Ms) return;
     const int src = crow_tok[orow];
     if (src == -2) return;                               // representative row: written by its window's block above
+    const int pk = (PENDING && src >= 0) ? pd.inv[src] : 0;
     f32x4 v[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int vi = lane + 64 * i;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (vi < nvec) {
-            if (src >= 0) v[i] = *reinterpret_cast<const f32x4*>(x + (int64_t)src * C + 4 * vi);
+            if (src >= 0) v[i] = token_value<PENDING>(x, C, src, pk, vi, pd);
             // the f32 copy of a kept row is only needed when the projection GEMM reads its residual from the compact buffer; with
             // kept_copy == 0 that GEMM gathers the row from x itself (toc3d_linear_fused residual_index) and 40 % of this kernel's bytes go
             // (explicit zero rows, src < 0, keep theirs: the GEMM reads rows without a token in place)
@@ -437,6 +468,17 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
     float mean, rstd;
     wave_ln_stats<MAXV>(v, nvec, lane, C, eps, mean, rstd);
     wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
+}
+
+// token -> slot of a selection: inv[token] = compact row (kept) or -(1 + window) (dropped); pad slots (tok < 0) have no token.
+__global__ __launch_bounds__(256) void token_inverse_map_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ prow, int nW, int N, int k,
+                                                                int32_t* __restrict__ inv) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)nW * N) return;
+    const int t = tok[id];
+    if (t < 0) return;
+    const int p = (int)(id % N);
+    inv[t] = p < k ? prow[id] : -1 - (int)(id / N);
 }
 
 // scatter the slow rows back and add the representative token's branch outputs to the fast rows, in place.
@@ -658,6 +700,31 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
     return TOC3D_OK;
 }
 
+}  // extern "C"
+
+static int launch_gather(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok, const int32_t* rep_row,
+                         int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma, const float* beta, float eps, float* shortcut, void* a_out,
+                         int64_t lda, int64_t kept_copy, PendingScatter pd, toc3d_stream_t stream) {
+    dim3 grid((unsigned)(nW + (rows + 15) / 16)), block(1024);
+    const size_t lds = (size_t)16 * C * 4;
+    hipStream_t s = as_stream(stream);
+#define TOC3D_GATHER(T, P)                                                                                                          \
+    do {                                                                                                                            \
+        static Toc3dLdsAttr attr;                                                                                                   \
+        attr.ensure(reinterpret_cast<const void*>(&gather_merge_ln_kernel<T, 4, P>), 65536);                                        \
+        toc3d_launch((gather_merge_ln_kernel<T, 4, P>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, \
+                     gamma, beta, eps, shortcut, (T*)a_out, lda, (int)(kept_copy != 0), pd);                                        \
+    } while (0)
+    if (dtype == TOC3D_BF16) { if (pd.inv) TOC3D_GATHER(bf16_t, true); else TOC3D_GATHER(bf16_t, false); }
+    else if (dtype == TOC3D_F32) { if (pd.inv) TOC3D_GATHER(float, true); else TOC3D_GATHER(float, false); }
+    else { toc3d_set_error("toc3d_gather_merge_ln: bad dtype"); return TOC3D_ERR_ARG; }
+#undef TOC3D_GATHER
+    TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln");
+    return TOC3D_OK;
+}
+
+extern "C" {
+
 int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                              const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
                              const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy, toc3d_stream_t stream) {
@@ -667,19 +734,30 @@ int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t
     // each of the 16 waves prefetches the index / weight of its share of the dropped tokens in its 64 lanes
     TOC3D_REQUIRE(N - k <= 1024, "toc3d_gather_merge_ln: N - k = %lld dropped tokens per window exceed the kernel's 1024", (long long)(N - k));
     if (nW <= 0) return TOC3D_OK;
-    dim3 grid((unsigned)(nW + (rows + 15) / 16)), block(1024);
-    const size_t lds = (size_t)16 * C * 4;
-    hipStream_t s = as_stream(stream);
-    if (dtype == TOC3D_BF16) {
-        static Toc3dLdsAttr attr;
-        attr.ensure(reinterpret_cast<const void*>(&gather_merge_ln_kernel<bf16_t, 4>), 65536);
-        toc3d_launch((gather_merge_ln_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (bf16_t*)a_out, lda, (int)(kept_copy != 0));
-    } else if (dtype == TOC3D_F32) {
-        static Toc3dLdsAttr attr;
-        attr.ensure(reinterpret_cast<const void*>(&gather_merge_ln_kernel<float, 4>), 65536);
-        toc3d_launch((gather_merge_ln_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, gamma, beta, eps, shortcut, (float*)a_out, lda, (int)(kept_copy != 0));
-    } else { toc3d_set_error("toc3d_gather_merge_ln: bad dtype"); return TOC3D_ERR_ARG; }
-    TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln");
+    return launch_gather(dtype, x, C, tok, wgt, crow_tok, rep_row, nW, N, k, rows, gamma, beta, eps, shortcut, a_out, lda, kept_copy, PendingScatter{}, stream);
+}
+
+int toc3d_gather_merge_ln_pending(int dtype, float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
+                                  const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
+                                  const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy,
+                                  const int32_t* prev_inverse, const float* prev_slow, const float* rep_raw1, const float* rep_raw2,
+                                  const float* rep_raw3, const float* rep_raw4, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && tok && wgt && crow_tok && rep_row && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln_pending: null buffer");
+    TOC3D_REQUIRE(prev_inverse && prev_slow && rep_raw1 && rep_raw2, "toc3d_gather_merge_ln_pending: the pending scatter needs its inverse map, compact rows and two updates");
+    TOC3D_REQUIRE((rep_raw3 == nullptr) == (rep_raw4 == nullptr), "toc3d_gather_merge_ln_pending: rep_raw3 and rep_raw4 come as a pair");
+    TOC3D_REQUIRE(prev_slow != shortcut, "toc3d_gather_merge_ln_pending: the previous compact rows are read while `shortcut` is written: two buffers");
+    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln_pending: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
+    TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW && N - k <= 1024, "toc3d_gather_merge_ln_pending: bad k / lda / rows");
+    if (nW <= 0) return TOC3D_OK;
+    return launch_gather(dtype, x, C, tok, wgt, crow_tok, rep_row, nW, N, k, rows, gamma, beta, eps, shortcut, a_out, lda, kept_copy,
+                         PendingScatter{prev_inverse, prev_slow, rep_raw1, rep_raw2, rep_raw3, rep_raw4, x}, stream);
+}
+
+int toc3d_token_inverse_map(const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k, int32_t* inverse, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(tok && prow && inverse && k >= 0 && k < N, "toc3d_token_inverse_map: bad arguments");
+    if (nW <= 0 || N <= 0) return TOC3D_OK;
+    toc3d_launch(token_inverse_map_kernel, dim3((unsigned)((nW * N + 255) / 256)), dim3(256), 0, as_stream(stream), tok, prow, (int)nW, (int)N, (int)k, inverse);
+    TOC3D_LAUNCH_CHECK("toc3d_token_inverse_map");
     return TOC3D_OK;
 }
 

@@ -51,6 +51,8 @@ _SIGS = {
     "toc3d_gather_merge_ln": "iplppppllllppfpplp",
     "toc3d_gather_merge_ln_ex": "iplppppllllppfppllp",
     "toc3d_scatter_update": "plpplllpppppp",
+    "toc3d_gather_merge_ln_pending": "iplppppllllppfppll" + "pppppp" + "p",
+    "toc3d_token_inverse_map": "pplllpp",
     "toc3d_rebase_layernorm_rows": "iplpppllppppfpllp",
     "toc3d_pack_motion_weights": "p" * 24 + "p",
     "toc3d_motion_queries": "pllppppippllpp",

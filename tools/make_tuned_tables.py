@@ -32,6 +32,7 @@ for spec in specs:
             if synth.is_toc3d(cfg):
                 kw = {k: inp[k].to(dev) for k in ("temp_queries", "temp_ref_points", "temp_vel", "temp_timestamp", "temp_ego_pose", "ego_pose_inv")}
                 feat = m(x, prev_exists=True, gumbel_noise=[g.to(dev) for g in inp["gumbel"]], **kw).img_feats["last_feat"]
+                m(x, prev_exists=False, gumbel_noise=[g.to(dev) for g in inp["gumbel"]], **kw)      # first frame of a sequence: the image-only scorer's shapes
             else:
                 feat = m(x)["last_feat"]
             neck([feat])
