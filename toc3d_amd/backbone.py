@@ -1242,6 +1242,11 @@ class ToC3DEVAViT(_BackboneBase):
 
         # ---- the frame: lanes 0..G-1 = view groups, G..2G-1 = their side lanes, 2G = query-side scorer prep -----------------------
         prep_lane = 2 * G
+        # TOC3D_SIDE_LANES=0 (experiment): the scorer's query preparation and the rankings run on the block chain's own lane instead of beside it
+        serial = os.environ.get("TOC3D_SIDE_LANES", "1") == "0"
+        side_of = (lambda g: g) if serial else (lambda g: G + g)
+        if serial:
+            prep_lane = 0
 
         def frame(ex):
             for gp in groups:
@@ -1269,15 +1274,15 @@ class ToC3DEVAViT(_BackboneBase):
                     with ex.lane(g):
                         if i in self.pruning_loc:
                             r0, r1 = gp["v0"] * T, (gp["v0"] + gp["nv"]) * T
-                            self._score_stage(ex, g, G + g, prep_lane, st, gp, P, prev, [gm[r0:r1] for gm in sg["gumbel"]])
+                            self._score_stage(ex, g, side_of(g), prep_lane, st, gp, P, prev, [gm[r0:r1] for gm in sg["gumbel"]])
                         if self._accelerated(i):
-                            self._accel_block(ex, g, G + g, i, st, gp, P, carry_in=cin, carry_out=cout)
+                            self._accel_block(ex, g, side_of(g), i, st, gp, P, carry_in=cin, carry_out=cout)
                         else:
                             self._dense_block(i, gp, P)
                         self._block_done(i, gp, cout)
             for g, gp in enumerate(groups):
                 with ex.lane(g):
-                    self._join_side(ex, g, G + g, gp)
+                    self._join_side(ex, g, side_of(g), gp)
                     if G > 1:
                         # private per-group buffers -> the contiguous outputs, on the group's own lane (write-only, disjoint
                         # bytes; nothing reads the shared buffers before the join below)

@@ -22,6 +22,9 @@ for spec in specs:
     m = toc3d_amd.build_backbone(dict(cfg, precision=prec))
     m.load_state_dict(synth.make_state_dict(cfg))
     m = m.to(dev).eval()
+    shipped = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "toc3d_amd", "tuned", f"{name}_{H}x{W}_{prec}.json")
+    if os.environ.get("TOC3D_KEEP_TABLE") == "1" and os.path.exists(shipped):
+        m.load_tuning(shipped)                           # keep the shipped picks, measure only the shapes the table does not hold yet
     neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision=prec))
     neck.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG))
     neck = neck.to(dev).eval()
