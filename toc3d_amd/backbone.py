@@ -297,19 +297,19 @@ class _BackboneBase(nn.Module):
         self.carry_compact = precision == "bf16" and os.environ.get("TOC3D_CARRY", "1") != "0"   # see _accel_block
         # bf16 path: SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused): no LayerNorm pass over
         # the hidden activations.  The strict-parity fp32 path keeps the reference's sequence (eva_vit.py:47-49).
-        self.fold_ffn_ln = precision == "bf16" and os.environ.get("TOC3D_FOLD_LN", "1") != "0"
+        self.fold_ffn_ln = precision in ("bf16", "fp32x3") and os.environ.get("TOC3D_FOLD_LN", "1") != "0"      # (fp32x3, round 3: f32 statistics, bf16 x 3 products)
         # ... and norm2 folded across the attention-projection -> w1|w2 boundary the same way (EPI_RESIDUAL_STATS -> EPI_SWIGLU_STATS_LN): the
         # projection's residual epilogue also leaves the updated rows in bf16 with their statistics, so the LayerNorm launch in front of the MLP goes
         # Measured neutral (same-box A/B 191.1 vs 189.2 frames/s: the 6-8 us LayerNorm launches it removes cost what the extra epilogue phases of the
         # latency-bound N = 1024 projection GEMMs cost), so it is OFF by default; TOC3D_FOLD_N2=1 enables it (7 launches per accelerated block).
-        self.fold_norm2 = self.fold_ffn_ln and os.environ.get("TOC3D_FOLD_N2", "0") != "0"
+        self.fold_norm2 = precision == "bf16" and self.fold_ffn_ln and os.environ.get("TOC3D_FOLD_N2", "0") != "0"
         # round 3, measured and OFF by default (TOC3D_LN_SELF=1 / 2 enables it): the LayerNorms folded into the CONSUMING GEMM alone -- its K loop
         # spans the whole normalised row (norm1 / norm2: K = C, ffn_ln: K = the hidden width), so it takes the row statistics from the operand tiles it
         # multiplies anyway (EPI_*_LNSELF, include/toc3d.h): no LayerNorm launch, no statistics buffer; the producer only leaves a bf16 copy of its
         # rows (EPI_RESIDUAL_ACT).  Correct and slightly more accurate than the explicit launches (tests/test_gpu_lnself.py) but slower: the K loops
         # do not tolerate the extra LDS read + statistics work per K step (three forms tried, profiles/r03_lnself.txt: -4.5 % ... -7 % frames/s with
         # norm2 + ffn_ln, -12 % ... -23 % with norm1 of the dense blocks as well, against +0.17 ms of LayerNorm launches saved).
-        self.ln_self = self.fold_ffn_ln and os.environ.get("TOC3D_LN_SELF", "0") != "0"
+        self.ln_self = precision == "bf16" and self.fold_ffn_ln and os.environ.get("TOC3D_LN_SELF", "0") != "0"
         self.ln_self_norm1 = self.ln_self and os.environ.get("TOC3D_LN_SELF", "0") not in ("0", "1")      # TOC3D_LN_SELF=2: norm1 of the dense blocks as well
         # the gather kernel skips the f32 copy of the kept rows (40 % of its bytes); the projection GEMM reads their residual from x through
         # crow_tok instead (toc3d_gather_merge_ln_ex kept_copy = 0 + toc3d_linear_fused residual_index).  Same bits either way.

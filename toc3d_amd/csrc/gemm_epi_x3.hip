@@ -9,6 +9,9 @@ int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s)
         case TOC3D_EPI_RESIDUAL: return launch_epi_x<TOC3D_EPI_RESIDUAL, 3>(variant, a, s);
         case TOC3D_EPI_SWIGLU: return launch_epi_x<TOC3D_EPI_SWIGLU, 3>(variant, a, s);
         case TOC3D_EPI_CONV3X3: return launch_epi_x<TOC3D_EPI_CONV3X3, 3>(variant, a, s);
+        // SwiGLU.ffn_ln folded across the w1|w2 -> w3 boundary on the parity-grade fast path as well (f32 statistics, f32 row table): no LayerNorm pass over the hidden units
+        case TOC3D_EPI_SWIGLU_STATS: return launch_epi_x<TOC3D_EPI_SWIGLU_STATS, 3>(variant, a, s);
+        case TOC3D_EPI_RESIDUAL_LN: return launch_epi_x<TOC3D_EPI_RESIDUAL_LN, 3>(variant, a, s);
         default: return TOC3D_ERR_ARG;
     }
 }

@@ -1074,7 +1074,8 @@ template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM 
 void launch_cfg(const GemmArgs& a, hipStream_t s) {
     // a wave must own whole (w1, w2) 32-column groups; the folded-LayerNorm statistics need N-tiles of whole 128-column slots; the fold is bf16 only
     constexpr bool unsupported = (epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) ||
-                                 (EPI >= TOC3D_EPI_SWIGLU_STATS && EPI != TOC3D_EPI_CONV3X3 && sizeof(T) != 2);
+                                 (EPI >= TOC3D_EPI_SWIGLU_STATS && EPI != TOC3D_EPI_CONV3X3 && sizeof(T) != 2 &&
+                                  !(X3 == 3 && (EPI == TOC3D_EPI_SWIGLU_STATS || EPI == TOC3D_EPI_RESIDUAL_LN)));   // ... and the bf16 x 3 form of the ffn_ln fold
     if constexpr (unsupported) {
         g_bad_variant = true;
     } else {
