@@ -825,6 +825,51 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
         lib.call("toc3d_linear_fused", lib.F32, lib.EPI_SWIGLU_STATS, 16, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, None, 0, 0.0, None, 0, None, S())
 
 
+def test_ffn_ln_fold_on_the_bf16x3_path():
+    """EPI_SWIGLU_STATS -> EPI_RESIDUAL_LN on f32 operands with bf16 x 3 products (precision fp32x3, round 3): against an f64 reference of
+    w3(ffn_ln(silu(w1 x) * w2 x)) + residual (eva_vit.py:47-49,263) and across tile variants."""
+    dt, tdt = lib.F32, torch.float32
+    M, K, Hd, Hp, C = 777, 512, 300, 320, 384
+    eps = 1e-6
+    A = rnd(M, K, seed=1).to(DEV)
+    w1, w2 = rnd(Hd, K, seed=5, scale=K ** -0.5).to(DEV), rnd(Hd, K, seed=6, scale=K ** -0.5).to(DEV)
+    b1, b2 = rnd(Hd, seed=7).to(DEV), rnd(Hd, seed=8).to(DEV)
+    w12 = torch.empty(2 * Hp, K, dtype=tdt, device=DEV)
+    b12 = torch.empty(2 * Hp, device=DEV)
+    lib.call("toc3d_pack_swiglu", dt, w1, w2, b1, b2, Hd, K, w12, b12, Hp, K, S())
+    gamma, beta = (1.0 + 0.3 * rnd(Hd, seed=9)).to(DEV), (0.2 * rnd(Hd, seed=10)).to(DEV)
+    W3, b3 = rnd(C, Hd, seed=11, scale=Hd ** -0.5).to(DEV), rnd(C, seed=12).to(DEV)
+    res = rnd(M, C, seed=13).to(DEV)
+    Ad = A.double()
+    h = torch.nn.functional.silu(Ad @ w1.double().T + b1.double()) * (Ad @ w2.double().T + b2.double())
+    ln = (h - h.mean(1, keepdim=True)) / torch.sqrt(h.var(1, unbiased=False, keepdim=True) + eps) * gamma.double() + beta.double()
+    ref = res.double() + ln @ W3.double().T + b3.double()
+    w3f = torch.zeros(ru(C, 128), Hp, dtype=tdt, device=DEV)
+    c1, c2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    lib.call("toc3d_pack_weight_lnfold", dt, W3.contiguous(), gamma, beta, b3, C, Hd, w3f, w3f.shape[0], Hp, c1, c2, S())
+    cap = 6
+    first = None
+    for v in (1, 8, 10, 16, 17, 19, 22, 26, 28, 49, 116, 117, 126, 149):
+        stats = torch.zeros(4 + M * cap * 2, device=DEV)
+        hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
+        try:
+            lib.call("toc3d_linear_fused", lib.F32X3, lib.EPI_SWIGLU_STATS, v, A, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd,
+                     stats, cap, None, 0, None, 0, 0.0, None, 0, None, S())
+        except RuntimeError as e:                     # N-tiles that are not whole statistics slots
+            assert "cannot serve" in str(e)
+            continue
+        out = res.clone()
+        lib.call("toc3d_linear_fused", lib.F32X3, lib.EPI_RESIDUAL_LN, v, hid, Hp, w3f, Hp, c2, out, C, out, C, 0, None, None, M, C, Hp, 0,
+                 None, 0, stats, cap, c1, Hd, eps, None, 0, None, S())
+        if first is None:
+            first = (hid.clone(), out.clone())
+            e = relerr(out, ref)
+            print(f"[ffn_ln fold, bf16 x 3] rel err vs f64 {e:.3e}")
+            assert relerr(hid[:, :Hd], h) < 3e-5 and e < 3e-5 and torch.count_nonzero(hid[:, Hd:]) == 0
+        assert torch.equal(hid, first[0]) and torch.equal(out, first[1]), f"variant {v} differs"
+    assert first is not None
+
+
 def test_norm2_folded_across_the_projection_boundary():
     """norm2 folded (EPI_RESIDUAL_STATS -> EPI_SWIGLU_STATS_LN, eva_vit.py:263) against the explicit sequence (EPI_RESIDUAL ->
     toc3d_layernorm_rows -> EPI_SWIGLU_STATS) and an f64 reference; bf16 copy, statistics and hidden units independent of the tile variant."""
@@ -994,4 +1039,4 @@ def test_linear_bf16x3_products_on_f32_operands(M, N, K):
     lib.call("toc3d_linear", lib.F32X3, lib.EPI_GELU, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, S())
     assert relerr(out, torch.nn.functional.gelu(ref)) < 2e-5
     with pytest.raises(RuntimeError, match="bf16 x 3"):
-        lib.call("toc3d_linear_fused", lib.F32X3, lib.EPI_SWIGLU_STATS, 0, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, *lib.NO_FUSED, S())
+        lib.call("toc3d_linear_fused", lib.F32X3, lib.EPI_RESIDUAL_STATS, 0, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, *lib.NO_FUSED, S())   # (epilogues 4 / 5, the ffn_ln fold, are served since round 3)

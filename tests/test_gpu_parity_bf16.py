@@ -278,8 +278,8 @@ def test_shipped_tile_tables_give_the_default_variants_bits(path, name, hw, prec
     m.load_tuning(path)
     table = {tuple(k): v for k, v in json.load(open(path))["table"]}
     assert table and all(m._tuned[k] == v for k, v in table.items())
-    # (the rotating q|k|v launches look their tile up under the bias epilogue's key without recording a key of their own; the dense backbone launches four other shapes, its table also holds the two neck shapes)
-    assert len(seen & set(table)) >= min(8, len(table) - 3) and any(table[k] != 0 for k in seen & set(table)), "the table must cover the shapes this forward launches"
+    # (the rotating q|k|v launches look their tile up under the bias epilogue's key without recording a key of their own; the dense backbone launches four or five other shapes; tables may also hold the neck's shapes and shapes of forms no longer launched)
+    assert len(seen & set(table)) >= min(8, len(seen) - 1) and any(table[k] != 0 for k in seen & set(table)), "the table must cover the shapes this forward launches"
     m._plans = {}
     tuned = fwd()
     for a, b in zip(base, tuned):
