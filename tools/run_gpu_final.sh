@@ -12,3 +12,11 @@ print(round(d['value'], 1), 'frames/s', round(d['ms_per_step'], 3), 'ms  rooflin
       'parity', d.get('parity_path', {}).get('value'), 'fast', (d.get('parity_path_fast') or {}).get('value'), 'cpu', d.get('cpu_baseline', {}).get('value'))
 print('other', [(o['config'][:20], round(o['value'], 1)) for o in d.get('other_configs', [])])
 PY
+# kernel trace of the same bench command (profiles/r03_kernel_stats.csv is summarised from it by tools/summarize_prof.py)
+export TMPDIR=/tmp
+OUT="$GRAFT_REPO_ROOT/gpurun_out"
+rm -rf $OUT/kt
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-breakdown --no-batched --no-parity-path --no-other-configs > $OUT/final_prof_bench.json 2> $OUT/final_prof.err
+for f in $(find $OUT/kt -mindepth 2 -name "kt_*.csv"); do cp $f $OUT/kt/; done
+find $OUT/kt -mindepth 1 -type d -exec rm -rf {} + 2>/dev/null
+ls $OUT/kt | head
