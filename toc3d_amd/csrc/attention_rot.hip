@@ -61,7 +61,7 @@ struct AttnRotArgs {
 // The attention kernels leave HBM idle, and the GEMMs that follow them start on weights that were last touched a frame ago (0.6 GB of bf16
 // weights cycle through a 256 MB Infinity Cache).  Round 2 streamed the next GEMMs' weights through extra "rider" workgroups in front of the
 // attention grid; they held CU slots and registers and delayed the attention workgroups behind them by 3-6 us per launch
-// (profiles/r03_attn_timeline_v2.txt).  Here every wavefront of the attention grid itself requests a few KB of those weights by LDS-DMA into a
+// (development timeline of that version; profiles/r03_attn_timeline.txt is the shipped kernel).  Here every wavefront of the attention grid itself requests a few KB of those weights by LDS-DMA into a
 // 1 KB dump area right after its operands have landed: no registers, no extra workgroups, the requests drain while the wave computes.  Wave w
 // of W takes the 1 KB pieces w, w + W, ... (neighbouring waves read neighbouring KB).
 TOC3D_DEV void prefetch_weights(const AttnRotArgs& a, char* dump, int64_t wave_id, int64_t nwaves, int lane) {
@@ -90,7 +90,7 @@ TOC3D_DEV int v_swz(int r) { return ((r >> 1) & 3) << 1; }
 // TWICE instead of being held: pass 1 = running max of S^T = K.Q^T over all keys, pass 2 = the same scores again, 32 keys at a time,
 // exp(S - max) straight into the P fragment of O^T = V^T.P^T.  The first version of this kernel kept every score of a query tile in
 // registers (94-176 VGPRs, 3-4 waves per SIMD, fully unrolled per-tile guards): its compute phase was latency-bound at 9-25 us per
-// workgroup (profiles/r03_attn_timeline_v1.txt) although the MFMA work is < 1 us -- dependent ds_read -> MFMA chains with nothing to
+// workgroup (development timeline of that version, not kept) although the MFMA work is < 1 us -- dependent ds_read -> MFMA chains with nothing to
 // overlap them.  Recomputing costs 2 extra MFMAs per 16 keys and buys a 72-register kernel: 7 waves per SIMD, ONE query tile per
 // wavefront (the workgroup has as many waves as the window has 16-query tiles, up to 16), so the chains of 16-32 waves per CU overlap.
 constexpr int MAXPC = 8;                         // DMA pieces (8 keys x 128 B) per wave and operand: the host launches >= ceil(keys / 64) waves
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(1024, 7) void attn_rot_kernel(AttnRotArgs a) {     
 
 // Wavefronts per workgroup: one 16-query tile per wave where the chip can hold the whole grid at once, two otherwise.  Always a multiple of
 // four: a workgroup's waves are dealt to the four SIMDs in turn, and the kernel's 72 VGPRs admit 7 waves per SIMD -- with 9 waves per
-// workgroup the third workgroup of a CU found no SIMD-balanced home and the launch ran in 1.5 rounds (profiles/r03_attn_timeline_v2.txt).
+// workgroup the third workgroup of a CU found no SIMD-balanced home and the launch ran in 1.5 rounds (development timeline of that version).
 void launch_rot(const AttnRotArgs& a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
     const size_t lds = (size_t)((a.stride + 31) / 32 * 32) * 256 + 1024;      // K image, V image, 1 KB prefetch dump
     static Toc3dLdsAttr attr;
