@@ -300,9 +300,10 @@ class _BackboneBase(nn.Module):
         self.fold_ffn_ln = precision in ("bf16", "fp32x3") and os.environ.get("TOC3D_FOLD_LN", "1") != "0"      # (fp32x3, round 3: f32 statistics, bf16 x 3 products)
         # ... and norm2 folded across the attention-projection -> w1|w2 boundary the same way (EPI_RESIDUAL_STATS -> EPI_SWIGLU_STATS_LN): the
         # projection's residual epilogue also leaves the updated rows in bf16 with their statistics, so the LayerNorm launch in front of the MLP goes
-        # Measured neutral (same-box A/B 191.1 vs 189.2 frames/s: the 6-8 us LayerNorm launches it removes cost what the extra epilogue phases of the
-        # latency-bound N = 1024 projection GEMMs cost), so it is OFF by default; TOC3D_FOLD_N2=1 enables it (7 launches per accelerated block).
-        self.fold_norm2 = precision == "bf16" and self.fold_ffn_ln and os.environ.get("TOC3D_FOLD_N2", "0") != "0"
+        # (7 launches per accelerated block, 179 per frame instead of 203).  Round 2 measured it neutral (191.1 vs 189.2 frames/s) and left it off;
+        # on the round-3 kernels it reads +0.3 % in two same-box A/B rounds (198.5 / 199.5 -> 199.0 / 200.2), the parity suites are green with it:
+        # ON since the end of round 3, TOC3D_FOLD_N2=0 restores the explicit launch.
+        self.fold_norm2 = precision == "bf16" and self.fold_ffn_ln and os.environ.get("TOC3D_FOLD_N2", "1") != "0"
         # round 3, measured and OFF by default (TOC3D_LN_SELF=1 / 2 enables it): the LayerNorms folded into the CONSUMING GEMM alone -- its K loop
         # spans the whole normalised row (norm1 / norm2: K = C, ffn_ln: K = the hidden width), so it takes the row statistics from the operand tiles it
         # multiplies anyway (EPI_*_LNSELF, include/toc3d.h): no LayerNorm launch, no statistics buffer; the producer only leaves a bf16 copy of its
