@@ -1,0 +1,60 @@
+"""Development tool: cut replayed frames out of a rocprofv3 --kernel-trace CSV of `python bench.py ...` and say where a frame's time goes --
+launches per kernel family, first start -> last end, sum of kernel durations, idle gaps on the union of all lanes, kernels that are not ours.
+A frame = the launches between two toc3d copy_segments launches (the staging of the per-frame inputs is the first launch of every frame).
+    python tools/frame_timeline.py gpurun_out/kt/kt_kernel_trace.csv [frame index from the end, default -3 -5]
+profiles/r03_where_time_goes*.txt are this tool's output."""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+SIDE = ("motion_queries", "collapse_kernel", "window_topk", "rank_desc")
+
+
+def short(name):
+    m = re.search(r"[a-z][a-z0-9_]*?_kernel", name)                       # plain or mangled (_ZN12_GLOBAL__N_111gemm_kernelI...)
+    base = m.group(0) if m else name.split("(")[0].split("<")[0].strip()
+    if base.startswith("gemm_"):
+        return "gemm_kernel (all toc3d_linear* launches)"
+    return base + (" (side lane)" if base.startswith(SIDE) else "")
+
+
+def ours(name):
+    return "toc3d" in name or "anonymous namespace" in name or "_kernel" in name and "rocclr" not in name and "at::" not in name
+
+
+def main():
+    path = sys.argv[1]
+    which = [int(a) for a in sys.argv[2:]] or [-3, -5]
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    cuts = [i for i, r in enumerate(rows) if "copy_segments" in r[2]]
+    frames = [rows[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    print(f"# {len(rows)} dispatches, {len(frames)} frames between copy_segments launches; frames taken from the end of the run (the timed region)")
+    for w in which:
+        fr = frames[w]
+        t0, t1 = fr[0][0], max(r[1] for r in fr)
+        busy_end, idle = fr[0][1], 0
+        for s, e, _ in fr[1:]:
+            if s > busy_end:
+                idle += s - busy_end
+            busy_end = max(busy_end, e)
+        fam = defaultdict(lambda: [0, 0])
+        for s, e, n in fr:
+            k = short(n)
+            fam[k][0] += 1
+            fam[k][1] += e - s
+        foreign = sum(1 for r in fr if not ours(r[2]))
+        tot = sum(v[1] for v in fam.values())
+        print(f"\nframe {w}: {len(fr)} launches, first start -> last end {(t1 - t0) / 1e6:.3f} ms, sum of kernel durations {tot / 1e6:.3f} ms "
+              f"(side lanes overlap the block chain), idle gaps on the union of all lanes {idle / 1e3:.1f} us; kernels that are not toc3d kernels: {foreign}")
+        print(f"{'family':52s} {'launches':>8s} {'total us':>10s} {'avg us':>8s}")
+        for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+            print(f"{k:52s} {c:8d} {t / 1e3:10.1f} {t / 1e3 / c:8.2f}")
+
+
+if __name__ == "__main__":
+    main()
