@@ -544,7 +544,7 @@ def test_head_token_embedding_full_size_matches_oracle():
 
 def test_folded_layernorms_and_riding_prefetch_against_the_explicit_sequence():
     """bf16 dense backbone (no discrete decisions): ffn_ln folded into the w1|w2 / w3 GEMMs (default), norm2 folded into the projection /
-    w1|w2 GEMMs as well (opt-in), against the explicit LayerNorm launches; all within bf16 rounding of each other and of the fp32 oracle.
+    w1|w2 GEMMs as well (default since the end of round 3), against the explicit LayerNorm launches; all within bf16 rounding of each other and of the fp32 oracle.
     The weight prefetch riding on the attention launches must not change a bit."""
     cfg = configs.get("eva_dense")
     sd = synth.make_state_dict(cfg)
