@@ -295,3 +295,27 @@ def test_round3_entry_points_validate_without_gpu():
     assert l.toc3d_linear_qkv_rope_ln(lib.BF16, 0, None, 0, None, 0, None, None, 0, 4, 192, 64, None, None, 16, 0.125, None, 64, 1e-6, None) == -1
     assert b"null buffer" in l.toc3d_last_error()
     assert l.toc3d_linear_chain_trace(None, 0) == 0
+
+
+def test_frame_timeline_cuts_frames_and_counts_idle_time():
+    """tools/frame_timeline.py (the tool behind profiles/r03_where_time_goes*.txt): frames are cut at the copy_segments launches, overlapping side-lane
+    kernels do not count as idle time, mangled and plain kernel names land in one family, torch / runtime kernels are counted as foreign."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("frame_timeline", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "frame_timeline.py"))
+    ft = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ft)
+    g1 = "_ZN12_GLOBAL__N_111gemm_kernelIDF16bLi4ELi128ELi128ELi1ELi128ELi2ELi4ELi6ELi0EEEv8GemmArgs"
+    g2 = "void (anonymous namespace)::gemm_kernel<__bf16, 5, 64, 64, 2, 128, 2, 2, 1, 0>(GemmArgs)"
+    rows = []
+    for f in range(3):
+        t = f * 10000
+        rows += [(t, t + 100, "(anonymous namespace)::copy_segments_kernel(void const*)"), (t + 100, t + 1100, g1),
+                 (t + 300, t + 900, "(anonymous namespace)::motion_queries_kernel<float>(int)"),           # side lane, inside the GEMM: no idle time
+                 (t + 1150, t + 2150, g2),                                                                  # 50 ns gap
+                 (t + 2150, t + 2200, "void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>>(int)")]
+    frames = ft.cut_frames(list(reversed(rows)))
+    assert len(frames) == 2                                                                                # the open last frame is dropped
+    r = ft.summarize(frames[0])
+    assert r["launches"] == 5 and r["span"] == 2200 and r["idle"] == 50 and r["foreign"] == 1
+    assert r["families"]["gemm_kernel (all toc3d_linear* launches)"] == [2, 2000]
+    assert r["families"]["motion_queries_kernel (side lane)"] == [1, 600]

@@ -23,36 +23,43 @@ def ours(name):
     return "toc3d" in name or "anonymous namespace" in name or "_kernel" in name and "rocclr" not in name and "at::" not in name
 
 
+def cut_frames(rows):
+    """rows: (start ns, end ns, kernel name).  Frames = the launches from one copy_segments launch up to the next one (the last, open one is dropped)."""
+    rows = sorted(rows)
+    cuts = [i for i, r in enumerate(rows) if "copy_segments" in r[2]]
+    return [rows[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def summarize(fr):
+    """One frame -> launches, span, idle time on the union of all lanes (ns), per-family [launches, ns], kernels that are not ours."""
+    t0, t1 = fr[0][0], max(r[1] for r in fr)
+    busy_end, idle = fr[0][1], 0
+    for s, e, _ in fr[1:]:
+        if s > busy_end:
+            idle += s - busy_end
+        busy_end = max(busy_end, e)
+    fam = defaultdict(lambda: [0, 0])
+    for s, e, n in fr:
+        k = short(n)
+        fam[k][0] += 1
+        fam[k][1] += e - s
+    return dict(launches=len(fr), span=t1 - t0, idle=idle, families=dict(fam), foreign=sum(1 for r in fr if not ours(r[2])))
+
+
 def main():
     path = sys.argv[1]
     which = [int(a) for a in sys.argv[2:]] or [-3, -5]
-    rows = []
     with open(path) as f:
-        for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
-    rows.sort()
-    cuts = [i for i, r in enumerate(rows) if "copy_segments" in r[2]]
-    frames = [rows[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(f)]
+    frames = cut_frames(rows)
     print(f"# {len(rows)} dispatches, {len(frames)} frames between copy_segments launches; frames taken from the end of the run (the timed region)")
     for w in which:
-        fr = frames[w]
-        t0, t1 = fr[0][0], max(r[1] for r in fr)
-        busy_end, idle = fr[0][1], 0
-        for s, e, _ in fr[1:]:
-            if s > busy_end:
-                idle += s - busy_end
-            busy_end = max(busy_end, e)
-        fam = defaultdict(lambda: [0, 0])
-        for s, e, n in fr:
-            k = short(n)
-            fam[k][0] += 1
-            fam[k][1] += e - s
-        foreign = sum(1 for r in fr if not ours(r[2]))
-        tot = sum(v[1] for v in fam.values())
-        print(f"\nframe {w}: {len(fr)} launches, first start -> last end {(t1 - t0) / 1e6:.3f} ms, sum of kernel durations {tot / 1e6:.3f} ms "
-              f"(side lanes overlap the block chain), idle gaps on the union of all lanes {idle / 1e3:.1f} us; kernels that are not toc3d kernels: {foreign}")
+        r = summarize(frames[w])
+        tot = sum(v[1] for v in r["families"].values())
+        print(f"\nframe {w}: {r['launches']} launches, first start -> last end {r['span'] / 1e6:.3f} ms, sum of kernel durations {tot / 1e6:.3f} ms "
+              f"(side lanes overlap the block chain), idle gaps on the union of all lanes {r['idle'] / 1e3:.1f} us; kernels that are not toc3d kernels: {r['foreign']}")
         print(f"{'family':52s} {'launches':>8s} {'total us':>10s} {'avg us':>8s}")
-        for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        for k, (c, t) in sorted(r["families"].items(), key=lambda kv: -kv[1][1]):
             print(f"{k:52s} {c:8d} {t / 1e3:10.1f} {t / 1e3 / c:8.2f}")
 
 
