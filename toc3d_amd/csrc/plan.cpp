@@ -11,6 +11,7 @@
 // Lanes are how the recording names concurrency: the `stream` argument of a recorded call is a lane handle
 // (toc3d_plan_lane_stream), and toc3d_plan_wait(plan, a, b) orders lane a's next launch behind everything recorded so far on lane b.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -103,6 +104,19 @@ namespace {
         }                                                                                     \
     } while (0)
 
+// Flags of the events behind the cross-lane edges.  They are only ever waited on by hipStreamWaitEvent of a stream of the SAME device, never by
+// the host, so the system-scope fence an event record performs by default (L2 write-back + invalidate, and its cost to the kernels that follow)
+// is not needed for correctness: kernel boundaries already release / acquire at agent scope.  TOC3D_EVENT_FENCE: 0 = HIP's default (system-scope
+// fence), 1 = hipEventReleaseToDevice, 2 = hipEventDisableSystemFence.
+unsigned event_flags() {
+    static const unsigned flags = [] {
+        const char* e = getenv("TOC3D_EVENT_FENCE");
+        const int mode = e ? atoi(e) : 0;
+        return (unsigned)hipEventDisableTiming | (mode == 1 ? (unsigned)hipEventReleaseToDevice : mode == 2 ? (unsigned)hipEventDisableSystemFence : 0u);
+    }();
+    return flags;
+}
+
 int build_streams(Toc3dPlan* p) {
     int nlanes = 1;
     for (int l = 1; l < MAX_LANES; ++l)
@@ -112,17 +126,17 @@ int build_streams(Toc3dPlan* p) {
         PLAN_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         p->streams.push_back(s);
         hipEvent_t e;
-        PLAN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        PLAN_HIP(hipEventCreateWithFlags(&e, event_flags()));
         p->lane_done.push_back(e);
     }
-    PLAN_HIP(hipEventCreateWithFlags(&p->entry, hipEventDisableTiming));
+    PLAN_HIP(hipEventCreateWithFlags(&p->entry, event_flags()));
     // one event per node that some other lane waits on
     for (size_t i = 0; i < p->nodes.size(); ++i)
         for (int d : p->nodes[i].deps) {
             Toc3dPlan::Node& src = p->nodes[d];
             if (src.signal < 0) {
                 hipEvent_t e;
-                PLAN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                PLAN_HIP(hipEventCreateWithFlags(&e, event_flags()));
                 src.signal = (int)p->events.size();
                 p->events.push_back(e);
             }
