@@ -309,10 +309,10 @@ def test_frame_timeline_cuts_frames_and_counts_idle_time():
     rows = []
     for f in range(3):
         t = f * 10000
-        rows += [(t, t + 100, "(anonymous namespace)::copy_segments_kernel(void const*)"), (t + 100, t + 1100, g1),
-                 (t + 300, t + 900, "(anonymous namespace)::motion_queries_kernel<float>(int)"),           # side lane, inside the GEMM: no idle time
-                 (t + 1150, t + 2150, g2),                                                                  # 50 ns gap
-                 (t + 2150, t + 2200, "void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>>(int)")]
+        rows += [(t, t + 100, "(anonymous namespace)::copy_segments_kernel(void const*)", "0"), (t + 100, t + 1100, g1, "0"),
+                 (t + 300, t + 900, "(anonymous namespace)::motion_queries_kernel<float>(int)", "3"),      # another stream, inside the GEMM: no idle time
+                 (t + 1150, t + 2150, g2, "0"),                                                             # 50 ns gap
+                 (t + 2150, t + 2200, "void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>>(int)", "0")]
     frames = ft.cut_frames(list(reversed(rows)))
     assert len(frames) == 2                                                                                # the open last frame is dropped
     r = ft.summarize(frames[0])
