@@ -419,6 +419,9 @@ int toc3d_score_tokens(const float* x, int64_t C, const float* mask, const float
  * memory, zero-initialised by the caller: state[0] is the frame counter, advanced by ONE per launch by the kernel itself (state[1] is its
  * ticket), so a recorded launch plan draws fresh, reproducible noise on every replay without any host-side argument changing. */
 int toc3d_gumbel_noise(float* out, int64_t n, uint64_t seed, uint64_t* state, toc3d_stream_t stream);
+/* The map toc3d_gumbel_noise applies to every 32-bit Philox word, on caller-supplied words: out[i] = -log(-log(U)), U = ((bits[i] >> 9) + 0.5) * 2^-23
+ * in [2^-24, 1 - 2^-24] -- finite for EVERY word, 0 and 0xFFFFFFFF included (what the parity tests pin). */
+int toc3d_gumbel_from_bits(const uint32_t* bits, int64_t n, float* out, toc3d_stream_t stream);
 
 /* First-frame scorer pieces (ScoreBasedTokenSelector.score, backbones/toc3d_utils.py:114-129): the two big
  * Linear layers run through toc3d_linear (GELU epilogue); these cover the rest.

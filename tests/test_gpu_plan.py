@@ -176,3 +176,30 @@ def test_device_side_gumbel_draw_is_part_of_the_plan_and_has_gumbel_statistics()
     assert st.get("cplan") is not None, "frames 3-5 were replayed from the recorded plan"
     assert all(not torch.equal(masks[i], masks[j]) for i in range(5) for j in range(i))
     assert int(m._plans[key]["stage"]["rng"][0].item()) == 5
+    # ONE frame counter per model: a second input shape (its own plan) continues the stream instead of replaying it from frame 0
+    inp3 = synth.make_inputs(cfg, views_per_frame=1)
+    m(d(inp3["x"]), temp_queries=d(inp3["temp_queries"]), prev_exists=True, temp_ref_points=d(inp3["temp_ref_points"]), temp_vel=d(inp3["temp_vel"]),
+      temp_timestamp=d(inp3["temp_timestamp"]), temp_ego_pose=d(inp3["temp_ego_pose"]), ego_pose_inv=d(inp3["ego_pose_inv"]))
+    assert len(m._plans) == 2 and int(m._gumbel_rng[0].item()) == 6
+    assert all(pl["stage"]["rng"].data_ptr() == m._gumbel_rng.data_ptr() for pl in m._plans.values())
+
+
+def test_gumbel_map_is_finite_for_every_32_bit_word():
+    """The uniform behind -log(-log(U)) must stay strictly inside (0, 1) for every Philox word: U = 1 gives +inf noise, inf - inf = NaN in the
+    soft mask (toc3d_utils.py:147) and a NaN score in the next stage.  The extreme words, every exponent boundary of the 23-bit mantissa path and a
+    random sample, against the same map in f64."""
+    import numpy as np
+    edge = [0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0x80000000, 0xFFFFFE00, 0xFFFFFDFF, 0xFFFFFFFE, 0xFFFFFFFF]
+    rnd = np.random.default_rng(5).integers(0, 1 << 32, size=1 << 16, dtype=np.uint64)
+    words = np.concatenate([np.array(edge, dtype=np.uint64), rnd]).astype(np.uint32)
+    bits = torch.from_numpy(words.view(np.int32)).to(DEV)
+    out = torch.empty(len(words), device=DEV)
+    lib.call("toc3d_gumbel_from_bits", bits, len(words), out, lib.stream_ptr())
+    torch.cuda.synchronize()
+    got = out.double().cpu().numpy()
+    assert np.isfinite(got).all()
+    u = ((words >> 9).astype(np.float64) + 0.5) * 2.0 ** -23
+    assert u.min() >= 2.0 ** -24 and u.max() <= 1 - 2.0 ** -24
+    ref = -np.log(-np.log(u))
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    assert got[9] > 15.9 and got[0] < -2.7                               # the largest / smallest sample the map can produce: ~16.6 / ~-2.8

@@ -343,7 +343,7 @@ class _BackboneBase(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._packed = None
-        self._plans = {}
+        self._plans = {}                # (the Gumbel frame counter survives: plans on the same device keep naming it, _rng_state re-creates it on a new one)
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -353,11 +353,13 @@ class _BackboneBase(nn.Module):
 
     # -- copies / pickles: recorded launch plans (native handles with baked device pointers), workspaces and packed weights belong to
     # THIS instance's buffers; a copy starts without them and re-packs / re-records on its first forward -----------------------------
-    _TRANSIENT = ("_packed", "_plans", "_stream_pool")
+    _TRANSIENT = ("_packed", "_plans", "_stream_pool", "_gumbel_rng")
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_packed"], d["_plans"], d["_stream_pool"] = None, {}, []
+        if "_gumbel_rng" in d:
+            d["_gumbel_rng"] = None                    # a copy draws its own stream from frame 0 (same seed)
         return d
 
     def __deepcopy__(self, memo):
@@ -870,7 +872,12 @@ class ToC3DEVAViT(_BackboneBase):
         self.token_ratio = list(token_ratio)
         self.use_represent_tokens = use_represent_tokens
         self.token_selection_loss = None                 # training-only (TokenSelectionLoss); inference build
-        self.gumbel_seed = int(torch.initial_seed()) & 0x7fffffffffffffff   # key of the device-side Gumbel draw (toc3d_gumbel_noise) when no noise is injected
+        # Device-side Gumbel draw (toc3d_gumbel_noise) when no noise is injected: Philox key = gumbel_seed (None: torch.initial_seed() at the first
+        # forward, so torch.manual_seed() before inference is honoured like by the reference's generator), counter = ONE frame counter per model
+        # (_gumbel_rng, device memory), shared by every launch plan -- a second input shape, or a plan rebuilt after eviction, continues the stream
+        # instead of replaying it from frame 0.
+        self.gumbel_seed = None
+        self._gumbel_rng = None
         half = embed_dim // num_heads // 2
         self.score_predictor = nn.ModuleList([_Scorer(embed_dim, pruning_num_queries, token_ratio[i], pc_range)
                                               for i in range(len(pruning_loc))])
@@ -1016,7 +1023,7 @@ class ToC3DEVAViT(_BackboneBase):
         m["stage"] = dict(tq=torch.empty(B, Q, QUERY_DIM, **f32), rp=torch.empty(B, Q, 3, **f32), vel=torch.empty(B, Q, 2, **f32),
                           ts32=torch.empty(B, Q, 1, **f32), ts64=torch.empty(B, Q, 1, dtype=torch.float64, device=dev),
                           pose=torch.empty(B, Q, 4, 4, **f32), inv=torch.empty(B, 4, 4, **f32),
-                          gumbel_all=torch.empty(ns, V * T, 2, **f32), rng=torch.zeros(2, dtype=torch.int64, device=dev))
+                          gumbel_all=torch.empty(ns, V * T, 2, **f32), rng=self._rng_state(dev))
         m["stage"]["gumbel"] = [m["stage"]["gumbel_all"][s_] for s_ in range(ns)]      # one buffer: the device-side draw fills all stages in one launch
         m["groups"] = []
         layout = self._group_layout(V, B)
@@ -1036,6 +1043,14 @@ class ToC3DEVAViT(_BackboneBase):
                 gp["order"] = [torch.empty(nv, T, dtype=torch.int64, device=dev) for _ in range(ns)]
             m["groups"].append(gp)
         return m
+
+    def _rng_state(self, dev):
+        """The model's Gumbel frame counter (uint64 [2]: counter, ticket) on ``dev`` -- created once, named by every recorded plan."""
+        if self._gumbel_rng is None or self._gumbel_rng.device != dev:
+            self._gumbel_rng = torch.zeros(2, dtype=torch.int64, device=dev)
+            if self.gumbel_seed is None:
+                self.gumbel_seed = int(torch.initial_seed()) & 0x7fffffffffffffff
+        return self._gumbel_rng
 
     # -- scorer stage (toc3d_eva_vit.py:264-285) -------------------------------------------------------
     # -- extension points of the test-only subclass (toc3d_amd/testing.py); the product forward carries no test switches -----------------

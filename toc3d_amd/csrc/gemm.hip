@@ -350,6 +350,10 @@ int toc3d_linear_chain(int dtype, int config, int64_t n_ops, const toc3d_chain_o
                                   o.M, o.N, o.K, o.n_valid, o.stats_out, o.stats_out_cap, o.stats_in, o.stats_in_cap, o.col_sums, o.ln_n, (float)o.ln_eps,
                                   o.out_act, o.ld_act, o.residual_index);
         if (rc != TOC3D_OK) return rc;
+        // a consumer tile waits for ITS row panel only, while the slot count in the statistics header is written by the producer's tile (0, 0): the
+        // header may be stale (zero on a first launch) for every other panel -- the host must pass the count (high half of stats_in_cap)
+        TOC3D_REQUIRE((o.epilogue != TOC3D_EPI_RESIDUAL_LN && o.epilogue != TOC3D_EPI_SWIGLU_STATS_LN) || (o.stats_in_cap >> 32) > 0,
+                      "toc3d_linear_chain: op %d consumes LayerNorm statistics: pass the slots per row in the high 32 bits of stats_in_cap (the header is not ordered with the row panels)", i);
         c.op[i].dep = i - 1;
         c.op[i].publish = i + 1 < n_ops;
     }

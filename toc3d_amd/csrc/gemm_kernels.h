@@ -135,10 +135,16 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 64-byte rows (4 rows per 256-byte bank row): swz = (-(r >> 2)) & 3; rows of 256 / 512 bytes (every row starts on
 // the same bank): swz = r & 15.  Each makes every ds_read_b128 lane group of the MFMA fragment reads hit 16
 // distinct 16-byte slots.
-template <int RB> TOC3D_DEV int swz(int r) { return RB >= 256 ? (r & 15) : (RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3)); }
+// SW = 1: the image read by the 32x32x16 MFMA fragments (gemm_tile, MF32): a ds_read_b128 lane group then holds rows {0-3, 12-15, 20-27} (+4 / +32 ...) of ONE
+// logical chunk, and on 128-byte rows two rows of equal parity with equal r & 7 (12 and 20) would share a 16-byte slot: swz = (r >> 1) & 7 separates the
+// eight even and the eight odd rows of every such group.  Rows of 256 / 512 bytes: r & 15 is distinct over those row sets as it stands.
+template <int RB, int SW = 0> TOC3D_DEV int swz(int r) {
+    if constexpr (SW == 1 && RB == 128) return (r >> 1) & 7;
+    return RB >= 256 ? (r & 15) : (RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3));
+}
 
 // stage one R-row x RB-byte operand tile with 16-byte global_load_lds: R*RB/16 chunks over 256 threads.
-template <typename T, int R, int RB, int NTHR>
+template <typename T, int R, int RB, int NTHR, int SW = 0>
 TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max_row, int k0, char* lds_tile, int wave, int lane) {
     constexpr int CPR = RB / 16;                        // chunks per row
 #pragma unroll
@@ -147,9 +153,40 @@ TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max
         const int r = cidx / CPR, p = cidx % CPR;
         int gr = row0 + r;
         gr = gr < max_row ? gr : max_row;
-        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB>(r)) << 4);
+        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB, SW>(r)) << 4);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + (t * NTHR + wave * 64) * 16), 16, 0, 0);
     }
+}
+
+// ---- 32x32x16 MFMA form (bf16; gemm_tile with X3 == 32) ----------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16: A / B operands = 8 consecutive K per lane, lane = (row | col) + 32 * k-group (two groups of 8 per 16-deep step); a 32x32 block
+// of the output = 16 f32 per lane.  Per 64-deep K-tile a wave reads (TM + TN) / 32 * 4 fragments of 1 KB -- the same LDS bytes per FLOP as the 16x16x32
+// form on the same per-wave tile -- and issues half as many MFMA instructions at the higher 32x32 rate (MI355X_MICROARCH.md: 2382 vs 2075 TF).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// fragment of the 32-row block starting at tile row r0 for the 16-wide K step s of the K-tile (RB bytes per row)
+template <int RB>
+TOC3D_DEV bf16x8 lds_frag32(const char* tile, int r0, int s, int lane) {
+    const int r = r0 + (lane & 31), cc = s * 2 + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(tile + r * RB + ((cc ^ swz<RB, 1>(r)) << 4));
+}
+
+// One 32x32 accumulator block (operands swapped like mma_step: D rows = W rows = output columns, D columns = activation rows), i.e. per lane: output row
+// m = lane & 31, columns n = q * 8 + (lane >> 5) * 4 + e for register q * 4 + e  ->  the four 16x16 C^T tiles (i2, j2) the epilogues are written for
+// (lane: row i2 * 16 + (lane & 15), columns j2 * 16 + (lane >> 4) * 4 + e).  In bits: the new lane bit 5 is q's low bit, the new lane bit 4 is the old
+// lane bit 5, the row half i2 is the old lane bit 4 -- a three-cycle between two lane bits and one register bit = one v_permlane32_swap (lane bit 5 <->
+// register bit) followed by one v_permlane16_swap (lane bit 4 <-> register bit) per register pair: 16 VALU instructions per block, no LDS.
+TOC3D_DEV void block32_to_tiles16(const f32x16& c, f32x4& t00, f32x4& t01, f32x4& t10, f32x4& t11) {
+#pragma unroll
+    for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned a = __builtin_bit_cast(unsigned, c[(2 * j2) * 4 + e]), b = __builtin_bit_cast(unsigned, c[(2 * j2 + 1) * 4 + e]);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+            const auto s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+            const float lo = __builtin_bit_cast(float, (unsigned)s2[0]), hi = __builtin_bit_cast(float, (unsigned)s2[1]);
+            if (j2 == 0) { t00[e] = lo; t10[e] = hi; } else { t01[e] = lo; t11[e] = hi; }
+        }
 }
 
 // fragment of row r (tile-local) for the 32-wide K step s, lane group g = lane >> 4
@@ -534,7 +571,9 @@ TOC3D_DEV void split_bf16x6(const Frag<float>& f, bf16x8& hi, bf16x8& mid, bf16x
 // workgroup's dynamic LDS.  gemm_kernel below runs one tile per workgroup; gemm_chain_kernel walks a queue of tiles of several GEMMs.
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int X3 = 0>
 TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* smem) {
-    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4), "the bf16 x 3 / x 6 product forms run on f32 operands");
+    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4) || (X3 == 32 && sizeof(T) == 2), "the bf16 x 3 / x 6 product forms run on f32 operands, the 32x32x16 MFMA form on bf16");
+    constexpr bool MF32 = X3 == 32;                     // v_mfma_f32_32x32x16_bf16 in the K loop (see lds_frag32); accumulators handed to the epilogue as 16x16 tiles
+    constexpr int SW = MF32 ? 1 : 0;
     constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
     constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
     constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
@@ -555,11 +594,22 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int MT32 = MF32 ? TM / 32 : 1, NT32 = MF32 ? TN / 32 : 1;
+    static_assert(!MF32 || (TM % 32 == 0 && TN % 32 == 0 && RB >= 128), "32x32 MFMA blocks: per-wave tiles of whole 32x32 blocks, K-tiles of >= 64");
+    f32x16 acc32[MT32][NT32];
+    if constexpr (MF32) {
+#pragma unroll
+        for (int i = 0; i < MT32; ++i)
+#pragma unroll
+            for (int j = 0; j < NT32; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+    }
 
     // EPI_*_LNSELF: LayerNorm of the A rows folded into the epilogue with the statistics taken by this kernel's own K loop (K spans the whole
     // normalised row: norm1 / norm2 in front of q|k|v / w1|w2, ffn_ln in front of w3) -- no statistics hand-off, no LayerNorm launch.
     constexpr bool LNSELF = epi_ln_self(EPI);
-    static_assert(!LNSELF || (sizeof(T) == 2 && X3 == 0), "self-normalising epilogues are bf16 only");
+    static_assert(!LNSELF || (sizeof(T) == 2 && X3 == 0), "self-normalising epilogues are bf16 only (16x16 MFMA form)");
     constexpr int LN_OWN = LNSELF ? (MT + WN - 1) / WN : 1;
     f32x4 ln_sum[LN_OWN], ln_sq[LN_OWN];
 #pragma unroll
@@ -602,18 +652,33 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
                 const int y2 = (cv_yx[u] >> 16) + dy, x2 = (cv_yx[u] & 0xffff) + dx;
                 const bool in = (unsigned)y2 < (unsigned)a.conv_h && (unsigned)x2 < (unsigned)a.conv_w;
                 // out-of-image taps: any 16 zero bytes (no chunk offset: K-tiles of 256 / 512 bytes would run past a small zero line)
-                const char* src = in ? reinterpret_cast<const char*>(A + (int64_t)(cv_m[u] + dy * a.conv_w + dx) * C + c0) + ((pch ^ swz<RB>(r)) << 4)
+                const char* src = in ? reinterpret_cast<const char*>(A + (int64_t)(cv_m[u] + dy * a.conv_w + dx) * C + c0) + ((pch ^ swz<RB, SW>(r)) << 4)
                                      : reinterpret_cast<const char*>(a.zeros);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + (u * NTHR + wave * 64) * 16), 16, 0, 0);
             }
         } else {
-            stage_tile<T, BM, RB, NTHR>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
+            stage_tile<T, BM, RB, NTHR, SW>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
         }
-        stage_tile<T, BN, RB, NTHR>(W, a.ldw, n0, w_max, t * BK, slot + A_BYTES, wave, lane);
+        stage_tile<T, BN, RB, NTHR, SW>(W, a.ldw, n0, w_max, t * BK, slot + A_BYTES, wave, lane);
     };
     auto multiply = [&](int t) {
         const char* sA = smem + (t % STAGES) * STAGE_BYTES;
         const char* sB = sA + A_BYTES;
+        if constexpr (MF32) {
+#pragma unroll
+            for (int s = 0; s < 2 * KS; ++s) {           // 16-deep steps
+                bf16x8 fa[MT32], fb[NT32];
+#pragma unroll
+                for (int i = 0; i < MT32; ++i) fa[i] = lds_frag32<RB>(sA, wm * TM + i * 32, s, lane);
+#pragma unroll
+                for (int j = 0; j < NT32; ++j) fb[j] = lds_frag32<RB>(sB, wn * TN + j * 32, s, lane);
+#pragma unroll
+                for (int i = 0; i < MT32; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT32; ++j) acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc32[i][j], 0, 0, 0);   // swapped: C^T layout
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             Frag<T> fa[MT], fb[NT];
@@ -813,6 +878,12 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         if constexpr (epi_is_rope(EPI)) { wait_vmcnt<0>(); tile_barrier(); }
     }
     TOC3D_TRACE(1);
+    if constexpr (MF32) {
+#pragma unroll
+        for (int i = 0; i < MT32; ++i)
+#pragma unroll
+            for (int j = 0; j < NT32; ++j) block32_to_tiles16(acc32[i][j], acc[2 * i][2 * j], acc[2 * i][2 * j + 1], acc[2 * i + 1][2 * j], acc[2 * i + 1][2 * j + 1]);
+    }
 
     if constexpr (LNSELF) {
         // (mean, rstd) of the tile's rows into the row table behind the operand stages (nothing else lives there).  C layout of the 16x16 MFMA:
@@ -1181,6 +1252,27 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 52: launch_cfg<T, EPI, 192, 192, 1, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 single buffer, 96x48 per wave, 48 KiB: 512 tiles for q|k|v at M = 6000 (one per slot at two per CU)
         case 53: launch_cfg<T, EPI, 192, 192, 2, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 double buffered, 96 KiB
         case 51: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 8 : 1)>(a, s); break;   // variant 16 held to 64 registers (bf16): FOUR workgroups per CU -- the loop is bound by operand bytes in flight per CU
+        // 32x32x16 MFMA form of the K loop (bf16 only; round 4): per-wave tiles of whole 32x32 blocks, own LDS swizzle, same epilogues (the accumulators are
+        // permuted into the 16x16 C^T layout first).  NOT bit-identical with the 16x16x32 variants: the matrix core sums 16 instead of 32 products per step.
+#define TOC3D_MF32(BM_, BN_, ST_, RB_, WM_, WN_, OCC_)                                                                              \
+        if constexpr (sizeof(T) == 2 && !epi_ln_self(EPI)) launch_cfg<bf16_t, EPI, BM_, BN_, ST_, RB_, WM_, WN_, OCC_, 32>(a, s); \
+        else return TOC3D_ERR_ARG;                                                                                                 \
+        break
+        case 70: TOC3D_MF32(128, 128, 1, 128, 2, 4, 6);      // variant 16's tile: 8 waves, 64x32 per wave, single buffer
+        case 71: TOC3D_MF32(128, 128, 2, 128, 2, 4, 1);      // variant 17's: double buffered
+        case 72: TOC3D_MF32(128, 128, 1, 128, 2, 2, 4);      // 4 waves, 64x64 per wave (2x2 blocks), single buffer, <= 128 registers: 4 workgroups per CU
+        case 73: TOC3D_MF32(128, 128, 2, 128, 2, 2, 1);      // ... double buffered
+        case 74: TOC3D_MF32(256, 128, 1, 128, 4, 2, 1);      // 8 waves, 256x128, 64x64 per wave, single buffer (48 KiB)
+        case 75: TOC3D_MF32(256, 128, 2, 128, 4, 2, 1);      // ... double buffered (96 KiB)
+        case 76: TOC3D_MF32(128, 256, 2, 128, 2, 4, 1);      // 8 waves, 128x256, 64x64 per wave, double buffered
+        case 77: TOC3D_MF32(256, 256, 2, 128, 4, 2, 1);      // 8 waves, 256x256, 64x128 per wave, double buffered (128 KiB)
+        case 78: TOC3D_MF32(192, 192, 1, 128, 2, 2, 1);      // 4 waves, 192x192, 96x96 per wave (3x3 blocks), single buffer (48 KiB)
+        case 79: TOC3D_MF32(128, 128, 4, 128, 2, 4, 1);      // variant 29's: 4-deep ring
+        case 80: TOC3D_MF32(256, 128, 3, 128, 4, 2, 1);      // 256x128, 3-deep ring (144 KiB)
+        case 81: TOC3D_MF32(128, 128, 3, 128, 2, 2, 1);      // 4 waves, 64x64 per wave, 3-deep ring (96 KiB)
+        case 82: TOC3D_MF32(64, 128, 2, 128, 2, 2, 1);       // 64x128, 4 waves, 32x64 per wave, double buffered
+        case 83: TOC3D_MF32(128, 64, 2, 128, 2, 2, 1);       // 128x64, 4 waves, 64x32 per wave, double buffered
+#undef TOC3D_MF32
         // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
         case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB
         case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB

@@ -451,6 +451,19 @@ TOC3D_DEV void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
     }
 }
 
+// 32 random bits -> one Gumbel(0, 1) sample -log(-log(U)).  U = (23 random bits + 0.5) * 2^-23: the sum has 24 significant bits, so it is exact in f32
+// and U lies in [2^-24, 1 - 2^-24] -- strictly inside (0, 1), both logs finite for EVERY input word.  (The first form took 24 bits + 0.5: 25
+// significant bits, and 0xFFFFFF + 0.5 rounded to 2^24, i.e. U = 1 and a sample of +inf once in 2^24 draws -> NaN soft mask.)
+TOC3D_DEV float gumbel_from_bits(unsigned bits) {
+    const float u = ((float)(bits >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    return -logf(-logf(u));
+}
+
+__global__ __launch_bounds__(256) void gumbel_from_bits_kernel(const unsigned* __restrict__ bits, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = gumbel_from_bits(bits[i]);
+}
+
 __global__ __launch_bounds__(256) void gumbel_noise_kernel(float* __restrict__ out, int64_t n, unsigned long long seed, unsigned long long* __restrict__ state) {
     const unsigned long long frame = state[0];
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one Philox block = 4 values
@@ -459,10 +472,7 @@ __global__ __launch_bounds__(256) void gumbel_noise_kernel(float* __restrict__ o
         philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
         float gv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float u = ((float)(c[e] >> 8) + 0.5f) * 5.9604644775390625e-08f;      // (0, 1) strictly: 24 random bits
-            gv[e] = -logf(-logf(u));
-        }
+        for (int e = 0; e < 4; ++e) gv[e] = gumbel_from_bits(c[e]);
         if (q * 4 + 4 <= n) *reinterpret_cast<f32x4*>(out + q * 4) = f32x4{gv[0], gv[1], gv[2], gv[3]};
         else for (int e = 0; q * 4 + e < n; ++e) out[q * 4 + e] = gv[e];
     }
@@ -552,6 +562,14 @@ int toc3d_gumbel_noise(float* out, int64_t n, uint64_t seed, uint64_t* state, to
     TOC3D_REQUIRE(blocks <= 0x7fffffff, "toc3d_gumbel_noise: n too large");
     toc3d_launch(gumbel_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out, n, (unsigned long long)seed, (unsigned long long*)state);
     TOC3D_LAUNCH_CHECK("toc3d_gumbel_noise");
+    return TOC3D_OK;
+}
+
+int toc3d_gumbel_from_bits(const uint32_t* bits, int64_t n, float* out, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(bits && out && n >= 0, "toc3d_gumbel_from_bits: bad arguments");
+    if (n == 0) return TOC3D_OK;
+    toc3d_launch(gumbel_from_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), bits, n, out);
+    TOC3D_LAUNCH_CHECK("toc3d_gumbel_from_bits");
     return TOC3D_OK;
 }
 

@@ -59,6 +59,7 @@ _SIGS = {
     "toc3d_collapse_query_scorer": "ppppplllfppp",
     "toc3d_score_tokens": "plpppplllpppp",
     "toc3d_gumbel_noise": "plLpp",
+    "toc3d_gumbel_from_bits": "plpp",
     "toc3d_global_mean_half": "ipllllp",
     "toc3d_score_head": "ipllppplpppp",
     "toc3d_nhwc_to_nchw": "pplllp",
