@@ -15,8 +15,8 @@ from toc3d_amd import configs, lib
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(lib.LIB_PATH), "build first: make -C toc3d_amd/csrc"
     dll = ctypes.CDLL(lib.LIB_PATH)
-    names = lib.header_functions()
-    assert len(names) >= 20
+    names = lib.header_functions()                 # the declarations of THIS build flavour (#ifdef TOC3D_EXPERIMENTAL blocks only for EXPERIMENTAL=1 libraries)
+    assert len(names) >= 50 and set(lib.header_functions(True)) - set(lib.header_functions(False)) == set(lib._SIGS_EXPERIMENTAL) | {"toc3d_linear_chain_info"}
     for n in names:
         assert hasattr(dll, n), f"{n} declared in include/toc3d.h but not exported"
     l = lib.load()
@@ -26,14 +26,15 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_ctypes_signatures_match_header():
-    txt = re.sub(r"/\*.*?\*/", "", open(lib.HEADER_PATH).read(), flags=re.S)
+    txt = lib.header_text(True)                    # every declaration, the experimental ones included: their ctypes signatures are checked too
+    sigs = dict(lib._SIGS, **lib._SIGS_EXPERIMENTAL)
     seen = 0
     for m in re.finditer(r"\bint\s+(toc3d_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
         name, args = m.group(1), m.group(2)
         if name == "toc3d_abi_version":
             continue
-        if name not in lib._SIGS:
-            continue                      # int64_t-returning helpers are matched by the second regex below
+        if name not in sigs:
+            continue                      # helpers with other return types are bound by hand in lib.load()
         sig = ""
         for a in (x.strip() for x in args.split(",")):
             if "*" in a or "toc3d_stream_t" in a or "toc3d_plan_t" in a:
@@ -48,9 +49,9 @@ def test_ctypes_signatures_match_header():
                 sig += "f"
             else:
                 raise AssertionError(f"unparsed parameter {a!r} in {name}")
-        assert lib._SIGS[name] == sig, name
+        assert sigs[name] == sig, name
         seen += 1
-    assert seen == len(lib._SIGS)
+    assert seen == len(sigs)
     assert lib.load().toc3d_window_topk_rows(6, 20, 50, 16, 128) == 6 * (3 * 129 + 33 + 3 * 65 + 9)
 
 
@@ -254,6 +255,30 @@ def test_product_forward_has_no_test_switches():
     assert im is m and isinstance(m, InstrumentedToC3DEVAViT) and m._instrumented is True and "forced_scores" in inspect.signature(type(m).forward).parameters
 
 
+def test_launch_schedule_switches_are_attributes_not_environment():
+    """The schedule switches of the product forward (toc3d_amd.backbone.schedule_defaults) are constructor kwargs / attributes with shipped defaults per
+    precision; no module of the product package reads an environment variable to pick a code path (TOC3D_LIB, the library file name, is the one
+    environment hook: it selects WHICH build is loaded, not what the host code does)."""
+    from toc3d_amd.backbone import schedule_defaults
+    assert set(schedule_defaults("bf16")) == {"carry_compact", "fold_ffn_ln", "fold_norm2", "gathered_residual", "prefetch_weights", "attn_rot", "side_lanes",
+                                              "big_windows_first", "launch_mode"}
+    d16, d32, dx3 = schedule_defaults("bf16"), schedule_defaults("fp32"), schedule_defaults("fp32x3")
+    assert d16["fold_norm2"] and d16["carry_compact"] and d16["attn_rot"] and d16["prefetch_weights"] > 0
+    assert not (d32["fold_ffn_ln"] or d32["fold_norm2"] or d32["carry_compact"] or d32["attn_rot"]), "the strict-parity path keeps the reference's sequence"
+    assert dx3["fold_ffn_ln"]
+    m = toc3d_amd.build_backbone(dict(configs.get("toc3d_tiny"), schedule=dict(fold_norm2=False, side_lanes=False)))
+    assert m.fold_norm2 is False and m.side_lanes is False and m.fold_ffn_ln is True
+    with pytest.raises(TypeError, match="unknown schedule"):
+        toc3d_amd.build_backbone(dict(configs.get("toc3d_tiny"), schedule=dict(ln_self=True)))
+    pkg = os.path.dirname(os.path.abspath(toc3d_amd.__file__))
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            reads = set(re.findall(r"environ[^\n]*?[\"'](TOC3D_\w+)[\"']", src))
+            assert reads <= ({"TOC3D_LIB"} if fn == "lib.py" else set()), (fn, reads)
+
+
+@pytest.mark.skipif(not lib.experimental(), reason="GEMM chains exist only in `make EXPERIMENTAL=1` builds (TOC3D_LIB=libtoc3d_gfx950_exp.so)")
 def test_chain_schedule_host_logic():
     """toc3d_linear_chain's tile lists (toc3d_amd/lib.py chain_schedule) without a GPU: every tile of every op exactly once, and every tile behind
     ALL the tiles it reads (the N-tiles of the previous op that cover its rows) inside its own band -- for every config, ragged M, band counts, lags
@@ -285,6 +310,7 @@ def test_chain_schedule_host_logic():
     assert lib.chain_info(55) is None
 
 
+@pytest.mark.skipif(not lib.experimental(), reason="round-3 experiments exist only in `make EXPERIMENTAL=1` builds (TOC3D_LIB=libtoc3d_gfx950_exp.so)")
 def test_round3_entry_points_validate_without_gpu():
     l = lib.load()
     assert l.toc3d_linear_chain(lib.BF16, 0, 3, None, None, 8, None, 768, 0, None) == -1 and b"bad arguments" in l.toc3d_last_error()

@@ -8,7 +8,7 @@ import torch
 
 from toc3d_amd import lib
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not lib.experimental(), reason="round-3 experiment: `make EXPERIMENTAL=1`, TOC3D_LIB=libtoc3d_gfx950_exp.so")]
 DEV = "cuda:0"
 
 

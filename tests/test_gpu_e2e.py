@@ -398,27 +398,6 @@ def test_carried_compact_set_matches_scatter_gather_between_blocks():
     assert not m32.carry_compact, "the strict-parity path keeps the reference's scatter / gather between all blocks by default"
 
 
-def test_scatter_folded_into_the_next_gather_gives_the_same_bits():
-    """toc3d_gather_merge_ln_pending (the scatter of block i applied by the gather of block i + 1 where the window type changes,
-    toc3d_eva_vit.py:452-456 + :412-420) against the separate toc3d_scatter_update + toc3d_gather_merge_ln_ex launches: features, soft masks and kept
-    lists bit-identical, fp32 with a previous frame (every block scatters: 15 folded pairs) and bf16 on a first frame (carried pairs in between: updates three
-    and four ride along), three forwards each (eager warm-up, recording, replay)."""
-    inp = synth.make_inputs(configs.get("toc3d_faster"), views_per_frame=6)
-    for precision, prev in (("fp32", True), ("bf16", False)):        # (all four combinations were run when the kernel was written; these two keep the suite short)
-        if True:
-            outs = {}
-            for fuse in (True, False):
-                _, m = build("toc3d_faster", precision)
-                m.fuse_scatter, m.autotune = fuse, False
-                for _ in range(3):
-                    o = run_toc3d(m, inp, prev)
-                outs[fuse] = [o.img_feats["last_feat"].clone()] + [t.clone() for t in o.token_masks] + [t.clone() for t in o.keep_idx]
-                del m
-            for a, b in zip(outs[True], outs[False]):
-                assert torch.equal(a, b), f"{precision} prev={prev}: the folded scatter changes the result"
-            assert bool(torch.isfinite(outs[True][0].float()).all())
-
-
 def test_carried_compact_set_on_long_runs_of_one_window_type():
     """A layout the shipped configs do not have: up to six consecutive accelerated blocks of one window type within a stage
     (global_attn_indexes=(2, 11), pruning_loc=[3, 9]).  Carried sets must pair up (3,4) (5,6) (7,8); a block after a pair starts from

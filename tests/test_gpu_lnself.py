@@ -9,7 +9,7 @@ from toc3d_amd import lib, synth
 from test_gpu_ops import DEV, S, as_act, pack, relerr, rnd, ru
 from test_gpu_attn_rot import compact_tables, rc_of, rope_ref
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not lib.experimental(), reason="round-3 experiment: `make EXPERIMENTAL=1`, TOC3D_LIB=libtoc3d_gfx950_exp.so")]
 BF, TBF = lib.BF16, torch.bfloat16
 EPS = 1e-6
 

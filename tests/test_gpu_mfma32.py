@@ -10,7 +10,7 @@ import torch
 from test_gpu_ops import DEV, S, as_act, pack, relerr, rnd, ru
 from toc3d_amd import lib
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not lib.experimental(), reason="measured, not faster (profiles/r04_mfma32_variants.txt): `make EXPERIMENTAL=1`, TOC3D_LIB=libtoc3d_gfx950_exp.so")]
 MF32 = (70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83)
 dt, tdt = lib.BF16, torch.bfloat16
 

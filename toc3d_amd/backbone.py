@@ -14,13 +14,13 @@ memory, streams and parameter bookkeeping only.  There is no CPU fallback: a non
 Extra (non-reference) constructor kwarg: ``precision`` = ``"bf16"`` (bf16 MFMA operands, f32 accumulate,
 f32 residual stream), ``"fp32"`` (exact-f32 MFMA, the strict-parity path) or ``"fp32x3"`` (f32 buffers everywhere, the linear
 layers' products as three bf16 MFMAs on (hi, lo) operand splits: parity-grade at several times the fp32 path's speed).
+``schedule`` = dict of overrides of the launch-schedule attributes of ``schedule_defaults`` (A/B runs, tests); the defaults are the shipped schedule.
 Extra forward kwarg: ``gumbel_noise`` (list of 3 tensors (B*Nv, T, 2)) to make the stochastic soft mask
 (``toc3d_utils.py:147``) reproducible; when omitted the noise is drawn on the device like the reference does.
 """
 from __future__ import annotations
 
 import math
-import os
 from functools import partial
 from typing import Dict, List, Optional
 
@@ -167,7 +167,26 @@ _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28,
              lib.F32X3: (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 114, 116, 117, 122, 126, 149)}
 _VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3]
 
-_TABLE_ALIAS = {lib.EPI_RESIDUAL_ACT: lib.EPI_RESIDUAL, lib.EPI_SWIGLU_LNSELF: lib.EPI_SWIGLU_STATS, lib.EPI_RESIDUAL_LNSELF: lib.EPI_RESIDUAL_LN}
+
+def schedule_defaults(precision):
+    """The launch-schedule switches of the backbones and their shipped defaults per precision.  Plain attributes (``model.fold_norm2 = False`` before the
+    first forward, or ``schedule=dict(...)`` at construction); every one is pinned by a test (tests/test_gpu_e2e.py, tests/test_cpu_abi.py).  The
+    experiments of rounds 2-3 that lost (LayerNorm statistics in the consuming K loop, scatter folded into the next gather, prefetch across the frame
+    boundary, lighter event fences) are not part of the product forward any more: DESIGN.md section 4 keeps their measurements, `make EXPERIMENTAL=1`
+    their kernels."""
+    bf16 = precision == "bf16"
+    fast = precision in ("bf16", "fp32x3")
+    return dict(
+        carry_compact=bf16,          # consecutive accelerated blocks of one window type continue on the same compact rows (_accel_block)
+        fold_ffn_ln=fast,            # SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused)
+        fold_norm2=bf16,             # norm2 folded across the attention-projection -> w1|w2 boundary the same way
+        gathered_residual=True,      # the gather skips the f32 copy of the kept rows; the projection GEMM reads their residual from x through crow_tok
+        prefetch_weights=192 if bf16 else 0,   # workgroups of each attention launch that pull the next GEMMs' weights towards the chip (0 = off)
+        attn_rot=bf16,               # RoPE + q scale in the q|k|v GEMM epilogue, attention on the pre-rotated buffer with K / V staged by DMA
+        side_lanes=True,             # scorer query prep and rankings on lanes beside the block chain (False: on the chain's own lane)
+        big_windows_first=True,      # dense attention windows ordered biggest-first in the static window lists
+        launch_mode="plan",          # "plan" (recorded launch plan replayed from C), "graph" (explicit hipGraph), "eager"
+    )
 
 
 def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED):
@@ -181,21 +200,15 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
     key = (epi, M, N, K)
     var = self._tuned.get(key)
     s = lib.stream_ptr()
-    if epi in (lib.EPI_QKV_ROPE, lib.EPI_QKV_ROPE_LNSELF):
+    if epi == lib.EPI_QKV_ROPE:
         # the rotating epilogue costs what the bias epilogue costs: it shares that epilogue's tile table (no second tuning sweep)
         rope = fused
         if var is None:
             var = self._tuned.get((lib.EPI_BIAS, M, N, K), 0)
         if var % 100 in (60, 61, 62, 63):                        # the phased tiles do not carry the RoPE tables
             var = 0
-        lib.call("toc3d_linear_qkv_rope" if epi == lib.EPI_QKV_ROPE else "toc3d_linear_qkv_rope_ln", dtg, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
+        lib.call("toc3d_linear_qkv_rope", dtg, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
         return
-    if var is None and epi in _TABLE_ALIAS:
-        # the self-normalising epilogues run the K loop and the tile shapes of the statistics-passing forms: a shipped table's entry for
-        # those serves them until this shape is tuned under its own key
-        var = self._tuned.get((_TABLE_ALIAS[epi], M, N, K))
-        if var is not None and var % 100 in (60, 61, 62, 63):
-            var = None
     if var is None:
         var = 0
         if lib.recording():
@@ -204,15 +217,15 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
             return
         if self.autotune and not torch.cuda.is_current_stream_capturing():
             o = out
-            if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS, lib.EPI_RESIDUAL_ACT, lib.EPI_RESIDUAL_LNSELF):   # in-place residual add: tune into scratch
+            if epi in (lib.EPI_RESIDUAL, lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # in-place residual add: tune into scratch
                 o = torch.empty(M, ldo, dtype=torch.float32, device=out.device)
             rep_s = torch.empty_like(rep_out) if rep_out is not None else None
             cands = _VARIANTS[dtg]
-            if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN, lib.EPI_SWIGLU_LNSELF):
+            if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):
                 cands = [v for v in cands if v not in (33, 45, 145, 52, 53, 152)]   # wave slabs that are not whole (w1, w2) 32-column groups
             if epi in (lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):  # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
                 cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47, 60, 63)]
-            if epi in (lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS, lib.EPI_RESIDUAL_ACT, lib.EPI_RESIDUAL_LNSELF, lib.EPI_SWIGLU_LNSELF):   # the phased tiles do not carry the folded-LayerNorm epilogues
+            if epi in (lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # the phased tiles do not carry the folded-LayerNorm epilogues
                 cands = [v for v in cands if v % 100 not in (60, 63)]
             # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
             # L2 / Infinity Cache): time single launches behind a cache-sized memset, not a warm back-to-back loop, or the
@@ -250,7 +263,7 @@ class _BackboneBase(nn.Module):
 
     def _setup_common(self, img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias,
                       use_abs_pos, pt_hw_seq_len, window_size, global_window_size, global_attn_indexes,
-                      pretrain_img_size, pretrain_use_cls_token, out_feature, precision, img_norm_cfg=None, pad_size_divisor=32):
+                      pretrain_img_size, pretrain_use_cls_token, out_feature, precision, img_norm_cfg=None, pad_size_divisor=32, schedule=None):
         assert precision in ("bf16", "fp32", "fp32x3", "fp32x6"), precision
         # uint8 boundary: with img_norm_cfg (the config's dict(mean, std, to_rgb), ToC3D_faster.py:13-14)
         # forward() also accepts raw uint8 HWC camera images and applies NormalizeMultiviewImage + PadMultiViewImage
@@ -294,44 +307,14 @@ class _BackboneBase(nn.Module):
         self.autotune = True            # pick the GEMM tile variant per shape by measurement (first eager forward)
         self.alias_outputs = False      # True: returned tensors alias the reused workspace (benchmarks)
         self.view_groups = 1            # > 1: split the views into groups that run concurrently on separate lanes (HIP streams)
-        self.carry_compact = precision == "bf16" and os.environ.get("TOC3D_CARRY", "1") != "0"   # see _accel_block
-        # bf16 path: SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused): no LayerNorm pass over
-        # the hidden activations.  The strict-parity fp32 path keeps the reference's sequence (eva_vit.py:47-49).
-        self.fold_ffn_ln = precision in ("bf16", "fp32x3") and os.environ.get("TOC3D_FOLD_LN", "1") != "0"      # (fp32x3, round 3: f32 statistics, bf16 x 3 products)
-        # ... and norm2 folded across the attention-projection -> w1|w2 boundary the same way (EPI_RESIDUAL_STATS -> EPI_SWIGLU_STATS_LN): the
-        # projection's residual epilogue also leaves the updated rows in bf16 with their statistics, so the LayerNorm launch in front of the MLP goes
-        # (7 launches per accelerated block, 179 per frame instead of 203).  Round 2 measured it neutral (191.1 vs 189.2 frames/s) and left it off;
-        # on the round-3 kernels it reads +0.3 % in two same-box A/B rounds (198.5 / 199.5 -> 199.0 / 200.2), the parity suites are green with it:
-        # ON since the end of round 3, TOC3D_FOLD_N2=0 restores the explicit launch.
-        self.fold_norm2 = precision == "bf16" and self.fold_ffn_ln and os.environ.get("TOC3D_FOLD_N2", "1") != "0"
-        # round 3, measured and OFF by default (TOC3D_LN_SELF=1 / 2 enables it): the LayerNorms folded into the CONSUMING GEMM alone -- its K loop
-        # spans the whole normalised row (norm1 / norm2: K = C, ffn_ln: K = the hidden width), so it takes the row statistics from the operand tiles it
-        # multiplies anyway (EPI_*_LNSELF, include/toc3d.h): no LayerNorm launch, no statistics buffer; the producer only leaves a bf16 copy of its
-        # rows (EPI_RESIDUAL_ACT).  Correct and slightly more accurate than the explicit launches (tests/test_gpu_lnself.py) but slower: the K loops
-        # do not tolerate the extra LDS read + statistics work per K step (three forms tried, profiles/r03_lnself.txt: -4.5 % ... -7 % frames/s with
-        # norm2 + ffn_ln, -12 % ... -23 % with norm1 of the dense blocks as well, against +0.17 ms of LayerNorm launches saved).
-        self.ln_self = precision == "bf16" and self.fold_ffn_ln and os.environ.get("TOC3D_LN_SELF", "0") != "0"
-        self.ln_self_norm1 = self.ln_self and os.environ.get("TOC3D_LN_SELF", "0") not in ("0", "1")      # TOC3D_LN_SELF=2: norm1 of the dense blocks as well
-        # the gather kernel skips the f32 copy of the kept rows (40 % of its bytes); the projection GEMM reads their residual from x through
-        # crow_tok instead (toc3d_gather_merge_ln_ex kept_copy = 0 + toc3d_linear_fused residual_index).  Same bits either way.
-        self.gathered_residual = os.environ.get("TOC3D_GATHERED_RES", "1") != "0"
-        # software prefetch of the weights of the GEMMs that follow each attention launch, by extra workgroups of that launch
-        # (toc3d_window_attention_pf): number of prefetch workgroups, 0 = off
-        # (same-box A/B r02: 190.8 frames/s without, 193.8 / 193.4 / 192.8 / 191.6 with 128 / 256 / 512 / 1024 workgroups)
-        self.prefetch_weights = int(os.environ.get("TOC3D_PREFETCH", "192" if precision == "bf16" else "0"))
-        self.prefetch_wrap = os.environ.get("TOC3D_PREFETCH_WRAP", "0") != "0"
-        # round 3, measured and OFF by default (TOC3D_FUSE_SCATTER=1): where the window type changes between two accelerated blocks (7 -> 8, 8 -> 9, ...), the
-        # scatter of block i folded into the gather of block i + 1 (toc3d_gather_merge_ln_pending): one pass over x instead of two, nine launches less per
-        # frame, same bits (tests/test_gpu_e2e.py) -- and 3 % slower (202.7 -> 196.4 frames/s): the merge waves of the gather are latency-critical (18-48
-        # workgroups walk the dropped tokens four at a time) and now wait for three row loads and a store per token instead of one load.
-        self.fuse_scatter = os.environ.get("TOC3D_FUSE_SCATTER", "0") != "0"
-        # bf16 path, round 3: RoPE + the q scale applied by the q|k|v GEMM's epilogue on the f32 accumulators (toc3d_linear_qkv_rope), attention on the
-        # pre-rotated buffer with K / V staged by DMA (toc3d_window_attention_rot).  The strict-parity fp32 path keeps the reference's sequence.
-        self.attn_rot = precision == "bf16" and os.environ.get("TOC3D_ATTN_ROT", "1") != "0"
-        # "plan": the frame's launch sequence is recorded once per (input shape, config) and replayed from C with one call per frame
-        # (toc3d_plan_run, HIP streams + events); "graph": the same recording as an explicitly built hipGraph; "eager": every launch
-        # issued from Python (what the first forward of a shape always does: it autotunes, and it is what gets recorded next).
-        self.launch_mode = os.environ.get("TOC3D_LAUNCH", "plan")
+        # launch-schedule switches (schedule_defaults above): shipped defaults per precision, overridable per model -- no environment variables
+        sched = schedule_defaults(precision)
+        unknown = set(schedule or {}) - set(sched)
+        if unknown:
+            raise TypeError(f"unknown schedule switches {sorted(unknown)}; known: {sorted(sched)}")
+        sched.update(schedule or {})
+        for k_, v_ in sched.items():
+            setattr(self, k_, v_)
         assert self.launch_mode in MODES, self.launch_mode
         self._stream_pool = []
 
@@ -423,7 +406,7 @@ class _BackboneBase(nn.Module):
             lib.call("toc3d_pack_swiglu", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias),
                      self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
             p["w12"], p["b12"] = w12, b12
-            if self.fold_norm2 or self.ln_self:                   # gamma2-scaled interleaved weights + (c1, c2) in packed column order; replaces w12 / b12
+            if self.fold_norm2:                                   # gamma2-scaled interleaved weights + (c1, c2) in packed column order; replaces w12 / b12
                 p["c1_12"], p["c2_12"] = torch.empty(2 * Hp, device=dev), torch.empty(2 * Hp, device=dev)
                 lib.call("toc3d_pack_swiglu_lnfold", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias), self._f32(m.w2.bias),
                          self._f32(blk.norm2.weight), self._f32(blk.norm2.bias), Hd, C, w12, p["c1_12"], p["c2_12"], Hp, C, lib.stream_ptr())
@@ -436,13 +419,6 @@ class _BackboneBase(nn.Module):
                 p["w3"] = w3f                                     # gamma-scaled; c1 / c2 carry the mean and beta / bias terms
             else:
                 p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
-            if self.ln_self_norm1 and self.attn_rot and not self._accelerated(len(blocks)):
-                # norm1 folded into q|k|v the same way (dense blocks): gamma1-scaled weights, c1 = their row sums, c2 = W.beta1 + bias
-                wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)
-                p["wqkv_ln"] = torch.zeros(_round_up(3 * C, 128), C, dtype=self._tdt, device=dev)
-                p["c1_qkv"], p["c2_qkv"] = torch.empty(3 * C, device=dev), torch.empty(3 * C, device=dev)
-                lib.call("toc3d_pack_weight_lnfold", self._dt, self._f32(wq).contiguous(), self._f32(blk.norm1.weight), self._f32(blk.norm1.bias), p["bqkv"],
-                         3 * C, C, p["wqkv_ln"], p["wqkv_ln"].shape[0], C, p["c1_qkv"], p["c2_qkv"], lib.stream_ptr())
             for n, mod in (("ln1", blk.norm1), ("ln2", blk.norm2), ("lnf", m.ffn_ln)):
                 p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
             p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
@@ -509,7 +485,7 @@ class _BackboneBase(nn.Module):
              "count": torch.empty(nW, dtype=torch.int32, device=dev), "npad": torch.empty(nW, dtype=torch.int32, device=dev),
              "nW": nW, "N": N, "max_count": min(N, min(L, h) * min(L, w))}
         lib.call("toc3d_window_map_dense", V, h, w, L, d["rows"], d["slots"], d["count"], d["npad"], lib.stream_ptr())
-        if os.environ.get("TOC3D_BIG_WINDOWS_FIRST", "1") != "0":
+        if self.big_windows_first:
             # Windows are independent, so their order in the lists is free: biggest first.  The attention grid is dispatched in list order and the
             # edge windows of a 20 x 50 token grid are a fraction of the full ones (16 x 16 windows: 256 / 64 / 32 / 8 keys; 20 x 20: 400 / 200); with
             # the full windows spread over the dispatch rounds the launch ends on a round of stragglers (profiles/r03_attn_timeline.txt: dense
@@ -596,14 +572,6 @@ class _BackboneBase(nn.Module):
         C = self.embed_dim
         Kp = plan["col"].shape[1]
         pos = P["pos"][(plan["h"], plan["w"])]
-        plan["a_is_x"] = False
-        if self.ln_self_norm1 and self.attn_rot and not self._accelerated(0):
-            # the first block's q|k|v normalises its own rows: the stem leaves them in bf16 as well
-            self._linear(lib.EPI_RESIDUAL_ACT, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
-                         plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, None, plan["M"], C, Kp, 0,
-                         fused=lib.NO_FUSED[:7] + (plan["a"], C, None))
-            plan["a_is_x"] = True
-            return
         self._linear(lib.EPI_RESIDUAL, plan["col"], Kp, P["w_patch"], P["w_patch"].shape[1], P["b_patch"],
                      plan["x"], C, pos, C, plan["T"] if pos is not None else 0, None, None, plan["M"], C, Kp, 0)
 
@@ -629,22 +597,15 @@ class _BackboneBase(nn.Module):
         nb = (ctypes.c_int64 * len(ts))(*[t.numel() * t.element_size() for t in ts])
         lib.call("toc3d_window_attention_pf", *args, len(ts), ptrs, nb, self.prefetch_weights, s)
 
-    def _qkv_attention(self, P, i, plan, M, rope_rc, arows, aslots, count_q, count_k, npad, pad, stride, nwin, max_count, v_bias, norm1_self=False):
-        """q|k|v projection + windowed attention of block i on plan["a"] [M, C] -> plan["att"] (eva_vit.py:97-113, toc3d_eva_vit.py:495-512).
-        norm1_self: plan["a"] holds the raw bf16 rows of x and the projection normalises them itself (EPI_QKV_ROPE_LNSELF)."""
+    def _qkv_attention(self, P, i, plan, M, rope_rc, arows, aslots, count_q, count_k, npad, pad, stride, nwin, max_count, v_bias):
+        """q|k|v projection + windowed attention of block i on plan["a"] [M, C] -> plan["att"] (eva_vit.py:97-113, toc3d_eva_vit.py:495-512)."""
         bp = P["blocks"][i]
         C, dt = self.embed_dim, self._dt
         if self.attn_rot and stride <= 416:
-            if norm1_self:
-                self._linear(lib.EPI_QKV_ROPE_LNSELF, plan["a"], C, bp["wqkv_ln"], C, bp["c2_qkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
-                             fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5, bp["c1_qkv"], C, self.LN_EPS))
-            else:
-                self._linear(lib.EPI_QKV_ROPE, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
-                             fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5))
+            self._linear(lib.EPI_QKV_ROPE, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
+                         fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5))
             import ctypes
-            # the last block's attention pulls the NEXT FRAME's first q|k|v weights: block 0 otherwise starts every frame on weights that were last
-            # touched a frame ago (its q|k|v launch reads 68 us against 42 for the other dense blocks, profiles/r03_where_time_goes.txt)
-            nxt = P["blocks"][i + 1] if i + 1 < self.depth else (P["blocks"][0] if self.prefetch_wrap else None)
+            nxt = P["blocks"][i + 1] if i + 1 < self.depth else None
             ts = [bp["wproj"], bp["w12"], bp["w3"]] + ([nxt["wqkv"]] if nxt is not None else [])
             if not self.prefetch_weights:
                 ts = []
@@ -663,30 +624,19 @@ class _BackboneBase(nn.Module):
         norm2 folded the epilogue also leaves the updated rows in bf16 (plan["a"]) and their statistics (plan["stats2"]) for the w1|w2 GEMM."""
         C = self.embed_dim
         res = out if res is None else res
-        if self.ln_self:
-            self._linear(lib.EPI_RESIDUAL_ACT, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
-                         fused=lib.NO_FUSED[:7] + (plan["a"], C, res_index))
-        elif self.fold_norm2:
+        if self.fold_norm2:
             self._linear(lib.EPI_RESIDUAL_STATS, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
                          fused=(plan["stats2"], plan["stats2_cap"], None, 0, None, 0, 0.0, plan["a"], C, res_index))
         else:
             self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
                          fused=lib.NO_FUSED[:9] + (res_index,))
 
-    def _mlp(self, bp, plan, rows, res, rep_out, rep_index, copy_out=False):
-        """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C].
-        copy_out (ln_self): the w3 GEMM also leaves its rows in bf16 in plan["a"] (the next block's q|k|v normalises them itself)."""
+    def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
+        """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
         s = lib.stream_ptr()
         C, Hd = self.embed_dim, self.hidden_dim
         Hp = plan["hid"].shape[1]
         dt = self._dt
-        if self.ln_self:
-            # both LayerNorms inside the consuming GEMMs: plan["a"] = the bf16 rows the projection left (_proj)
-            self._linear(lib.EPI_SWIGLU_LNSELF, plan["a"], C, bp["w12"], C, bp["c2_12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                         fused=(None, 0, None, 0, bp["c1_12"], C, self.LN_EPS, None, 0, None))
-            self._linear(lib.EPI_RESIDUAL_LNSELF, plan["hid"], Hp, bp["w3"], bp["w3"].shape[1], bp["c2"], res, C, res, C, 0,
-                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, None, 0, bp["c1"], Hd, self.LN_EPS, plan["a"] if copy_out else None, C if copy_out else 0, None))
-            return
         if self.fold_ffn_ln:
             # ffn_ln folded: the SwiGLU GEMM leaves per-row (sum, sum^2) slots, the w3 GEMM (gamma-scaled weights) normalises in its epilogue;
             # norm2 folded the same way: plan["a"] / plan["stats2"] were left by the projection GEMM (_proj), no LayerNorm launch here
@@ -714,17 +664,10 @@ class _BackboneBase(nn.Module):
         C, M, dt = self.embed_dim, plan["M"], self._dt
         x = plan["x"]
         dm = plan["dense"][self._block_side(i)]
-        # norm1: by the q|k|v GEMM itself when the previous launch left the bf16 rows of x (the stem or the previous dense block's w3), else its own launch
-        n1_self = self.ln_self_norm1 and self.attn_rot and dm["N"] <= 416 and bool(plan.get("a_is_x")) and "wqkv_ln" in bp
-        if not n1_self:
-            lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
-        self._qkv_attention(P, i, plan, M, dm.get("rc"), dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None, dm["N"], dm["nW"], dm["max_count"], bp["v_bias"],
-                            norm1_self=n1_self)
+        lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
+        self._qkv_attention(P, i, plan, M, dm.get("rc"), dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None, dm["N"], dm["nW"], dm["max_count"], bp["v_bias"])
         self._proj(bp, plan, M, x, None, None)
-        nxt = i + 1 < self.depth and not self._accelerated(i + 1) and "wqkv_ln" in P["blocks"][i + 1]
-        nxt = nxt and self.ln_self_norm1 and self.attn_rot and plan["dense"][self._block_side(i + 1)]["N"] <= 416
-        self._mlp(bp, plan, M, x, None, None, copy_out=nxt)
-        plan["a_is_x"] = bool(nxt)
+        self._mlp(bp, plan, M, x, None, None)
 
     # -- view groups: independent views processed concurrently on separate HIP streams ----------
     def _group_layout(self, V, B):
@@ -779,7 +722,7 @@ class EVA_ViT(_BackboneBase):
                                       "are dead code for the shipped configs and not built")
         self._setup_common(img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, use_abs_pos,
                            pt_hw_seq_len, window_size, global_window_size, global_attn_indexes, pretrain_img_size,
-                           pretrain_use_cls_token, out_feature, precision, unused.get("img_norm_cfg"), unused.get("pad_size_divisor", 32))
+                           pretrain_use_cls_token, out_feature, precision, unused.get("img_norm_cfg"), unused.get("pad_size_divisor", 32), unused.get("schedule"))
         self.blocks = nn.ModuleList([
             _Block(embed_dim, mlp_ratio, qkv_bias, partial(nn.LayerNorm, eps=1e-6),
                    self.rope_glb if i in self.global_attn_indexes else self.rope_win) for i in range(depth)])
@@ -864,7 +807,7 @@ class ToC3DEVAViT(_BackboneBase):
                                       "(toc3d_eva_vit.py:463); use EVA_ViT for the dense baseline")
         self._setup_common(img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_ratio, qkv_bias, use_abs_pos,
                            pt_hw_seq_len, window_size, global_window_size, global_attn_indexes, pretrain_img_size,
-                           pretrain_use_cls_token, out_feature, precision, unused.get("img_norm_cfg"), unused.get("pad_size_divisor", 32))
+                           pretrain_use_cls_token, out_feature, precision, unused.get("img_norm_cfg"), unused.get("pad_size_divisor", 32), unused.get("schedule"))
         self.pruning_loc = pruning_loc
         self.pruning_num_queries = pruning_num_queries
         self.pruning_attn_scale = pruning_attn_scale
@@ -987,7 +930,6 @@ class ToC3DEVAViT(_BackboneBase):
         f32 = dict(dtype=torch.float32, device=dev)
         plan["B"] = B
         plan["slow"] = torch.empty(max_rows, C, **f32)
-        plan["slow2"] = torch.empty(max_rows, C, **f32) if self.fuse_scatter else None      # the compact rows of a block whose scatter is pending are read while the next block's are written
         plan["rep1"] = torch.empty(max_nw, C, **f32)
         plan["rep2"] = torch.empty(max_nw, C, **f32)
         plan["rep3"] = torch.empty(max_nw, C, **f32)          # second block of a carried pair (carry_compact)
@@ -1000,7 +942,7 @@ class ToC3DEVAViT(_BackboneBase):
                                     prow=torch.empty(nW, N, **i32), crow_tok=torch.empty(ms, **i32), rep_index=torch.empty(ms, **i32),
                                     rep_row=torch.empty(nW, **i32), arows=torch.empty(nW, k + 1, **i32),
                                     aslots=torch.empty(nW, k + 1, **i32), acount_q=torch.empty(nW, **i32), acount_k=torch.empty(nW, **i32),
-                                    crow_rc=torch.zeros(ms, **i32), inv=torch.empty(M, **i32) if self.fuse_scatter else None)
+                                    crow_rc=torch.zeros(ms, **i32))
         ns = len(self.pruning_loc)
         plan["pred"] = [torch.empty(M, 2, **f32) for _ in range(ns)]
         plan["u1"] = plan["u2"] = None                    # first-frame scorer scratch, allocated on demand
@@ -1096,8 +1038,6 @@ class ToC3DEVAViT(_BackboneBase):
             sel = plan["sel"][(st, L)]
             lib.call("toc3d_window_topk", score, V, plan["h"], plan["w"], L, sel["k"], sel["order"], sel["tok"], sel["wgt"], sel["prow"],
                      sel["crow_tok"], sel["rep_index"], sel["rep_row"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], sel["crow_rc"], lib.stream_ptr())
-            if sel["inv"] is not None:                    # token -> slot of this selection, for a scatter folded into the next block's gather
-                lib.call("toc3d_token_inverse_map", sel["tok"], sel["prow"], sel["nW"], sel["N"], sel["k"], sel["inv"], lib.stream_ptr())
         # image-level keep/drop lists are only returned to the caller (vis / loss): rank them beside the blocks
         # ... and so is the selection for the window type the next block does not use (first needed two blocks later)
         first = self._block_side(self.pruning_loc[st])
@@ -1144,32 +1084,18 @@ class ToC3DEVAViT(_BackboneBase):
         s = lib.stream_ptr()
         bp = P["blocks"][i]
         C, dt = self.embed_dim, self._dt
-        plan["a_is_x"] = False                            # plan["a"] holds compact rows from here on
         if plan.get("side_L") == self._block_side(i):     # this window type's selection was computed on the side lane
             self._join_side(ex, lane, side, plan)
             plan["side_L"] = None
         sel = plan["sel"][(st, self._block_side(i))]
         nW, N, k, rows = sel["nW"], sel["N"], sel["k"], sel["rows"]
-        slow = plan.get("slow_cur")
-        slow = plan["slow"] if slow is None else slow
-        pend = plan.get("pending")
+        slow = plan["slow"]
         if carry_in:
-            assert pend is None
             lib.call("toc3d_rebase_layernorm_rows", dt, slow, C, sel["rep_index"], sel["tok"], sel["wgt"], N, k, plan["rep1"], plan["rep2"],
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, rows, s)
-        elif pend is not None:
-            # the previous block did not scatter: its update of x is applied by this gather (same values, same order of additions), into the other
-            # compact buffer because the previous block's rows are read while this block's are written
-            slow = plan["slow2"] if pend["slow"] is plan["slow"] else plan["slow"]
-            ps = pend["sel"]
-            lib.call("toc3d_gather_merge_ln_pending", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
-                     bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1,
-                     ps["inv"], pend["slow"], plan["rep1"], plan["rep2"], plan["rep3"] if pend["four"] else None, plan["rep4"] if pend["four"] else None, s)
-            plan["pending"] = None
         else:
             lib.call("toc3d_gather_merge_ln_ex", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1, s)
-        plan["slow_cur"] = slow
         rot = self.attn_rot and k + 1 <= 416
         self._qkv_attention(P, i, plan, rows, sel["crow_rc"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], None,
                             bp["pad_rot"] if rot else bp["pad_qkv"], k + 1, nW, sel["max_q"], None)
@@ -1180,15 +1106,8 @@ class ToC3DEVAViT(_BackboneBase):
             self._proj(bp, plan, rows, slow, ra, sel["rep_index"])
         self._mlp(bp, plan, rows, slow, rb, sel["rep_index"])
         if not carry_out:
-            # the next block gathers right away (accelerated, no scorer stage reading x in between): it applies this scatter itself
-            nxt = i + 1
-            fuse = (self.fuse_scatter and not self._instrumented and sel["inv"] is not None and nxt < self.depth and self._accelerated(nxt)
-                    and nxt not in self.pruning_loc)
-            if fuse:
-                plan["pending"] = dict(sel=sel, slow=slow, four=bool(carry_in))
-            else:
-                lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"],
-                         plan["rep3"] if carry_in else None, plan["rep4"] if carry_in else None, s)
+            lib.call("toc3d_scatter_update", plan["x"], C, sel["tok"], sel["prow"], nW, N, k, slow, plan["rep1"], plan["rep2"],
+                     plan["rep3"] if carry_in else None, plan["rep4"] if carry_in else None, s)
 
     def _carries(self, i):
         """Block i may hand its compact rows to block i + 1 (same stage, same window type, both accelerated)."""
@@ -1258,8 +1177,8 @@ class ToC3DEVAViT(_BackboneBase):
 
         # ---- the frame: lanes 0..G-1 = view groups, G..2G-1 = their side lanes, 2G = query-side scorer prep -----------------------
         prep_lane = 2 * G
-        # TOC3D_SIDE_LANES=0 (experiment): the scorer's query preparation and the rankings run on the block chain's own lane instead of beside it
-        serial = os.environ.get("TOC3D_SIDE_LANES", "1") == "0"
+        # side_lanes=False (A/B switch): the scorer's query preparation and the rankings run on the block chain's own lane instead of beside it
+        serial = not self.side_lanes
         side_of = (lambda g: g) if serial else (lambda g: G + g)
         if serial:
             prep_lane = 0
@@ -1267,7 +1186,6 @@ class ToC3DEVAViT(_BackboneBase):
         def frame(ex):
             for gp in groups:
                 gp["side_pending"], gp["side_L"] = False, None
-                gp["pending"], gp["slow_cur"] = None, None
             if draw:
                 # part of the recorded frame: the frame counter lives in device memory, so every replay draws fresh noise (one launch for all stages)
                 lib.call("toc3d_gumbel_noise", sg["gumbel_all"], sg["gumbel_all"].numel(), self.gumbel_seed, sg["rng"], lib.stream_ptr())

@@ -31,8 +31,10 @@ int launch_gemm(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_
     switch (epi) {
         case TOC3D_EPI_BIAS: case TOC3D_EPI_GELU: case TOC3D_EPI_CONV3X3: return toc3d_gemm_launch_plain(is_bf16, epi, variant, a, s);
         case TOC3D_EPI_RESIDUAL: case TOC3D_EPI_RESIDUAL_LN: case TOC3D_EPI_RESIDUAL_STATS: return toc3d_gemm_launch_residual(is_bf16, epi, variant, a, s);
+#ifdef TOC3D_EXPERIMENTAL
         case TOC3D_EPI_RESIDUAL_ACT: case TOC3D_EPI_SWIGLU_LNSELF: case TOC3D_EPI_RESIDUAL_LNSELF: case TOC3D_EPI_QKV_ROPE_LNSELF:
             return is_bf16 ? toc3d_gemm_launch_lnself(epi, variant, a, s) : TOC3D_ERR_ARG;
+#endif
         case TOC3D_EPI_SWIGLU: case TOC3D_EPI_SWIGLU_STATS: case TOC3D_EPI_SWIGLU_STATS_LN: return toc3d_gemm_launch_swiglu(is_bf16, epi, variant, a, s);
         case TOC3D_EPI_QKV_ROPE: return toc3d_gemm_launch_rope(is_bf16, epi, variant, a, s);
         default: return TOC3D_ERR_ARG;
@@ -331,6 +333,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     return TOC3D_OK;
 }
 
+#ifdef TOC3D_EXPERIMENTAL
 int toc3d_linear_chain(int dtype, int config, int64_t n_ops, const toc3d_chain_op_t* ops, const int32_t* schedule, int64_t n_bands, void* state,
                        int64_t grid, int64_t flags, toc3d_stream_t stream) {
     TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear_chain: bf16 only");
@@ -379,6 +382,7 @@ int toc3d_linear_chain_info(int config, int32_t* info) {
     TOC3D_REQUIRE(info, "toc3d_linear_chain_info: null buffer");
     return toc3d_gemm_chain_info(config, info);
 }
+#endif  // TOC3D_EXPERIMENTAL
 
 int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const void* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
                        int64_t V, int64_t h, int64_t w, int64_t Cout, const void* zeros, toc3d_stream_t stream) {
@@ -411,6 +415,7 @@ int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, co
     return TOC3D_OK;
 }
 
+#ifdef TOC3D_EXPERIMENTAL
 int toc3d_linear_qkv_rope_ln(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
                              int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
                              float q_scale, const float* col_sums, int64_t ln_n, float ln_eps, toc3d_stream_t stream) {
@@ -433,6 +438,7 @@ int toc3d_linear_qkv_rope_ln(int dtype, int variant, const void* A, int64_t lda,
     TOC3D_LAUNCH_CHECK("toc3d_linear_qkv_rope_ln");
     return TOC3D_OK;
 }
+#endif  // TOC3D_EXPERIMENTAL
 
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                     void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,

@@ -181,7 +181,8 @@ TOC3D_DEV void block32_to_tiles16(const f32x16& c, f32x4& t00, f32x4& t01, f32x4
     for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const unsigned a = __builtin_bit_cast(unsigned, c[(2 * j2) * 4 + e]), b = __builtin_bit_cast(unsigned, c[(2 * j2 + 1) * 4 + e]);
+            const float fa = c[(2 * j2) * 4 + e], fb = c[(2 * j2 + 1) * 4 + e];      // (a bit_cast of the vector-element expression itself reads element 0)
+            const unsigned a = __builtin_bit_cast(unsigned, fa), b = __builtin_bit_cast(unsigned, fb);
             const auto s1 = __builtin_amdgcn_permlane32_swap(a, b, false, false);
             const auto s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
             const float lo = __builtin_bit_cast(float, (unsigned)s2[0]), hi = __builtin_bit_cast(float, (unsigned)s2[1]);
@@ -1194,65 +1195,92 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
     }
     switch (variant) {
         case 1: launch_cfg<T, EPI, 128, 128, 2>(a, s); break;
+#ifdef TOC3D_EXPERIMENTAL
         case 2: launch_cfg<T, EPI, 128, 128, 3>(a, s); break;
         case 3: launch_cfg<T, EPI, 128, 128, 4>(a, s); break;
         case 4: launch_cfg<T, EPI, 128, 64, 3>(a, s); break;
         case 5: launch_cfg<T, EPI, 128, 64, 4>(a, s); break;
         case 6: launch_cfg<T, EPI, 64, 128, 3>(a, s); break;
         case 7: launch_cfg<T, EPI, 64, 64, 4>(a, s); break;
+#endif
         case 8: launch_cfg<T, EPI, 128, 128, 1>(a, s); break;
         case 9: launch_cfg<T, EPI, 128, 64, 2>(a, s); break;
         case 10: launch_cfg<T, EPI, 64, 128, 2>(a, s); break;
+#ifdef TOC3D_EXPERIMENTAL
         case 11: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 2, 64>(a, s); else return TOC3D_ERR_ARG; break;
         case 12: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64>(a, s); else return TOC3D_ERR_ARG; break;
+#endif
         case 13: launch_cfg<T, EPI, 128, 64, 1>(a, s); break;
         case 14: launch_cfg<T, EPI, 64, 64, 2>(a, s); break;
         case 15: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 2, 4>(a, s); break;      // v8 forced to <= 128 registers: 4 workgroups / CU
         case 16: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 6 : 1)>(a, s); break;   // 8 waves, 64x32 per wave; bf16 held to 80 registers (6 waves / SIMD = 3 workgroups / CU; the SwiGLU epilogue would take 82)
         case 17: launch_cfg<T, EPI, 128, 128, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, double buffered (64 KiB)
+#ifdef TOC3D_EXPERIMENTAL
         case 18: launch_cfg<T, EPI, 256, 128, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128 tile, double buffered (96 KiB)
+#endif
         case 19: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128, single buffer (48 KiB)
+#ifdef TOC3D_EXPERIMENTAL
         case 20: launch_cfg<T, EPI, 128, 256, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, 128x256 tile, double buffered
         case 21: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves 256x256, 128x128... per-wave 64x128
+#endif
         // big K-tiles for latency-bound launches (about one tile per CU): fewer, fatter load rounds
         case 22: launch_cfg<T, EPI, 128, 128, 1, 256, 2, 4, 1>(a, s); break;      // K-tile 128 bf16, 64 KiB
+#ifdef TOC3D_EXPERIMENTAL
         case 23: launch_cfg<T, EPI, 128, 128, 1, 512, 2, 4, 1>(a, s); break;      // K-tile 256 bf16, 128 KiB
+#endif
         case 24: launch_cfg<T, EPI, 64, 128, 1, 512, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 256, 96 KiB
+#ifdef TOC3D_EXPERIMENTAL
         case 25: launch_cfg<T, EPI, 128, 128, 2, 256, 2, 4, 1>(a, s); break;      // K-tile 128, double buffered, 128 KiB
+#endif
         case 26: launch_cfg<T, EPI, 64, 128, 1, 256, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 128, 48 KiB
         case 27: launch_cfg<T, EPI, 64, 64, 1, 512, 2, 2, 1>(a, s); break;        // 64x64 tile, 4 waves, K-tile 256, 64 KiB
         // deep LDS rings on 8 wavefronts: more bytes continuously in flight per CU (counted vmcnt, one barrier per K-tile)
         case 28: launch_cfg<T, EPI, 128, 128, 3, 128, 2, 4, 1>(a, s); break;      // 96 KiB
         case 29: launch_cfg<T, EPI, 128, 128, 4, 128, 2, 4, 1>(a, s); break;      // 128 KiB
         case 30: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 4, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 64 KiB
+#ifdef TOC3D_EXPERIMENTAL
         case 31: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 6, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 96 KiB
         case 32: launch_cfg<T, EPI, 256, 128, 3, 128, 4, 2, 1>(a, s); break;      // 256x128, 3-deep, 144 KiB
+#endif
         case 33: launch_cfg<T, EPI, 128, 64, 4, 128, 2, 4, 1>(a, s); break;       // 128x64, 4-deep, 96 KiB
         // 16 wavefronts per workgroup: 256-wide tiles (fewer L2->LDS bytes per FLOP) without giving up waves per CU
+#ifdef TOC3D_EXPERIMENTAL
         case 34: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 4, 1>(a, s); break;      // 256x128, 64x32 per wave, 48 KiB
         case 35: launch_cfg<T, EPI, 256, 256, 1, 128, 4, 4, 1>(a, s); break;      // 256x256, 64x64 per wave, 64 KiB
         case 36: launch_cfg<T, EPI, 128, 256, 1, 128, 4, 4, 1>(a, s); break;      // 128x256, 32x64 per wave, 48 KiB
         case 37: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 4, 1>(a, s); break;      // 256x256 double buffered, 128 KiB
+#endif
         // K-tile 32 rings on 8 wavefronts at the LDS footprint of the single-buffer tile: prefetch inside the workgroup without losing occupancy
+#ifdef TOC3D_EXPERIMENTAL
         case 38: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 32 KiB
         case 39: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 48 KiB
         case 40: launch_cfg<T, EPI, 128, 256, 1, 128, 2, 4, 1>(a, s); break;      // 128x256, 64x64 per wave, 48 KiB
         case 41: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 256, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 128x256, K-tile 32 x 2, 48 KiB
         case 42: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 256, 128, 2, 64, 4, 2, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 256x128, K-tile 32 x 2, 48 KiB
+#endif
         // N-tiles that are not powers of two (the vendor library's answer to tile-count quantisation on N = 3072 / 1024)
+#ifdef TOC3D_EXPERIMENTAL
         case 43: launch_cfg<T, EPI, 128, 192, 1, 128, 2, 4, 1>(a, s); break;      // 128x192, 64x48 per wave, 40 KiB
         case 44: launch_cfg<T, EPI, 128, 96, 1, 128, 2, 2, 1>(a, s); break;       // 128x96, 4 waves, 64x48 per wave, 28 KiB
+#endif
         case 45: launch_cfg<T, EPI, 128, 192, 2, 128, 2, 4, 1>(a, s); break;      // 128x192 double buffered, 80 KiB
+#ifdef TOC3D_EXPERIMENTAL
         case 46: launch_cfg<T, EPI, 128, 96, 2, 128, 2, 2, 1>(a, s); break;       // 128x96 double buffered, 56 KiB
+#endif
         case 47: launch_cfg<T, EPI, 128, 192, 2, 128, 4, 2, 1>(a, s); break;      // 128x192 double buffered, 32x96 per wave (serves SwiGLU)
+#ifdef TOC3D_EXPERIMENTAL
         case 48: launch_cfg<T, EPI, 128, 192, 3, 128, 2, 4, 1>(a, s); break;      // 128x192, 3-deep ring, 120 KiB
+#endif
         case 49: launch_cfg<T, EPI, 192, 128, 2, 128, 2, 4, 1>(a, s); break;      // 192x128 double buffered, 96x32 per wave (serves SwiGLU), 80 KiB
+#ifdef TOC3D_EXPERIMENTAL
         case 50: launch_cfg<T, EPI, 192, 128, 1, 128, 2, 4, 1>(a, s); break;      // 192x128 single buffer, 40 KiB
+#endif
         // (the rotating q|k|v epilogue is held to 128 registers -- two workgroups per CU like the other epilogues: unconstrained it took 138, ONE workgroup per CU and 83 instead of 51 us at M = 6000)
         case 52: launch_cfg<T, EPI, 192, 192, 1, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 single buffer, 96x48 per wave, 48 KiB: 512 tiles for q|k|v at M = 6000 (one per slot at two per CU)
         case 53: launch_cfg<T, EPI, 192, 192, 2, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 double buffered, 96 KiB
         case 51: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 8 : 1)>(a, s); break;   // variant 16 held to 64 registers (bf16): FOUR workgroups per CU -- the loop is bound by operand bytes in flight per CU
-        // 32x32x16 MFMA form of the K loop (bf16 only; round 4): per-wave tiles of whole 32x32 blocks, own LDS swizzle, same epilogues (the accumulators are
+#ifdef TOC3D_EXPERIMENTAL
+        // 32x32x16 MFMA form of the K loop (bf16 only; round 4; correct and NOT faster, profiles/r04_mfma32_variants.txt: experimental builds only): per-wave tiles of whole 32x32 blocks, own LDS swizzle, same epilogues (the accumulators are
         // permuted into the 16x16 C^T layout first).  NOT bit-identical with the 16x16x32 variants: the matrix core sums 16 instead of 32 products per step.
 #define TOC3D_MF32(BM_, BN_, ST_, RB_, WM_, WN_, OCC_)                                                                              \
         if constexpr (sizeof(T) == 2 && !epi_ln_self(EPI)) launch_cfg<bf16_t, EPI, BM_, BN_, ST_, RB_, WM_, WN_, OCC_, 32>(a, s); \
@@ -1273,10 +1301,13 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 82: TOC3D_MF32(64, 128, 2, 128, 2, 2, 1);       // 64x128, 4 waves, 32x64 per wave, double buffered
         case 83: TOC3D_MF32(128, 64, 2, 128, 2, 2, 1);       // 128x64, 4 waves, 64x32 per wave, double buffered
 #undef TOC3D_MF32
+#endif  // TOC3D_EXPERIMENTAL
         // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
         case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB
+#ifdef TOC3D_EXPERIMENTAL
         case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
         case 62: if (sizeof(T) == 2) launch_phased<EPI, 128, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
+#endif
         case 63: if (sizeof(T) == 2) launch_phased<EPI, 128, 128, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x32 per wave, 64 KiB: two per CU
         default: return TOC3D_ERR_ARG;
     }

@@ -715,8 +715,13 @@ static int launch_gather(int dtype, const float* x, int64_t C, const int32_t* to
         toc3d_launch((gather_merge_ln_kernel<T, 4, P>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, \
                      gamma, beta, eps, shortcut, (T*)a_out, lda, (int)(kept_copy != 0), pd);                                        \
     } while (0)
-    if (dtype == TOC3D_BF16) { if (pd.inv) TOC3D_GATHER(bf16_t, true); else TOC3D_GATHER(bf16_t, false); }
-    else if (dtype == TOC3D_F32) { if (pd.inv) TOC3D_GATHER(float, true); else TOC3D_GATHER(float, false); }
+#ifdef TOC3D_EXPERIMENTAL
+    if (pd.inv && dtype == TOC3D_BF16) TOC3D_GATHER(bf16_t, true);
+    else if (pd.inv && dtype == TOC3D_F32) TOC3D_GATHER(float, true);
+    else
+#endif
+    if (dtype == TOC3D_BF16) TOC3D_GATHER(bf16_t, false);
+    else if (dtype == TOC3D_F32) TOC3D_GATHER(float, false);
     else { toc3d_set_error("toc3d_gather_merge_ln: bad dtype"); return TOC3D_ERR_ARG; }
 #undef TOC3D_GATHER
     TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln");
@@ -737,6 +742,7 @@ int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t
     return launch_gather(dtype, x, C, tok, wgt, crow_tok, rep_row, nW, N, k, rows, gamma, beta, eps, shortcut, a_out, lda, kept_copy, PendingScatter{}, stream);
 }
 
+#ifdef TOC3D_EXPERIMENTAL
 int toc3d_gather_merge_ln_pending(int dtype, float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                                   const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
                                   const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy,
@@ -760,6 +766,7 @@ int toc3d_token_inverse_map(const int32_t* tok, const int32_t* prow, int64_t nW,
     TOC3D_LAUNCH_CHECK("toc3d_token_inverse_map");
     return TOC3D_OK;
 }
+#endif  // TOC3D_EXPERIMENTAL
 
 int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                           const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
@@ -809,6 +816,7 @@ int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t 
     return TOC3D_OK;
 }
 
+#ifdef TOC3D_EXPERIMENTAL
 int toc3d_prefetch(int64_t n, const void* const* ptrs, const int64_t* nbytes, int64_t workgroups, toc3d_stream_t stream) {
     TOC3D_REQUIRE(n >= 0 && n <= PREFETCH_MAX_SEGS && (n == 0 || (ptrs && nbytes)), "toc3d_prefetch: 0 <= n <= %d buffers, host arrays of n entries", PREFETCH_MAX_SEGS);
     if (n == 0) return TOC3D_OK;
@@ -824,6 +832,7 @@ int toc3d_prefetch(int64_t n, const void* const* ptrs, const int64_t* nbytes, in
     TOC3D_LAUNCH_CHECK("toc3d_prefetch");
     return TOC3D_OK;
 }
+#endif  // TOC3D_EXPERIMENTAL
 
 int toc3d_copy_segments(int64_t n, void* const* dst, const void* const* src, const int64_t* nbytes, toc3d_stream_t stream) {
     TOC3D_REQUIRE(n >= 0 && n <= COPY_MAX_SEGS && (n == 0 || (dst && src && nbytes)), "toc3d_copy_segments: 0 <= n <= %d segments, host arrays of n entries", COPY_MAX_SEGS);

@@ -14,11 +14,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so"))       # TOC3D_LIB: an experimental build beside the shipped one
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
-ABI_VERSION = 4                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
+ABI_VERSION = 5                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
 F32, BF16, F32X3, F32X6 = 0, 1, 2, 3          # F32X3: linear layers only -- f32 buffers, products as three bf16 MFMAs (include/toc3d.h)
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF = 10, 11, 12, 13
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
+# GEMM tile variants (mod 100; + 100 / 200 / 300 select the XCD order at run time) the product library carries: every variant the autotuner may pick or a
+# shipped table names.  EXPERIMENTAL=1 builds add the rest (csrc/gemm_kernels.h launch_epi).
+PRODUCT_VARIANTS = (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 60, 63)
+
+
+def has_variant(v: int) -> bool:
+    return experimental() or (v % 100) in PRODUCT_VARIANTS
 
 _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
@@ -27,8 +34,6 @@ _SIGS = {
     "toc3d_linear": "iiplplpplpllppllllp",
     "toc3d_linear_ex": "iiiplplpplpllppllllp",
     "toc3d_linear_fused": "iiiplplpplpllppllll" + "plplplf" + "pl" + "p" + "p",
-    "toc3d_linear_chain": "iilpplpllp",
-    "toc3d_linear_chain_trace": "pl",
     "toc3d_pack_swiglu_lnfold": "ippppppllpppllp",
     "toc3d_pack_weight_lnfold": "ippppllpllppp",
     "toc3d_conv3x3_nhwc": "iiplplpplllllpp",
@@ -46,13 +51,10 @@ _SIGS = {
     "toc3d_rank_desc": "pllpp",
     "toc3d_window_topk": "plllllppppppppppppp",
     "toc3d_linear_qkv_rope": "iiplplppllllpplfp",
-    "toc3d_linear_qkv_rope_ln": "iiplplppllllpplfplfp",
     "toc3d_window_attention_rot": "iplplppppppllllp" + "lppl" + "p",
     "toc3d_gather_merge_ln": "iplppppllllppfpplp",
     "toc3d_gather_merge_ln_ex": "iplppppllllppfppllp",
     "toc3d_scatter_update": "plpplllpppppp",
-    "toc3d_gather_merge_ln_pending": "iplppppllllppfppll" + "pppppp" + "p",
-    "toc3d_token_inverse_map": "pplllpp",
     "toc3d_rebase_layernorm_rows": "iplpppllppppfpllp",
     "toc3d_pack_motion_weights": "p" * 24 + "p",
     "toc3d_motion_queries": "pllppppippllpp",
@@ -74,7 +76,6 @@ _SIGS = {
     "toc3d_memory_post_update": "ppppppppppppplpppllllllp",
     "toc3d_copy_bytes": "pplp",
     "toc3d_copy_segments": "lpppp",
-    "toc3d_prefetch": "lpplp",
     "toc3d_plan_create": "p",
     "toc3d_plan_destroy": "p",
     "toc3d_plan_begin": "p",
@@ -82,16 +83,39 @@ _SIGS = {
     "toc3d_plan_end": "pi",
     "toc3d_plan_run": "pp",
 }
+# entry points that exist only in `make EXPERIMENTAL=1` builds (include/toc3d.h, #ifdef TOC3D_EXPERIMENTAL): bound when the loaded library has them
+_SIGS_EXPERIMENTAL = {
+    "toc3d_linear_chain": "iilpplpllp",
+    "toc3d_linear_chain_trace": "pl",
+    "toc3d_linear_qkv_rope_ln": "iiplplppllllpplfplfp",
+    "toc3d_gather_merge_ln_pending": "iplppppllllppfppll" + "pppppp" + "p",
+    "toc3d_token_inverse_map": "pplllpp",
+    "toc3d_prefetch": "lpplp",
+}
 _CT = {"p": _P, "l": _I64, "i": _I, "f": _F, "L": ctypes.c_uint64}
 
 _lib = None
 
 
-def header_functions():
-    """Names of all functions declared in include/toc3d.h (used by the symbol-export test)."""
+def header_text(experimental: bool) -> str:
+    """include/toc3d.h without comments; the `#ifdef TOC3D_EXPERIMENTAL` blocks kept only when ``experimental``."""
     txt = open(HEADER_PATH).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(toc3d_\w+)\s*\(", txt)))
+    if not experimental:
+        txt = re.sub(r"#ifdef TOC3D_EXPERIMENTAL.*?#endif", "", txt, flags=re.S)
+    return txt
+
+
+def header_functions(experimental: bool = None):
+    """Names of all functions declared in include/toc3d.h for this build flavour (used by the symbol-export test)."""
+    if experimental is None:
+        experimental = globals()["experimental"]()
+    return sorted(set(re.findall(r"\b(toc3d_\w+)\s*\(", header_text(experimental))))
+
+
+def experimental() -> bool:
+    """The loaded library is an EXPERIMENTAL=1 build (it exports the entry points of the `#ifdef TOC3D_EXPERIMENTAL` blocks)."""
+    return hasattr(load(), "toc3d_linear_chain")
 
 
 def load():
@@ -121,9 +145,10 @@ def load():
     lib.toc3d_plan_lane_stream.argtypes = [_I64]
     lib.toc3d_plan_num_launches.restype = _I64
     lib.toc3d_plan_num_launches.argtypes = [_P]
-    lib.toc3d_linear_chain_info.restype = _I            # number of ops (< 0: unknown config), not an error code
-    lib.toc3d_linear_chain_info.argtypes = [_I, _P]
-    for name, sig in _SIGS.items():
+    if hasattr(lib, "toc3d_linear_chain_info"):
+        lib.toc3d_linear_chain_info.restype = _I        # number of ops (< 0: unknown config), not an error code
+        lib.toc3d_linear_chain_info.argtypes = [_I, _P]
+    for name, sig in list(_SIGS.items()) + [(n, s_) for n, s_ in _SIGS_EXPERIMENTAL.items() if hasattr(lib, n)]:
         fn = getattr(lib, name)
         fn.restype = _I
         fn.argtypes = [_CT[c] for c in sig]
@@ -195,7 +220,7 @@ def recording() -> bool:
     return rec_lane() is not None
 
 
-# ---- GEMM chains (include/toc3d.h, toc3d_linear_chain) ---------------------------------------------------------------------
+# ---- GEMM chains (include/toc3d.h, toc3d_linear_chain; EXPERIMENTAL builds only) ---------------------------------------------------------------------
 CHAIN_STATE_BYTES = 3616
 CHAIN_MAX_BANDS, CHAIN_MAX_MT = 64, 256
 
@@ -283,3 +308,9 @@ def chain_schedule(config, M, Ns, n_bands=8, lag=1, n_major=()):
 def linear_chain(dtype, config, ops, schedule, n_bands, state, grid, flags, stream):
     arr = (ChainOp * len(ops))(*ops)
     call("toc3d_linear_chain", dtype, config, len(ops), ctypes.addressof(arr), schedule, n_bands, state, grid, flags, stream)
+
+
+def chain_status(state) -> int:
+    """Sticky error word of a chain state buffer (0: every bounded wait of every launch so far was satisfied; 1: a wait gave up -- the outputs of that
+    launch are WRONG, not late; 2: bad schedule entry).  The launch itself returns TOC3D_OK in all cases: callers poll this at their sync points."""
+    return int(state.view(-1).view(__import__("torch").int32)[1].item())

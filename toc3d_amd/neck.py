@@ -12,7 +12,6 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-import os
 
 from . import lib
 from .backbone import _round_up, tuned_linear
@@ -49,7 +48,7 @@ class CPFPN(nn.Module):
         self._tuned = {}                # (epilogue, M, N, K) -> GEMM tile variant (toc3d_amd.backbone.tuned_linear); bench.py shares the backbone's table
         self.autotune = True
         self.alias_outputs = False      # True: the returned level-0 tensor is the reused workspace (benchmarks, fused pipelines)
-        self.launch_mode = os.environ.get("TOC3D_LAUNCH", "plan")       # see toc3d_amd/plan.py
+        self.launch_mode = unused.get("launch_mode", "plan")            # see toc3d_amd/plan.py
         assert self.launch_mode in MODES
         self._stream_pool = []
 

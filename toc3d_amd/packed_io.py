@@ -65,7 +65,6 @@ def fingerprint(model) -> Dict[str, Any]:
               rope_sides=[int(model.rope_win.freqs_cos.shape[0]), int(model.rope_glb.freqs_cos.shape[0])],
               fold_ffn_ln=bool(getattr(model, "fold_ffn_ln", False)),      # w3 packed gamma-scaled + c1 / c2 instead of w3 / b3
               fold_norm2=bool(getattr(model, "fold_norm2", False)),        # w12 packed gamma2-scaled + c1_12 / c2_12
-              ln_self=int(bool(getattr(model, "ln_self", False))) + int(bool(getattr(model, "ln_self_norm1", False))),              # the same packing, plus gamma1-scaled q|k|v of the dense blocks
               attn_rot=bool(getattr(model, "attn_rot", False)),            # compact RoPE tables + per-slot rotated pad rows (pad_rot)
               abi=int(lib.load().toc3d_abi_version()))
     for k in ("pruning_loc", "token_ratio", "pruning_num_queries", "accelerate_global", "pruning_attn_scale"):
