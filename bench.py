@@ -162,9 +162,9 @@ def hbm_bytes(name, a, ctx):
     if name == "toc3d_rebase_layernorm_rows":
         C, rows = a[2], a[15]
         return rows * C * (4 + esz(a[0]))
-    if name in ("toc3d_gather_merge_ln_ex", "toc3d_gather_merge_ln"):
+    if name in ("toc3d_gather_merge_ln_ex", "toc3d_gather_merge_ln", "toc3d_gather_merge_ln_split"):
         C, nW, rows = a[2], a[7], a[10]
-        kept_copy = a[17] if name.endswith("_ex") else 1
+        kept_copy = 1 if name == "toc3d_gather_merge_ln" else a[17]
         # every real token is read once (kept: copied, dropped: merged); kept rows leave in the act dtype (+ the f32 copy when asked for),
         # representative rows in both
         return ctx["tokens"] * C * 4 + rows * C * esz(a[0]) + (rows if kept_copy else nW) * C * 4

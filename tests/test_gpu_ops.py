@@ -368,6 +368,26 @@ def test_gather_merge_ln_and_scatter(name, dt, tdt, C, L, ratio):
         pos_i = torch.cat([kept, torch.tensor([k])])
         assert relerr(short[rows_i], ref_short[i, pos_i]) < 1e-5
         assert relerr(a[rows_i].float(), ref_ln[i, pos_i]) < (2e-5 if dt == lib.F32 else 5e-3)
+    # the split merge (4 workgroups per window, partials through device memory, last arriver adds them in the single-workgroup kernel's order): the
+    # same bits, launch after launch on one scratch buffer (the kernel re-arms its arrival counters), with and without the f32 copy of the kept rows
+    nbytes = int(lib.load().toc3d_gather_merge_ln_scratch_bytes(nW, C))
+    assert nbytes >= nW * 16 * C * 4 + nW * 4 and nbytes % 256 == 0
+    scratch = torch.zeros(nbytes // 4, device=DEV)
+    for kept_copy in (1, 0, 1):
+        one_s, one_a = torch.full((ms, C), 7.0, device=DEV), torch.zeros(ms, C, dtype=tdt, device=DEV)
+        lib.call("toc3d_gather_merge_ln_ex", dt, xd, C, b["tok"], b["wgt"], b["crow_tok"], b["rep_row"], nW, N, k, ms, gw.to(DEV), gb.to(DEV), 1e-6,
+                 one_s, one_a, C, kept_copy, S())
+        for rep_i in range(3):
+            sp_s, sp_a = torch.full((ms, C), 7.0, device=DEV), torch.zeros(ms, C, dtype=tdt, device=DEV)
+            lib.call("toc3d_gather_merge_ln_split", dt, xd, C, b["tok"], b["wgt"], b["crow_tok"], b["rep_row"], nW, N, k, ms, gw.to(DEV), gb.to(DEV), 1e-6,
+                     sp_s, sp_a, C, kept_copy, scratch, nbytes, S())
+            assert torch.equal(sp_s, one_s) and torch.equal(sp_a.view(torch.uint8), one_a.view(torch.uint8)), (kept_copy, rep_i)
+        assert int(scratch[:nW].view(torch.int32).abs().sum().item()) == 0, "arrival counters re-armed"
+        if kept_copy:
+            assert torch.equal(one_s, short) and torch.equal(one_a, a)
+    with pytest.raises(RuntimeError, match="scratch"):
+        lib.call("toc3d_gather_merge_ln_split", dt, xd, C, b["tok"], b["wgt"], b["crow_tok"], b["rep_row"], nW, N, k, ms, gw.to(DEV), gb.to(DEV), 1e-6,
+                 sp_s, sp_a, C, 1, scratch, nbytes - 256, S())
     # scatter: kept rows replaced, dropped rows += r1 + r2, pads dropped (toc3d_eva_vit.py:449-467)
     slow_c = torch.randn(ms, C, generator=g)
     slow_out = torch.zeros(nW, k + 1, C)

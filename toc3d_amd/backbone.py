@@ -183,6 +183,7 @@ def schedule_defaults(precision):
         gathered_residual=True,      # the gather skips the f32 copy of the kept rows; the projection GEMM reads their residual from x through crow_tok
         prefetch_weights=192 if bf16 else 0,   # workgroups of each attention launch that pull the next GEMMs' weights towards the chip (0 = off)
         attn_rot=bf16,               # RoPE + q scale in the q|k|v GEMM epilogue, attention on the pre-rotated buffer with K / V staged by DMA
+        gather_split=True,           # every window's merge_tokens cut over 4 workgroups (toc3d_gather_merge_ln_split; same bits as the single-workgroup form)
         side_lanes=True,             # scorer query prep and rankings on lanes beside the block chain (False: on the chain's own lane)
         big_windows_first=True,      # dense attention windows ordered biggest-first in the static window lists
         launch_mode="plan",          # "plan" (recorded launch plan replayed from C), "graph" (explicit hipGraph), "eager"
@@ -934,6 +935,8 @@ class ToC3DEVAViT(_BackboneBase):
         plan["rep2"] = torch.empty(max_nw, C, **f32)
         plan["rep3"] = torch.empty(max_nw, C, **f32)          # second block of a carried pair (carry_compact)
         plan["rep4"] = torch.empty(max_nw, C, **f32)
+        # arrival counters + partial sums of the split merge (zeroed once: the kernel re-arms its counters)
+        plan["gm_scratch"] = torch.zeros(int(lib.load().toc3d_gather_merge_ln_scratch_bytes(max_nw, C)) // 4, **f32)
         plan["sel"] = {}
         for key, (nW, N, k, ms) in sel_geo.items():
             L = key[1]
@@ -1093,6 +1096,10 @@ class ToC3DEVAViT(_BackboneBase):
         if carry_in:
             lib.call("toc3d_rebase_layernorm_rows", dt, slow, C, sel["rep_index"], sel["tok"], sel["wgt"], N, k, plan["rep1"], plan["rep2"],
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, rows, s)
+        elif self.gather_split:
+            lib.call("toc3d_gather_merge_ln_split", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
+                     bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1,
+                     plan["gm_scratch"], plan["gm_scratch"].numel() * 4, s)
         else:
             lib.call("toc3d_gather_merge_ln_ex", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1, s)

@@ -470,6 +470,138 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
     wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// gather + merge + LN1, SPLIT form (round 4).  The single-workgroup merge above is bound by what ONE CU can ingest: a window's dropped rows are
+// up to 128-280 x 4 KB = 0.5-1.1 MB through one CU's ~60 GB/s load path (8-17 us) while the 200+ one-row workgroups finish in 2-3 us.  Here a window's
+// merge is cut over GM_SPLIT = 4 workgroups of 4 wavefronts; wavefront w of slice q IS wavefront 4 q + w of the kernel above (same rows k + wv + 16 j,
+// same order of accumulation), leaves its partial in scratch[win][wv][C], and the slice that arrives last (one agent-scope release per slice, one
+// relaxed ticket, one acquire by the last: cdna_hip_programming.md Guideline 16, counter form) adds the 16 partials in the order wv = 0..15 --
+// the fixed tree of the kernel above -- and normalises: BIT-IDENTICAL to it (tests/test_gpu_ops.py).  The slices of a window are placed on one XCD
+// (blocks b, b + 8, b + 16, b + 24; speed only).  counters: one word per window, zero before the first launch; the last slice re-arms its word.
+// ---------------------------------------------------------------------------------------------------
+constexpr int GM_SPLIT = 4;
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void gather_merge_ln_split_kernel(const float* __restrict__ x, int C, const int32_t* __restrict__ tok,
+                                                                     const float* __restrict__ wgt, const int32_t* __restrict__ crow_tok,
+                                                                     const int32_t* __restrict__ rep_row, int nW, int N, int k, int Ms,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                     float* __restrict__ shortcut, T* __restrict__ a_out, int64_t lda, int kept_copy,
+                                                                     float* __restrict__ partials, unsigned* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) float s_row[];         // [C] + the ticket
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nvec = C >> 2;
+    const int rep_blocks = ((nW + 7) / 8) * 8 * GM_SPLIT;
+    if ((int)blockIdx.x < rep_blocks) {
+        const int b = blockIdx.x;
+        const int win = (b / (8 * GM_SPLIT)) * 8 + (b & 7), q = (b >> 3) % GM_SPLIT;
+        if (win >= nW) return;
+        const int wv = GM_SPLIT * q + wave;              // the wavefront of the single-workgroup kernel this one stands for
+        f32x4 acc[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int mine = (N - k - wv + 15) / 16;
+        int my_src = -1;
+        float my_w = 0.f;
+        if (lane < mine) {
+            my_src = tok[(int64_t)win * N + k + wv + 16 * lane];
+            my_w = wgt[(int64_t)win * N + k + wv + 16 * lane];
+        }
+        constexpr int U = 8;                             // rows in flight per wavefront (the kernel above: 4; the order of the additions is the same)
+        for (int j0 = 0; j0 < mine; j0 += U) {
+            int src[U];
+            float wg[U];
+            f32x4 row[U][MAXV];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                src[u] = __shfl(my_src, (j0 + u) & 63, 64);
+                wg[u] = __shfl(my_w, (j0 + u) & 63, 64);
+                if (j0 + u >= mine) { src[u] = -1; wg[u] = 0.f; }
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int vi = lane + 64 * i;
+                    row[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (vi < nvec && src[u] >= 0) row[u][i] = *reinterpret_cast<const f32x4*>(x + (int64_t)src[u] * C + 4 * vi);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j0 + u < mine) {                     // (wave-uniform) rows past the end add nothing -- not even + 0 * 0, which would turn a -0 sum into +0
+#pragma unroll
+                    for (int i = 0; i < MAXV; ++i) acc[i] += wg[u] * row[u][i];
+                }
+        }
+        float* part = partials + ((int64_t)win * 16 + wv) * C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) *reinterpret_cast<f32x4*>(part + 4 * vi) = acc[i];
+        }
+        // publish: every wave's stores acknowledged -> workgroup barrier -> one lane releases at agent scope and takes the window's ticket
+        unsigned* s_ticket = reinterpret_cast<unsigned*>(s_row + C);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the wait behind buffer_wbl2: restated where it cannot)
+            *s_ticket = __hip_atomic_fetch_add(counters + win, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*s_ticket != (unsigned)(GM_SPLIT - 1)) return;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(counters + win, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch (a recorded plan needs no memset)
+        }
+        __syncthreads();
+        const float* pw = partials + (int64_t)win * 16 * C;
+        for (int vi = threadIdx.x; vi < nvec; vi += 256) {
+            f32x4 p16[16];
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) p16[w2] = *reinterpret_cast<const f32x4*>(pw + (int64_t)w2 * C + 4 * vi);
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) sum += p16[w2];           // wv = 0..15 in sequence: the fixed tree of gather_merge_ln_kernel
+            *reinterpret_cast<f32x4*>(s_row + 4 * vi) = sum;
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        f32x4 v[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            v[i] = vi < nvec ? *reinterpret_cast<const f32x4*>(s_row + 4 * vi) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int64_t orow = rep_row[win];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) *reinterpret_cast<f32x4*>(shortcut + orow * C + 4 * vi) = v[i];
+        }
+        float mean, rstd;
+        wave_ln_stats<MAXV>(v, nvec, lane, C, eps, mean, rstd);
+        wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
+        return;
+    }
+    const int64_t orow = (int64_t)(blockIdx.x - rep_blocks) * 4 + wave;
+    if (orow >= Ms) return;
+    const int src = crow_tok[orow];
+    if (src == -2) return;                               // representative row: written by its window's last slice above
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vi < nvec) {
+            if (src >= 0) v[i] = *reinterpret_cast<const f32x4*>(x + (int64_t)src * C + 4 * vi);
+            if (kept_copy || src < 0) *reinterpret_cast<f32x4*>(shortcut + orow * C + 4 * vi) = v[i];
+        }
+    }
+    float mean, rstd;
+    wave_ln_stats<MAXV>(v, nvec, lane, C, eps, mean, rstd);
+    wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
+}
+
 // token -> slot of a selection: inv[token] = compact row (kept) or -(1 + window) (dropped); pad slots (tok < 0) have no token.
 __global__ __launch_bounds__(256) void token_inverse_map_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ prow, int nW, int N, int k,
                                                                 int32_t* __restrict__ inv) {
@@ -740,6 +872,38 @@ int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t
     TOC3D_REQUIRE(N - k <= 1024, "toc3d_gather_merge_ln: N - k = %lld dropped tokens per window exceed the kernel's 1024", (long long)(N - k));
     if (nW <= 0) return TOC3D_OK;
     return launch_gather(dtype, x, C, tok, wgt, crow_tok, rep_row, nW, N, k, rows, gamma, beta, eps, shortcut, a_out, lda, kept_copy, PendingScatter{}, stream);
+}
+
+
+int64_t toc3d_gather_merge_ln_scratch_bytes(int64_t nW, int64_t C) {
+    if (nW <= 0 || C <= 0) return 0;
+    return 256 * ((nW * 4 + 255) / 256) + nW * 16 * C * 4;               // [counters, padded to 256 B][nW][16][C] f32 partials
+}
+
+int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
+                                const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
+                                const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy,
+                                void* scratch, int64_t scratch_bytes, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(x && tok && wgt && crow_tok && rep_row && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln_split: null buffer");
+    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln_split: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
+    TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW && N - k <= 1024, "toc3d_gather_merge_ln_split: bad k / lda / rows");
+    TOC3D_REQUIRE(scratch && ((uintptr_t)scratch % 256) == 0 && scratch_bytes >= toc3d_gather_merge_ln_scratch_bytes(nW, C),
+                  "toc3d_gather_merge_ln_split: scratch of toc3d_gather_merge_ln_scratch_bytes(nW, C) bytes, 256-byte aligned, zeroed once by the caller");
+    if (nW <= 0) return TOC3D_OK;
+    unsigned* counters = reinterpret_cast<unsigned*>(scratch);
+    float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + 256 * ((nW * 4 + 255) / 256));
+    dim3 grid((unsigned)(((nW + 7) / 8) * 8 * GM_SPLIT + (rows + 3) / 4)), block(256);
+    const size_t lds = (size_t)C * 4 + 16;
+    hipStream_t s = as_stream(stream);
+    if (dtype == TOC3D_BF16)
+        toc3d_launch((gather_merge_ln_split_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows,
+                     gamma, beta, eps, shortcut, (bf16_t*)a_out, lda, (int)(kept_copy != 0), partials, counters);
+    else if (dtype == TOC3D_F32)
+        toc3d_launch((gather_merge_ln_split_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows,
+                     gamma, beta, eps, shortcut, (float*)a_out, lda, (int)(kept_copy != 0), partials, counters);
+    else { toc3d_set_error("toc3d_gather_merge_ln_split: bad dtype"); return TOC3D_ERR_ARG; }
+    TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln_split");
+    return TOC3D_OK;
 }
 
 #ifdef TOC3D_EXPERIMENTAL

@@ -54,6 +54,7 @@ _SIGS = {
     "toc3d_window_attention_rot": "iplplppppppllllp" + "lppl" + "p",
     "toc3d_gather_merge_ln": "iplppppllllppfpplp",
     "toc3d_gather_merge_ln_ex": "iplppppllllppfppllp",
+    "toc3d_gather_merge_ln_split": "iplppppllllppfppll" + "pl" + "p",
     "toc3d_scatter_update": "plpplllpppppp",
     "toc3d_rebase_layernorm_rows": "iplpppllppppfpllp",
     "toc3d_pack_motion_weights": "p" * 24 + "p",
@@ -141,6 +142,8 @@ def load():
     lib.toc3d_motion_weights_floats.restype = _I64
     lib.toc3d_window_topk_rows.restype = _I64
     lib.toc3d_window_topk_rows.argtypes = [_I64] * 5
+    lib.toc3d_gather_merge_ln_scratch_bytes.restype = _I64
+    lib.toc3d_gather_merge_ln_scratch_bytes.argtypes = [_I64, _I64]
     lib.toc3d_plan_lane_stream.restype = _P
     lib.toc3d_plan_lane_stream.argtypes = [_I64]
     lib.toc3d_plan_num_launches.restype = _I64
