@@ -362,7 +362,7 @@ int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* t
 int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                              const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
                              const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy, toc3d_stream_t stream);
-/* toc3d_gather_merge_ln_ex with every window's merge cut over 4 workgroups (the single-workgroup merge is bound by what one CU can load: 0.5-1 MB of
+/* toc3d_gather_merge_ln_ex with every window's merge cut over `split` = 2, 4, 8 or 16 workgroups (0 = the default, 4) (the single-workgroup merge is bound by what one CU can load: 0.5-1 MB of
  *   dropped rows per window): same arguments, same results BIT FOR BIT (the partial sums are formed and added in the order of the single-workgroup
  *   kernel), plus `scratch` = toc3d_gather_merge_ln_scratch_bytes(nW, C) bytes of device memory, 256-byte aligned, zeroed ONCE by the caller (arrival
  *   counters + f32 partials; the kernel re-arms the counters itself, so a recorded launch plan replays it without a memset).  One scratch buffer per
@@ -371,7 +371,7 @@ int64_t toc3d_gather_merge_ln_scratch_bytes(int64_t nW, int64_t C);
 int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                                 const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
                                 const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy,
-                                void* scratch, int64_t scratch_bytes, toc3d_stream_t stream);
+                                void* scratch, int64_t scratch_bytes, int64_t split, toc3d_stream_t stream);
 /* toc3d_rebase_layernorm_rows: norm1 (toc3d_eva_vit.py:372) of a block that continues on the previous block's compact rows instead
  *   of re-gathering them (shortcut rows f32 [rows, C], in place; LN -> out act [rows, ldo]).  Representative rows (rep_index[r] = window
  *   i >= 0) are first turned into what merge_tokens (toc3d_utils.py:65-70) would produce from the updated dropped tokens:

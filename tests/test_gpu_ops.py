@@ -380,14 +380,14 @@ def test_gather_merge_ln_and_scatter(name, dt, tdt, C, L, ratio):
         for rep_i in range(3):
             sp_s, sp_a = torch.full((ms, C), 7.0, device=DEV), torch.zeros(ms, C, dtype=tdt, device=DEV)
             lib.call("toc3d_gather_merge_ln_split", dt, xd, C, b["tok"], b["wgt"], b["crow_tok"], b["rep_row"], nW, N, k, ms, gw.to(DEV), gb.to(DEV), 1e-6,
-                     sp_s, sp_a, C, kept_copy, scratch, nbytes, S())
+                     sp_s, sp_a, C, kept_copy, scratch, nbytes, (0, 8, 16)[rep_i], S())
             assert torch.equal(sp_s, one_s) and torch.equal(sp_a.view(torch.uint8), one_a.view(torch.uint8)), (kept_copy, rep_i)
         assert int(scratch[:nW].view(torch.int32).abs().sum().item()) == 0, "arrival counters re-armed"
         if kept_copy:
             assert torch.equal(one_s, short) and torch.equal(one_a, a)
     with pytest.raises(RuntimeError, match="scratch"):
         lib.call("toc3d_gather_merge_ln_split", dt, xd, C, b["tok"], b["wgt"], b["crow_tok"], b["rep_row"], nW, N, k, ms, gw.to(DEV), gb.to(DEV), 1e-6,
-                 sp_s, sp_a, C, 1, scratch, nbytes - 256, S())
+                 sp_s, sp_a, C, 1, scratch, nbytes - 256, 0, S())
     # scatter: kept rows replaced, dropped rows += r1 + r2, pads dropped (toc3d_eva_vit.py:449-467)
     slow_c = torch.randn(ms, C, generator=g)
     slow_out = torch.zeros(nW, k + 1, C)

@@ -183,7 +183,9 @@ def schedule_defaults(precision):
         gathered_residual=True,      # the gather skips the f32 copy of the kept rows; the projection GEMM reads their residual from x through crow_tok
         prefetch_weights=192 if bf16 else 0,   # workgroups of each attention launch that pull the next GEMMs' weights towards the chip (0 = off)
         attn_rot=bf16,               # RoPE + q scale in the q|k|v GEMM epilogue, attention on the pre-rotated buffer with K / V staged by DMA
-        gather_split=True,           # every window's merge_tokens cut over 4 workgroups (toc3d_gather_merge_ln_split; same bits as the single-workgroup form)
+        gather_split=False,          # True / 2 / 8 / 16: every window's merge_tokens cut over 4 / 2 / 8 / 16 workgroups (toc3d_gather_merge_ln_split, same bits as the
+                                     # single-workgroup form).  Round 4, built on the theory that one CU's load path bounds the merge -- measured: the launch is a chain
+                                     # of dependent round trips, not bandwidth (12-17 us either way, profiles/r04_gather_split.txt), +-0.5 % in the frame: off
         side_lanes=True,             # scorer query prep and rankings on lanes beside the block chain (False: on the chain's own lane)
         big_windows_first=True,      # dense attention windows ordered biggest-first in the static window lists
         launch_mode="plan",          # "plan" (recorded launch plan replayed from C), "graph" (explicit hipGraph), "eager"
@@ -1099,7 +1101,7 @@ class ToC3DEVAViT(_BackboneBase):
         elif self.gather_split:
             lib.call("toc3d_gather_merge_ln_split", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1,
-                     plan["gm_scratch"], plan["gm_scratch"].numel() * 4, s)
+                     plan["gm_scratch"], plan["gm_scratch"].numel() * 4, int(self.gather_split) if self.gather_split is not True else 0, s)
         else:
             lib.call("toc3d_gather_merge_ln_ex", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1, s)

@@ -123,6 +123,8 @@ int build_streams(Toc3dPlan* p) {
         if (p->lane_used[l]) nlanes = l + 1;
     for (int l = 1; l < nlanes; ++l) {
         hipStream_t s;
+        // (round 4, measured and not taken: side lanes created with hipStreamCreateWithPriority, lowest or highest -- 207.6 / 205.2 frames/s against 203.5 in
+        // one hardware-queue mapping, 101 / 81 frames/s in another: profiles/r04_stream_priority.txt)
         PLAN_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         p->streams.push_back(s);
         hipEvent_t e;

@@ -474,22 +474,21 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
 // ---------------------------------------------------------------------------------------------------
 // gather + merge + LN1, SPLIT form (round 4).  The single-workgroup merge above is bound by what ONE CU can ingest: a window's dropped rows are
 // up to 128-280 x 4 KB = 0.5-1.1 MB through one CU's ~60 GB/s load path (8-17 us) while the 200+ one-row workgroups finish in 2-3 us.  Here a window's
-// merge is cut over GM_SPLIT = 4 workgroups of 4 wavefronts; wavefront w of slice q IS wavefront 4 q + w of the kernel above (same rows k + wv + 16 j,
+// merge is cut over GM_SPLIT (2 ... 16, default 4) workgroups of 16 / GM_SPLIT wavefronts; wavefront w of slice q IS wavefront (16 / GM_SPLIT) q + w of the kernel above (same rows k + wv + 16 j,
 // same order of accumulation), leaves its partial in scratch[win][wv][C], and the slice that arrives last (one agent-scope release per slice, one
 // relaxed ticket, one acquire by the last: cdna_hip_programming.md Guideline 16, counter form) adds the 16 partials in the order wv = 0..15 --
 // the fixed tree of the kernel above -- and normalises: BIT-IDENTICAL to it (tests/test_gpu_ops.py).  The slices of a window are placed on one XCD
-// (blocks b, b + 8, b + 16, b + 24; speed only).  counters: one word per window, zero before the first launch; the last slice re-arms its word.
+// (blocks b, b + 8, b + 16, ...; speed only).  counters: one word per window, zero before the first launch; the last slice re-arms its word.
 // ---------------------------------------------------------------------------------------------------
-constexpr int GM_SPLIT = 4;
-
-template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void gather_merge_ln_split_kernel(const float* __restrict__ x, int C, const int32_t* __restrict__ tok,
+template <typename T, int MAXV, int GM_SPLIT>
+__global__ __launch_bounds__(1024 / GM_SPLIT) void gather_merge_ln_split_kernel(const float* __restrict__ x, int C, const int32_t* __restrict__ tok,
                                                                      const float* __restrict__ wgt, const int32_t* __restrict__ crow_tok,
                                                                      const int32_t* __restrict__ rep_row, int nW, int N, int k, int Ms,
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                      float* __restrict__ shortcut, T* __restrict__ a_out, int64_t lda, int kept_copy,
                                                                      float* __restrict__ partials, unsigned* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float s_row[];         // [C] + the ticket
+    constexpr int WPB = 16 / GM_SPLIT, NTHR = 64 * WPB;                   // wavefronts / threads per workgroup
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nvec = C >> 2;
     const int rep_blocks = ((nW + 7) / 8) * 8 * GM_SPLIT;
@@ -497,7 +496,7 @@ __global__ __launch_bounds__(256) void gather_merge_ln_split_kernel(const float*
         const int b = blockIdx.x;
         const int win = (b / (8 * GM_SPLIT)) * 8 + (b & 7), q = (b >> 3) % GM_SPLIT;
         if (win >= nW) return;
-        const int wv = GM_SPLIT * q + wave;              // the wavefront of the single-workgroup kernel this one stands for
+        const int wv = WPB * q + wave;                   // the wavefront of the single-workgroup kernel this one stands for
         f32x4 acc[MAXV];
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -555,7 +554,7 @@ __global__ __launch_bounds__(256) void gather_merge_ln_split_kernel(const float*
         }
         __syncthreads();
         const float* pw = partials + (int64_t)win * 16 * C;
-        for (int vi = threadIdx.x; vi < nvec; vi += 256) {
+        for (int vi = threadIdx.x; vi < nvec; vi += NTHR) {
             f32x4 p16[16];
 #pragma unroll
             for (int w2 = 0; w2 < 16; ++w2) p16[w2] = *reinterpret_cast<const f32x4*>(pw + (int64_t)w2 * C + 4 * vi);
@@ -583,7 +582,7 @@ __global__ __launch_bounds__(256) void gather_merge_ln_split_kernel(const float*
         wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
         return;
     }
-    const int64_t orow = (int64_t)(blockIdx.x - rep_blocks) * 4 + wave;
+    const int64_t orow = (int64_t)(blockIdx.x - rep_blocks) * WPB + wave;
     if (orow >= Ms) return;
     const int src = crow_tok[orow];
     if (src == -2) return;                               // representative row: written by its window's last slice above
@@ -883,7 +882,8 @@ int64_t toc3d_gather_merge_ln_scratch_bytes(int64_t nW, int64_t C) {
 int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                                 const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
                                 const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy,
-                                void* scratch, int64_t scratch_bytes, toc3d_stream_t stream) {
+                                void* scratch, int64_t scratch_bytes, int64_t split, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(split == 0 || split == 2 || split == 4 || split == 8 || split == 16, "toc3d_gather_merge_ln_split: split = 2, 4, 8, 16 workgroups per window (0 = the default, 4)");
     TOC3D_REQUIRE(x && tok && wgt && crow_tok && rep_row && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln_split: null buffer");
     TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln_split: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
     TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW && N - k <= 1024, "toc3d_gather_merge_ln_split: bad k / lda / rows");
@@ -892,16 +892,20 @@ int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int3
     if (nW <= 0) return TOC3D_OK;
     unsigned* counters = reinterpret_cast<unsigned*>(scratch);
     float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + 256 * ((nW * 4 + 255) / 256));
-    dim3 grid((unsigned)(((nW + 7) / 8) * 8 * GM_SPLIT + (rows + 3) / 4)), block(256);
+    const int sp = split == 0 ? 4 : (int)split, wpb = 16 / sp;
+    dim3 grid((unsigned)(((nW + 7) / 8) * 8 * sp + (rows + wpb - 1) / wpb)), block(64 * wpb);
     const size_t lds = (size_t)C * 4 + 16;
     hipStream_t s = as_stream(stream);
-    if (dtype == TOC3D_BF16)
-        toc3d_launch((gather_merge_ln_split_kernel<bf16_t, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows,
-                     gamma, beta, eps, shortcut, (bf16_t*)a_out, lda, (int)(kept_copy != 0), partials, counters);
-    else if (dtype == TOC3D_F32)
-        toc3d_launch((gather_merge_ln_split_kernel<float, 4>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows,
-                     gamma, beta, eps, shortcut, (float*)a_out, lda, (int)(kept_copy != 0), partials, counters);
+#define TOC3D_GSPLIT(T, SP)                                                                                                                       \
+    toc3d_launch((gather_merge_ln_split_kernel<T, 4, SP>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, \
+                 gamma, beta, eps, shortcut, (T*)a_out, lda, (int)(kept_copy != 0), partials, counters)
+#define TOC3D_GSPLIT_T(T)                                                                                            \
+    do { if (sp == 2) TOC3D_GSPLIT(T, 2); else if (sp == 4) TOC3D_GSPLIT(T, 4); else if (sp == 8) TOC3D_GSPLIT(T, 8); else TOC3D_GSPLIT(T, 16); } while (0)
+    if (dtype == TOC3D_BF16) TOC3D_GSPLIT_T(bf16_t);
+    else if (dtype == TOC3D_F32) TOC3D_GSPLIT_T(float);
     else { toc3d_set_error("toc3d_gather_merge_ln_split: bad dtype"); return TOC3D_ERR_ARG; }
+#undef TOC3D_GSPLIT_T
+#undef TOC3D_GSPLIT
     TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln_split");
     return TOC3D_OK;
 }

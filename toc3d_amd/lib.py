@@ -54,7 +54,7 @@ _SIGS = {
     "toc3d_window_attention_rot": "iplplppppppllllp" + "lppl" + "p",
     "toc3d_gather_merge_ln": "iplppppllllppfpplp",
     "toc3d_gather_merge_ln_ex": "iplppppllllppfppllp",
-    "toc3d_gather_merge_ln_split": "iplppppllllppfppll" + "pl" + "p",
+    "toc3d_gather_merge_ln_split": "iplppppllllppfppll" + "pll" + "p",
     "toc3d_scatter_update": "plpplllpppppp",
     "toc3d_rebase_layernorm_rows": "iplpppllppppfpllp",
     "toc3d_pack_motion_weights": "p" * 24 + "p",
