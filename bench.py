@@ -232,27 +232,30 @@ def dry_run(args, rank, world, tdist):
     assert not args.frames_total or args.frames_total % world == 0
     my_frames = list(tdist.frames_for_rank(args.frames_total, rank, world)) if args.frames_total else [rank]
     frames_per_step = args.frames_total if args.frames_total else world
-    gather = tdist.FeatureGather((6, 4, 2, 5), "cpu", dtype=torch.float32) if world > 1 and not args.sync_gather else None
+    # strong scaling: a rank's frames are ONE forward of B = frames per rank (main()); --sequential-frames keeps one forward per frame
+    batch = len(my_frames) if (args.frames_total and len(my_frames) > 1 and not args.sequential_frames) else 1
+    forwards = [my_frames] if batch > 1 else [[f] for f in my_frames]
+    gather = tdist.FeatureGather((6 * batch, 4, 2, 5), "cpu", dtype=torch.float32) if world > 1 and not args.sync_gather else None
     seen = []
 
     def step():
-        for f in my_frames:
+        for fw in forwards:
             time.sleep(0.002 * (1 + rank))
-            n0 = torch.full((6, 4, 2, 5), float(f))
+            n0 = torch.cat([torch.full((6, 4, 2, 5), float(f)) for f in fw], 0)     # (B * 6 views, ...): view 6 b belongs to frame fw[b]
             if gather is not None:
                 t = gather.submit(n0)
                 if t >= 1:
-                    seen.append(gather.wait(t - 1)[:, 0, 0, 0, 0].tolist())
+                    seen.append(gather.wait(t - 1)[:, ::6, 0, 0, 0].flatten().tolist())
             elif world > 1:
-                seen.append(tdist.all_gather_features(n0, dtype=torch.float32)[:, 0, 0, 0, 0].tolist())
+                seen.append(tdist.all_gather_features(n0, dtype=torch.float32)[:, ::6, 0, 0, 0].flatten().tolist())
 
     elapsed = tdist.timed_steps(step, args.steps, max(0, args.warmup), "cpu", finish=gather.drain if gather is not None else None)
-    census = tdist.exchange_census(torch.full((6, 4, 2, 5), float(rank) + 0.5), "cpu") if world > 1 else None
+    census = tdist.exchange_census(torch.full((6, 4, 2, 5), float(rank) + 0.5), "cpu") if world > 1 else None     # (one frame's worth: the byte count the test pins)
     if rank == 0:
         print(json.dumps({"metric": "LAUNCHER DRY RUN -- not a measurement", "value": frames_per_step * args.steps / elapsed, "unit": "frames/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
                           "scaling": "strong" if args.frames_total else "weak", "vs_baseline": None, "dtype": "none", "data": "stand-in step, no kernels (TOC3D_BENCH_DRY_RUN=1)",
-                          "config": {"workload": "dry run", "frames_per_step": frames_per_step, "last_exchange": seen[-1] if seen else None,
+                          "config": {"workload": "dry run", "frames_per_step": frames_per_step, "frames_per_forward": batch, "last_exchange": seen[-1] if seen else None,
                                      "ranks_seen": census["ranks_seen"] if census else [0], "gather_bytes": census["gather_bytes"] if census else 0,
                                      "gather_verified": census["verified"] if census else None}}))
     if world > 1:
@@ -275,6 +278,8 @@ def main():
                          "graph: the same recording as an explicitly built hipGraph; eager: every launch issued from Python")
     ap.add_argument("--frames-total", type=int, default=0, help="strong-scaling mode (SURVEY.md 8d C5): this many frames per step in total, "
                     "split over the ranks like the reference's DistributedSampler (contiguous chunks); 0 = one frame per rank per step (weak scaling)")
+    ap.add_argument("--sequential-frames", action="store_true", help="--frames-total: run a rank's frames one forward after the other instead of as ONE forward "
+                    "with B = frames per rank (the reference's own batch dimension, toc3d_eva_vit.py:230-242); the A/B leg of the batched form")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: all-gather the neck features on the compute stream instead of overlapped on a side stream")
     ap.add_argument("--tune-cache", default=None, help="JSON file: load the GEMM variant table if present, save it after warm-up "
                     "(default: the table shipped in toc3d_amd/tuned/ for this config, if any)")
@@ -356,6 +361,13 @@ def main():
     inps = [to_dev(inp_cpu)] + [to_dev(synth.make_inputs(cfg, n_frames=1, views_per_frame=6, hw=(H, W), seed=f)) for f in my_frames[1:]]
     inp = inps[0]
     V, h, w = 6, H // 16, W // 16
+    # Strong scaling: a rank's F / world frames are ONE forward with B = frames per rank -- the reference's own batch dimension
+    # (B = temp_queries.shape[0], 6 views per sample, samplers/distributed_sampler.py:41-44 + toc3d_eva_vit.py:230-242): every GEMM is B times as
+    # tall, the per-launch floors are paid once per step instead of once per frame.  --sequential-frames keeps the per-frame loop (the A/B of this).
+    batch_frames = len(inps) if (args.frames_total and len(inps) > 1 and not args.sequential_frames) else 1
+    if batch_frames > 1:
+        inps = [synth.stack_frames(inps)]
+        V = 6 * batch_frames
     # the one exchange (BASELINE.json config 5): per-frame neck features for the head, all-gathered over RCCL on a side stream
     # while the next frame's backbone runs (toc3d_amd/dist.py); the head would wait on the ticket where it reads them
     gather = tdist.FeatureGather((V, 256, h, w), dev) if world > 1 and not args.sync_gather else None
@@ -602,9 +614,11 @@ def main():
             "vs_baseline": (value / PAPER_FPS) if (args.config == "toc3d_faster" and (H, W) == (320, 800)) else None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config} EVA-02 ViT-L backbone + CPFPN neck, 6 views x 3x{H}x{W} per frame, "
-                                   + (f"{args.frames_total} frames per step split over the ranks, " if args.frames_total else "1 frame per rank per step, ")
+                                   + (f"{args.frames_total} frames per step split over the ranks"
+                                      + (f" (each rank's {batch_frames} frames as ONE forward, B = {batch_frames}), " if batch_frames > 1 else " (one forward per frame), ")
+                                      if args.frames_total else "1 frame per rank per step, ")
                                    + "random-init weights, prev_exists=True, injected Gumbel noise",
-                       "frames_per_step": frames_per_step,
+                       "frames_per_step": frames_per_step, "frames_per_forward": batch_frames,
                        "feature_exchange": None if world_report == 1 else ("all-gather on the compute stream" if args.sync_gather else "all-gather overlapped on a side stream"),
                        "launch": {"plan": "recorded launch plan replayed from C (toc3d_plan_run, HIP streams)", "graph": "recorded launch plan as an explicit hipGraph",
                                   "eager": "eager (Python issues every launch)"}[args.launch],
@@ -614,7 +628,7 @@ def main():
                        "ranks_seen": census["ranks_seen"] if census else [0], "gather_bytes": census["gather_bytes"] if census else 0,
                        "gather_verified": census["verified"] if census else None,
                        "baseline_note": "vs_baseline divides by the paper's 4.78 backbone-frames/s (fp32, GPU model unstated, BASELINE.md section 1)"},
-            "whole_path_tflops": (alg * frames_per_step / world_report / (ms * 1e-3)) / 1e12,      # per GPU
+            "whole_path_tflops": (flop_model(cfg, 6, h, w)[0] * frames_per_step / world_report / (ms * 1e-3)) / 1e12,      # per GPU (algorithmic FLOPs of ONE frame x frames)
             "paper_protocol": None if roof is None or block_loop_ms is None else {
                 "block_loop_ms": block_loop_ms, "block_loop_frames_per_s": 1e3 / block_loop_ms,
                 "note": "block loop only, single stream, event-timed (the span the paper's 209 ms covers); the headline value also "

@@ -183,7 +183,8 @@ def test_bench_py_launcher_contract_world2_dry_run():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TOC3D_BENCH_DRY_RUN="1")
-    for extra, scaling, fps, last in (([], "weak", 2, [0.0, 1.0]), (["--frames-total", "4"], "strong", 4, None)):
+    for extra, scaling, fps, last, fpf in (([], "weak", 2, [0.0, 1.0], 1), (["--frames-total", "4"], "strong", 4, [0.0, 1.0, 2.0, 3.0], 2),
+                                           (["--frames-total", "4", "--sequential-frames"], "strong", 4, None, 1)):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"] + extra
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
@@ -193,6 +194,7 @@ def test_bench_py_launcher_contract_world2_dry_run():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == scaling and d["higher_is_better"] is True
         assert d["config"]["frames_per_step"] == fps and d["value"] > 0 and "DRY RUN" in d["metric"]
+        assert d["config"]["frames_per_forward"] == fpf                    # strong scaling: a rank's frames are ONE forward (B = frames per rank)
         assert abs(d["value"] - fps * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
         if last is not None:
             assert d["config"]["last_exchange"] == last                    # every rank's frame, in rank order

@@ -307,13 +307,18 @@ def test_vitl_hires_1600x640_fp32_matches_oracle():
     assert err < 1e-3
 
 
-@pytest.mark.parametrize("groups", [1, 2])
-def test_two_frames_batch_matches_oracle(groups):
-    """B = 2 frames (the scorer's queries are per frame, toc3d_utils.py:240 repeat_interleave): fp32 path vs the oracle."""
+@pytest.mark.parametrize("groups,frames", [(1, 2), (2, 2), (1, 4)])
+def test_two_frames_batch_matches_oracle(groups, frames):
+    """B = 2 / 4 frames per forward (the scorer's queries are per frame, toc3d_utils.py:240 repeat_interleave; what bench.py --frames-total runs per rank):
+    fp32 path vs the oracle; B = 4 stacked from four single-frame inputs the way bench.py does it (synth.stack_frames)."""
     cfg, m = build("toc3d_tiny", "fp32")
     m.view_groups = groups
     sd = synth.make_state_dict(cfg)
-    inp = synth.make_inputs(cfg, n_frames=2, views_per_frame=2)
+    if frames == 2:
+        inp = synth.make_inputs(cfg, n_frames=2, views_per_frame=2)
+    else:
+        inp = synth.stack_frames([synth.make_inputs(cfg, n_frames=1, views_per_frame=2, seed=f) for f in range(frames)])
+        assert inp["x"].shape[0] == 2 * frames and inp["temp_queries"].shape[0] == frames and inp["gumbel"][0].shape[0] == 2 * frames
     with torch.no_grad():
         ref = O.forward_toc3d(sd, cfg, inp["x"], inp["temp_queries"], inp["temp_ref_points"], inp["temp_vel"], inp["temp_timestamp"],
                               inp["temp_ego_pose"], inp["ego_pose_inv"], True, inp["gumbel"])

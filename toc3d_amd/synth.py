@@ -311,3 +311,15 @@ def head_tokens_inputs(cfg: dict, B: int, N: int, h: int, w: int, seed: int = 0)
             E[:3, 3] = torch.tensor([0.1, -0.3, -1.5]) + 0.1 * torch.randn(3, generator=g)
             intr[b, n], l2i[b, n] = K, K @ E
     return dict(feats=feats, intrinsics=intr, lidar2img=l2i)
+
+
+def stack_frames(frames):
+    """Several single-frame input dicts (``make_inputs(n_frames=1, ...)``, any seeds) -> ONE B-frame batch as the reference's collate would hand it to
+    the backbone: views concatenated frame-major (B * Nv, 3, H, W), the memory-bank tensors along the batch dim (toc3d_eva_vit.py:230-242)."""
+    out = {}
+    for k, v in frames[0].items():
+        if isinstance(v, list):
+            out[k] = [torch.cat([f[k][i] for f in frames], 0) for i in range(len(v))]
+        else:
+            out[k] = torch.cat([f[k] for f in frames], 0)
+    return out
