@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Refine a tile table IN PLACE: the per-shape autotuner times isolated cold launches; here every GEMM shape of the frame is re-decided by
 the frame time itself (replayed launch plan, everything else in its real cache / prefetch context).  Greedy, one shape at a time:
-    python tools/tune_in_place.py <table.json> [out.json] [config] [frames per measurement]
+    python tools/tune_in_place.py <table.json> [out.json] [config] [frames per measurement] [tiles|orders] [HxW]
 A candidate replaces the current variant of a shape only if it beats it in two independent measurements."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,8 @@ table = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else table
 name = sys.argv[3] if len(sys.argv) > 3 else "toc3d_faster"
 frames = int(sys.argv[4]) if len(sys.argv) > 4 else 40
+cand_mode = sys.argv[5] if len(sys.argv) > 5 else "tiles"      # "tiles": the tile shapes of CANDS; "orders": the shape's own tile in the four XCD orders (+0 / +100 / +200 / +300)
+hw = tuple(int(v) for v in sys.argv[6].split("x")) if len(sys.argv) > 6 else (320, 800)
 cfg = configs.get(name)
 m = toc3d_amd.build_backbone(dict(cfg, precision="bf16")); m.load_state_dict(synth.make_state_dict(cfg)); m = m.cuda().eval()
 m.alias_outputs, m.autotune = True, False
@@ -20,7 +22,7 @@ m.load_tuning(table)
 neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision="bf16")); neck.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG)); neck = neck.cuda().eval()
 neck.alias_outputs, neck.autotune = True, False
 neck._tuned = m._tuned                                   # one shared table
-inp = synth.make_inputs(cfg, views_per_frame=6)
+inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
 kw = {k: inp[k].cuda() for k in ("temp_queries", "temp_ref_points", "temp_vel", "temp_timestamp", "temp_ego_pose", "ego_pose_inv")}
 g = [t.cuda() for t in inp["gumbel"]]
 x = inp["x"].cuda()
@@ -61,6 +63,8 @@ orig = lib.call
 def spy(nm, *a):
     if nm == "toc3d_linear_fused":
         used.setdefault((a[1], a[15], a[16], a[17]), a[2])
+    elif nm == "toc3d_linear_qkv_rope":                       # shares the bias epilogue's table entry (toc3d_amd.backbone.tuned_linear)
+        used.setdefault((lib.EPI_BIAS, a[9], a[10], a[11]), a[1])
     return orig(nm, *a)
 lib.call = spy
 forget_plans(); step(); step()
@@ -70,7 +74,7 @@ base = measure()
 print(f"start: {1e3 * base:.4f} ms/frame = {1 / base:.1f} frames/s, {len(used)} GEMM shapes", flush=True)
 for key, cur in used.items():
     best_v, best_t = cur, base
-    for v in CANDS:
+    for v in (CANDS if cand_mode == "tiles" else [cur % 100 + o for o in (0, 100, 200, 300)]):
         if v == cur:
             continue
         m._tuned[key] = v
