@@ -891,6 +891,54 @@ def test_ffn_ln_fold_on_the_bf16x3_path():
     assert first is not None
 
 
+def test_norm2_fold_on_the_bf16x3_path():
+    """EPI_RESIDUAL_STATS -> EPI_SWIGLU_STATS_LN on f32 buffers with bf16 x 3 products (precision fp32x3, round 4): the projection's f32 output, its f32
+    copy and statistics, and the hidden units against f64 (eva_vit.py:262-263, 44-47); parity grade (<= 1e-4), independent of the tile variant."""
+    dt, tdt = lib.F32, torch.float32
+    M, C, Hd, Hp = 777, 384, 300, 320
+    eps = 1e-6
+    att = rnd(M, C, seed=1).to(DEV)
+    Wp, bp = rnd(C, C, seed=2, scale=C ** -0.5), rnd(C, seed=3).to(DEV)
+    wproj = pack(Wp, dt, tdt)
+    x0 = (3.0 * rnd(M, C, seed=4) + 0.7).to(DEV)                      # residual stream with a non-zero mean
+    g2, b2 = (1.0 + 0.3 * rnd(C, seed=5)).to(DEV), (0.2 * rnd(C, seed=6)).to(DEV)
+    w1, w2 = rnd(Hd, C, seed=7, scale=C ** -0.5).to(DEV), rnd(Hd, C, seed=8, scale=C ** -0.5).to(DEV)
+    bb1, bb2 = rnd(Hd, seed=9).to(DEV), rnd(Hd, seed=10).to(DEV)
+    xd = x0.double() + att.double() @ Wp.double().T.to(DEV) + bp.double()
+    ln = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + eps) * g2.double() + b2.double()
+    h_ref = torch.nn.functional.silu(ln @ w1.double().T + bb1.double()) * (ln @ w2.double().T + bb2.double())
+    w12f = torch.empty(2 * Hp, C, dtype=tdt, device=DEV)
+    c1, c2 = torch.empty(2 * Hp, device=DEV), torch.empty(2 * Hp, device=DEV)
+    lib.call("toc3d_pack_swiglu_lnfold", dt, w1, w2, bb1, bb2, g2, b2, Hd, C, w12f, c1, c2, Hp, C, S())
+    cap2, cap = C // 64, 6
+    first = None
+    for v in (1, 8, 10, 16, 17, 19, 22, 26, 28, 49, 116, 117, 126, 149):
+        x = x0.clone()
+        a_raw = torch.full((M, C), 9.0, dtype=tdt, device=DEV)
+        st2 = torch.zeros(4 + M * cap2 * 2, device=DEV)
+        hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
+        st = torch.zeros(4 + M * cap * 2, device=DEV)
+        try:
+            lib.call("toc3d_linear_fused", lib.F32X3, lib.EPI_RESIDUAL_STATS, v, att, C, wproj, C, bp, x, C, x, C, 0, None, None, M, C, C, 0,
+                     st2, cap2, None, 0, None, 0, 0.0, a_raw, C, None, S())
+            lib.call("toc3d_linear_fused", lib.F32X3, lib.EPI_SWIGLU_STATS_LN, v, a_raw, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
+                     st, cap, st2, cap2 | (C // 64) << 32, c1, C, eps, None, 0, None, S())
+        except RuntimeError as e:                     # N-tiles that are not whole statistics slots
+            assert "cannot serve" in str(e)
+            continue
+        assert torch.equal(a_raw, x), "the f32 copy IS the f32 output"
+        if first is None:
+            first = (x.clone(), st2.clone(), hid.clone(), st.clone())
+            e_x, e_h = relerr(x, xd), relerr(hid[:, :Hd], h_ref)
+            print(f"[norm2 fold, bf16 x 3] rel err vs f64: projection + residual {e_x:.3e}, hidden units {e_h:.3e}")
+            assert e_x < 3e-5 and e_h < 1e-4 and torch.count_nonzero(hid[:, Hd:]) == 0
+            s2 = st2[4:].view(M, cap2, 2)
+            assert relerr(s2[..., 0].sum(1), x.double().sum(1)) < 1e-5 and relerr(s2[..., 1].sum(1), (x.double() ** 2).sum(1)) < 1e-5
+        for got, want, what in zip((x, st2, hid, st), first, ("projection", "norm2 statistics", "hidden units", "ffn_ln statistics")):
+            assert torch.equal(got, want), f"variant {v}: {what} depends on the tile variant"
+    assert first is not None
+
+
 def test_norm2_folded_across_the_projection_boundary():
     """norm2 folded (EPI_RESIDUAL_STATS -> EPI_SWIGLU_STATS_LN, eva_vit.py:263) against the explicit sequence (EPI_RESIDUAL ->
     toc3d_layernorm_rows -> EPI_SWIGLU_STATS) and an f64 reference; bf16 copy, statistics and hidden units independent of the tile variant."""

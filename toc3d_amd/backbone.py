@@ -177,9 +177,9 @@ def schedule_defaults(precision):
     bf16 = precision == "bf16"
     fast = precision in ("bf16", "fp32x3")
     return dict(
-        carry_compact=bf16,          # consecutive accelerated blocks of one window type continue on the same compact rows (_accel_block)
+        carry_compact=fast,          # consecutive accelerated blocks of one window type continue on the same compact rows (_accel_block)
         fold_ffn_ln=fast,            # SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused)
-        fold_norm2=bf16,             # norm2 folded across the attention-projection -> w1|w2 boundary the same way
+        fold_norm2=fast,             # norm2 folded across the attention-projection -> w1|w2 boundary the same way
         gathered_residual=True,      # the gather skips the f32 copy of the kept rows; the projection GEMM reads their residual from x through crow_tok
         prefetch_weights=192 if bf16 else 0,   # workgroups of each attention launch that pull the next GEMMs' weights towards the chip (0 = off)
         attn_rot=bf16,               # RoPE + q scale in the q|k|v GEMM epilogue, attention on the pre-rotated buffer with K / V staged by DMA

@@ -246,9 +246,10 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
                       float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
                       void* out_act, int64_t ld_act, const int32_t* residual_index) {
     TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3 || dtype == TOC3D_F32X6, "toc3d_linear: bad dtype %d", dtype);
-    const bool x3_fold = dtype == TOC3D_F32X3 && (epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_RESIDUAL_LN);
+    const bool x3_fold = dtype == TOC3D_F32X3 && (epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS ||
+                                                  epilogue == TOC3D_EPI_SWIGLU_STATS_LN);
     TOC3D_REQUIRE((dtype != TOC3D_F32X3 && dtype != TOC3D_F32X6) || epilogue <= TOC3D_EPI_GELU || epilogue == TOC3D_EPI_CONV3X3 || x3_fold,
-                  "toc3d_linear: the bf16 x 3 / x 6 product forms serve epilogues 0-3 and the 3x3 conv (x 3 also the ffn_ln fold, epilogues 4 and 5)");
+                  "toc3d_linear: the bf16 x 3 / x 6 product forms serve epilogues 0-3 and the 3x3 conv (x 3 also the folded LayerNorms, epilogues 4-7)");
     TOC3D_REQUIRE(A && W && out, "toc3d_linear: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && K > 0, "toc3d_linear: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     const int bk = 64;
@@ -269,7 +270,7 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
         TOC3D_REQUIRE(bias && col_sums && ln_n > 0 && ln_n <= K, "toc3d_linear: epilogue %d needs bias (c2), col_sums (c1) and 0 < ln_n <= K (K spans the normalised row)", epilogue);
         TOC3D_REQUIRE(epilogue != TOC3D_EPI_RESIDUAL_LNSELF || !out_act || (ld_act >= N && ((uintptr_t)out_act % 8) == 0 && ld_act % 4 == 0), "toc3d_linear: out_act [M, ld_act >= N], 8-byte aligned rows");
     }
-    if (epilogue >= TOC3D_EPI_SWIGLU_STATS && epilogue != TOC3D_EPI_CONV3X3) TOC3D_REQUIRE(dtype == TOC3D_BF16 || x3_fold, "toc3d_linear: the folded-LayerNorm epilogues are bf16 only (ffn_ln fold: also bf16 x 3)");
+    if (epilogue >= TOC3D_EPI_SWIGLU_STATS && epilogue != TOC3D_EPI_CONV3X3) TOC3D_REQUIRE(dtype == TOC3D_BF16 || x3_fold, "toc3d_linear: the folded-LayerNorm epilogues are bf16 only (and bf16 x 3 on f32 buffers)");
     if (e_stats_out) {
         TOC3D_REQUIRE(stats_out && ((uintptr_t)stats_out % 16) == 0, "toc3d_linear: epilogue %d needs a 16-byte aligned stats_out buffer", epilogue);
         const int64_t slot = e_swiglu ? 128 : 64;

@@ -12,6 +12,9 @@ int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s)
         // SwiGLU.ffn_ln folded across the w1|w2 -> w3 boundary on the parity-grade fast path as well (f32 statistics, f32 row table): no LayerNorm pass over the hidden units
         case TOC3D_EPI_SWIGLU_STATS: return launch_epi_x<TOC3D_EPI_SWIGLU_STATS, 3>(variant, a, s);
         case TOC3D_EPI_RESIDUAL_LN: return launch_epi_x<TOC3D_EPI_RESIDUAL_LN, 3>(variant, a, s);
+        // ... and norm2 across the projection -> w1|w2 boundary (round 4): the projection leaves the updated rows as an f32 copy with their statistics
+        case TOC3D_EPI_RESIDUAL_STATS: return launch_epi_x<TOC3D_EPI_RESIDUAL_STATS, 3>(variant, a, s);
+        case TOC3D_EPI_SWIGLU_STATS_LN: return launch_epi_x<TOC3D_EPI_SWIGLU_STATS_LN, 3>(variant, a, s);
         default: return TOC3D_ERR_ARG;
     }
 }

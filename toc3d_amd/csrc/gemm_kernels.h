@@ -1147,7 +1147,8 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
     // a wave must own whole (w1, w2) 32-column groups; the folded-LayerNorm statistics need N-tiles of whole 128-column slots; the fold is bf16 only
     constexpr bool unsupported = (epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) ||
                                  (EPI >= TOC3D_EPI_SWIGLU_STATS && EPI != TOC3D_EPI_CONV3X3 && sizeof(T) != 2 &&
-                                  !(X3 == 3 && (EPI == TOC3D_EPI_SWIGLU_STATS || EPI == TOC3D_EPI_RESIDUAL_LN)));   // ... and the bf16 x 3 form of the ffn_ln fold
+                                  !(X3 == 3 && (EPI == TOC3D_EPI_SWIGLU_STATS || EPI == TOC3D_EPI_RESIDUAL_LN || EPI == TOC3D_EPI_RESIDUAL_STATS ||
+                                                EPI == TOC3D_EPI_SWIGLU_STATS_LN)));   // ... and the bf16 x 3 forms of the ffn_ln and norm2 folds (f32 copies, f32 statistics)
     if constexpr (unsupported) {
         g_bad_variant = true;
     } else {

@@ -92,6 +92,7 @@ for key, cur in used.items():
         base = best_t
 final = measure()
 print(f"end: {1e3 * final:.4f} ms/frame = {1 / final:.1f} frames/s", flush=True)
+os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
 d = json.load(open(table))
 tab = {tuple(k): v for k, v in d["table"]}
 tab.update({k: int(v) for k, v in m._tuned.items()})
