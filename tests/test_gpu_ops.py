@@ -1108,4 +1108,4 @@ def test_linear_bf16x3_products_on_f32_operands(M, N, K):
     lib.call("toc3d_linear", lib.F32X3, lib.EPI_GELU, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, S())
     assert relerr(out, torch.nn.functional.gelu(ref)) < 2e-5
     with pytest.raises(RuntimeError, match="bf16 x 3"):
-        lib.call("toc3d_linear_fused", lib.F32X3, lib.EPI_RESIDUAL_STATS, 0, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, *lib.NO_FUSED, S())   # (epilogues 4 / 5, the ffn_ln fold, are served since round 3)
+        lib.call("toc3d_linear_fused", lib.F32X6, lib.EPI_RESIDUAL_STATS, 0, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, *lib.NO_FUSED, S())   # (x 3 serves the folded-LayerNorm epilogues 4-7 since rounds 3 / 4; x 6 does not)
