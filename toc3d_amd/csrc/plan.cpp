@@ -13,6 +13,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "capi.h"
@@ -44,7 +46,7 @@ struct Toc3dPlan {
     bool recording = false, finalized = false;
     int mode = 0, device = -1;
     // replay state
-    std::vector<hipStream_t> streams;            // lanes 1.. (owned)
+    std::vector<hipStream_t> streams;            // lanes 1.. (shared by every plan of the process: shared_lane_stream below; never destroyed)
     std::vector<hipEvent_t> events;              // one per signalling node (owned)
     hipEvent_t entry = nullptr;
     std::vector<hipEvent_t> lane_done;           // lanes 1..: joined into lane 0 at the end of a run
@@ -58,7 +60,6 @@ struct Toc3dPlan {
     void release() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
-        for (hipStream_t s : streams) (void)hipStreamDestroy(s);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         for (hipEvent_t e : lane_done) (void)hipEventDestroy(e);
         if (entry) (void)hipEventDestroy(entry);
@@ -117,6 +118,28 @@ unsigned event_flags() {
     return flags;
 }
 
+// The side lanes of EVERY plan of the process run on one set of HIP streams per device, created by the first plan that needs them.  Round 4 finding
+// (profiles/r04_stream_priority.txt, tools/ubench/schedule_ab.py with identical schedules): with private streams per plan, the process's first model ran
+// 2.3 % faster than every identical model built later -- HIP deals streams round-robin onto a few hardware queues, and a later plan's side lanes can land
+// on the queue of the caller's stream, which serialises the scorer's side work behind the block chain.  Sharing the first plan's streams gives every plan
+// its mapping.  Correctness never depended on the streams being private (cross-lane order is carried by events; two plans replayed concurrently from two
+// host threads merely share the side queues).  Immutable once created: the "no mutable global state" rule of include/toc3d.h is about data, and holds.
+int shared_lane_stream(int lane, hipStream_t* out) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, hipStream_t> pool;
+    int dev = 0;
+    PLAN_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find({dev, lane});
+    if (it == pool.end()) {
+        hipStream_t s;
+        PLAN_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        it = pool.emplace(std::make_pair(dev, lane), s).first;
+    }
+    *out = it->second;
+    return TOC3D_OK;
+}
+
 int build_streams(Toc3dPlan* p) {
     int nlanes = 1;
     for (int l = 1; l < MAX_LANES; ++l)
@@ -125,7 +148,7 @@ int build_streams(Toc3dPlan* p) {
         hipStream_t s;
         // (round 4, measured and not taken: side lanes created with hipStreamCreateWithPriority, lowest or highest -- 207.6 / 205.2 frames/s against 203.5 in
         // one hardware-queue mapping, 101 / 81 frames/s in another: profiles/r04_stream_priority.txt)
-        PLAN_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        { const int rc = shared_lane_stream(l, &s); if (rc != TOC3D_OK) return rc; }
         p->streams.push_back(s);
         hipEvent_t e;
         PLAN_HIP(hipEventCreateWithFlags(&e, event_flags()));
