@@ -162,7 +162,8 @@ _flush = None                   # 256 MB scratch shared by all models: evicts L2
 
 # + 100: 8 row bands per XCD.  The 2-D XCD partitions (+ 200 / + 300, round 3) win 6-20 % on isolated cold w1|w2 / w3 launches and nothing inside the frame
 # (profiles/r03_xcd_order_sweep.txt): they stay available through the C ABI but are not tuning candidates.
-_VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 152, 163),
+_VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 152,
+                        154, 155, 156, 158, 159, 163),
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126),
              lib.F32X3: (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 114, 116, 117, 122, 126, 149)}
 _VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3]

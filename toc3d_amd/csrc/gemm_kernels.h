@@ -147,14 +147,21 @@ template <int RB, int SW = 0> TOC3D_DEV int swz(int r) {
 template <typename T, int R, int RB, int NTHR, int SW = 0>
 TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max_row, int k0, char* lds_tile, int wave, int lane) {
     constexpr int CPR = RB / 16;                        // chunks per row
+    // Tiles whose chunk count is not a multiple of the workgroup size (96- / 160-row tiles on 512 threads): the wavefronts past the end of the last round
+    // re-issue pieces of the tile's head (same bytes to the same LDS place), so that EVERY wave issues the same number of DMA instructions -- the ring
+    // variants count them with a constant s_waitcnt vmcnt(N).
+    static_assert((R * CPR) % 64 == 0, "whole DMA instructions");
+    constexpr int ITER = (R * CPR + NTHR - 1) / NTHR;
 #pragma unroll
-    for (int t = 0; t < R * CPR / NTHR; ++t) {
-        const int cidx = t * NTHR + wave * 64 + lane;
+    for (int t = 0; t < ITER; ++t) {
+        int base = t * NTHR + wave * 64;                // wave-uniform
+        if constexpr ((R * CPR) % NTHR != 0) base = base < R * CPR ? base : base - R * CPR;
+        const int cidx = base + lane;
         const int r = cidx / CPR, p = cidx % CPR;
         int gr = row0 + r;
         gr = gr < max_row ? gr : max_row;
         const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB, SW>(r)) << 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + (t * NTHR + wave * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + base * 16), 16, 0, 0);
     }
 }
 
@@ -579,7 +586,9 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
     constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
     constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;
-    constexpr int LOADS = (BM + BN) * (RB / 16) / NTHR; // global_load_lds per thread per K-tile
+    constexpr int LOADS = (BM * (RB / 16) + NTHR - 1) / NTHR + (BN * (RB / 16) + NTHR - 1) / NTHR;   // global_load_lds per thread per K-tile (stage_tile rounds up)
+    static_assert(((BM * (RB / 16)) % NTHR == 0 && (BN * (RB / 16)) % NTHR == 0) || (X3 == 0 && EPI != TOC3D_EPI_CONV3X3),
+                  "tiles with a partial DMA round: plain bf16 / f32 operand loaders only");
     constexpr int KS = RB / 32 / (int)sizeof(T);        // 32-wide K steps per K-tile
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
@@ -1149,7 +1158,8 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
                                  (EPI >= TOC3D_EPI_SWIGLU_STATS && EPI != TOC3D_EPI_CONV3X3 && sizeof(T) != 2 &&
                                   !(X3 == 3 && (EPI == TOC3D_EPI_SWIGLU_STATS || EPI == TOC3D_EPI_RESIDUAL_LN || EPI == TOC3D_EPI_RESIDUAL_STATS ||
                                                 EPI == TOC3D_EPI_SWIGLU_STATS_LN)));   // ... and the bf16 x 3 forms of the ffn_ln and norm2 folds (f32 copies, f32 statistics)
-    if constexpr (unsupported) {
+    constexpr bool partial_round = (BM * (RB / 16)) % (64 * WM * WN) != 0 || (BN * (RB / 16)) % (64 * WM * WN) != 0;      // 96- / 160-row tiles
+    if constexpr (unsupported || (partial_round && (X3 != 0 || EPI == TOC3D_EPI_CONV3X3))) {
         g_bad_variant = true;
     } else {
         constexpr int lds_fixed = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);   // + the (mean, rstd) row table
@@ -1279,6 +1289,14 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         // (the rotating q|k|v epilogue is held to 128 registers -- two workgroups per CU like the other epilogues: unconstrained it took 138, ONE workgroup per CU and 83 instead of 51 us at M = 6000)
         case 52: launch_cfg<T, EPI, 192, 192, 1, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 single buffer, 96x48 per wave, 48 KiB: 512 tiles for q|k|v at M = 6000 (one per slot at two per CU)
         case 53: launch_cfg<T, EPI, 192, 192, 2, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 double buffered, 96 KiB
+        // M-tiles of 96 / 160 rows (round 4): the frame's launches run 1.2-2.6 rounds of 128-row tiles on the chip's 512-768 workgroup slots and pay for a whole
+        // last round; a 96- or 160-row tile changes the tile count by 4/3 or 4/5 at the same N-tile (whole statistics slots, whole (w1, w2) groups)
+        case 54: launch_cfg<T, EPI, 96, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 6 : 1)>(a, s); break;    // 96x128 single buffer, 48x32 per wave, 28 KiB
+        case 55: launch_cfg<T, EPI, 96, 128, 2, 128, 2, 4, 1>(a, s); break;                           // 96x128 double buffered, 56 KiB
+        case 56: launch_cfg<T, EPI, 96, 128, 4, 128, 2, 4, 1>(a, s); break;                           // 96x128 4-deep ring, 112 KiB
+        case 57: launch_cfg<T, EPI, 160, 128, 1, 128, 2, 4, 1>(a, s); break;                          // 160x128 single buffer, 80x32 per wave, 36 KiB
+        case 58: launch_cfg<T, EPI, 160, 128, 2, 128, 2, 4, 1>(a, s); break;                          // 160x128 double buffered, 72 KiB
+        case 59: launch_cfg<T, EPI, 192, 128, 3, 128, 2, 4, 1>(a, s); break;                          // 192x128 3-deep ring, 120 KiB: 32 x 8 = 256 tiles for N = 1024 at M = 6000
         case 51: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 8 : 1)>(a, s); break;   // variant 16 held to 64 registers (bf16): FOUR workgroups per CU -- the loop is bound by operand bytes in flight per CU
 #ifdef TOC3D_EXPERIMENTAL
         // 32x32x16 MFMA form of the K loop (bf16 only; round 4; correct and NOT faster, profiles/r04_mfma32_variants.txt: experimental builds only): per-wave tiles of whole 32x32 blocks, own LDS swizzle, same epilogues (the accumulators are

@@ -29,7 +29,9 @@ x = inp["x"].cuda()
 
 
 def step():
-    return neck([m(x, prev_exists=True, gumbel_noise=g, **kw).img_feats["last_feat"]])
+    if synth.is_toc3d(cfg):
+        return neck([m(x, prev_exists=True, gumbel_noise=g, **kw).img_feats["last_feat"]])
+    return neck([m(x)["last_feat"]])
 
 
 def forget_plans():
@@ -54,7 +56,7 @@ def measure():
     return best
 
 
-CANDS = (16, 116, 51, 151, 17, 117, 45, 145, 49, 149, 52, 152, 19, 114, 126, 14, 26, 28, 29, 9, 10)
+CANDS = (16, 116, 51, 151, 17, 117, 45, 145, 49, 149, 52, 152, 19, 114, 126, 14, 26, 28, 29, 9, 10, 54, 154, 55, 155, 56, 156, 57, 58, 158)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
