@@ -1005,6 +1005,13 @@ def test_norm2_folded_across_the_projection_boundary():
             sl = st[4:].view(M, cap, 2)[:, : (2 * Hp + 127) // 128]
             assert relerr(sl[..., 0].sum(1), hid.double().sum(1)) < 1e-5
         assert torch.equal(hid, ref_h) and torch.equal(st, ref_hs), f"variant {v}: folded w1|w2 epilogue depends on the tile variant"
+    # with the slot count passed by the host (what the backbone does: no read of the buffer's header): the same table, the same bits
+    for v in (16, 116, 15, 51, 17, 28, 29, 49, 54, 55, 56):
+        hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
+        st = torch.zeros(4 + M * cap * 2, device=DEV)
+        lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS_LN, v, ref_a, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
+                 st, cap, st2, cap2 | (C // 64) << 32, c1, C, eps, None, 0, None, S())
+        assert torch.equal(hid, ref_h) and torch.equal(st, ref_hs), f"variant {v}: the host-passed slot count changes the result"
     with pytest.raises(RuntimeError, match="different buffers"):
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS_LN, 16, ref_a, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
                  st2, cap2, st2, cap2, c1, C, eps, None, 0, None, S())

@@ -577,7 +577,7 @@ TOC3D_DEV void split_bf16x6(const Frag<float>& f, bf16x8& hi, bf16x8& mid, bf16x
 
 // One BM x BN output tile (rows m0.., columns n0..) by the calling workgroup of 64 * WM * WN threads: K loop + fused epilogue.  `smem` = the
 // workgroup's dynamic LDS.  gemm_kernel below runs one tile per workgroup; gemm_chain_kernel walks a queue of tiles of several GEMMs.
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int X3 = 0>
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int X3 = 0, int OCC = 1>
 TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* smem) {
     static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4) || (X3 == 32 && sizeof(T) == 2), "the bf16 x 3 / x 6 product forms run on f32 operands, the 32x32x16 MFMA form on bf16");
     constexpr bool MF32 = X3 == 32;                     // v_mfma_f32_32x32x16_bf16 in the K loop (see lds_frag32); accumulators handed to the epilogue as 16x16 tiles
@@ -822,7 +822,22 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
             row = row < a.M ? row : a.M - 1;
             const f32x2* sp = base + (int64_t)row * a.stats_in_cap;
             double s1 = 0.0, s2 = 0.0;
-            for (int sl = part; sl < nslots; sl += 4) {
+            // every slot of the thread requested before the first is added: the plain loop (load, wait, add per slot) was nslots / 4 = 4-11 DEPENDENT L2 round
+            // trips in front of every workgroup's K loop (round 4: +7.5 us on the w1|w2 launch at M = 6000).  Unconditional loads (clamped index), the validity
+            // test on the value: a per-element "load or not" makes hipcc branch and wait per element (cdna_hip_programming.md, traps (c)).  Same order of additions.
+            // slots 0 .. 15 in front of w1|w2 (residual-stream statistics: C / 64 = 16), 0 .. 47 in front of w3 (hidden units: 43); the register-capped tiles
+            // (OCC > 1: 64 / 80 / 128 registers for 8 / 6 / 4 waves per SIMD) would spill the batch and keep the plain loop
+            constexpr int PRE = OCC > 1 ? 0 : (epi_is_swiglu(EPI) ? 4 : 12);
+            f32x2 pv[PRE > 0 ? PRE : 1];
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                const int sl = part + 4 * j;
+                pv[j] = sp[sl < nslots ? sl : part];
+            }
+#pragma unroll
+            for (int j = 0; j < PRE; ++j)
+                if (part + 4 * j < nslots) { s1 += (double)pv[j][0]; s2 += (double)pv[j][1]; }
+            for (int sl = part + 4 * PRE; sl < nslots; sl += 4) {
                 const f32x2 v = sp[sl];
                 s1 += (double)v[0];
                 s2 += (double)v[1];
@@ -836,6 +851,10 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // table rows written before this wave reaches the K loop's first barrier
     };
+    // (Round 4, measured and removed: the statistics rows brought to LDS by DMA beside the first operand tile instead of through registers.  No gain on any tile --
+    // with the table stubbed out the whole cost of this epilogue disappears, with the rows in LDS it stays: what costs is the f64 reduction between the first
+    // barrier and the first MFMA, paid by every one of the 43 column tiles of a row panel, not the loads -- and the extra LDS and registers halved the 4-wave tile.
+    // profiles/r04_fold_epilogue_cost.txt.)
     // EPI_QKV_ROPE: every lane fetches the RoPE positions of its MT output rows at kernel start, and the compact tables ([cos | sin], 4-5 KB)
     // come to LDS by DMA while the K loop runs, so that the epilogue has no dependent global round trip (the first version read both from
     // global memory inside the epilogue: +7 us per q|k|v launch).  Single-buffer tiles: a region behind the operand stage, requested with the
@@ -988,7 +1007,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
         m0 = (r0 + l % hm) * BM;
         n0 = (c0 + l / hm) * BN;
     }
-    gemm_tile<T, EPI, BM, BN, STAGES, RB, WM, WN, X3>(a, m0, n0, smem);
+    gemm_tile<T, EPI, BM, BN, STAGES, RB, WM, WN, X3, OCC>(a, m0, n0, smem);
     TOC3D_TRACE_END();
 }
 
