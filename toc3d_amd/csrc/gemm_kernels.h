@@ -594,6 +594,53 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, g = lane >> 4;
 
+    f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
+    auto ln_rows_prepare = [&]() {
+        const int nslots = a.stats_in_slots > 0 ? a.stats_in_slots : *reinterpret_cast<const int*>(a.stats_in);
+        const f32x2* base = reinterpret_cast<const f32x2*>(a.stats_in + 4);
+        for (int w = tid; w < BM * 4; w += NTHR) {
+            const int r = w >> 2, part = w & 3;
+            int row = m0 + r;
+            row = row < a.M ? row : a.M - 1;
+            const f32x2* sp = base + (int64_t)row * a.stats_in_cap;
+            double s1 = 0.0, s2 = 0.0;
+            // every slot of the thread requested before the first is added: the plain loop (load, wait, add per slot) was nslots / 4 = 4-11 DEPENDENT L2 round
+            // trips in front of every workgroup's K loop (round 4: +7.5 us on the w1|w2 launch at M = 6000).  Unconditional loads (clamped index), the validity
+            // test on the value: a per-element "load or not" makes hipcc branch and wait per element (cdna_hip_programming.md, traps (c)).  Same order of additions.
+            // slots 0 .. 15 in front of w1|w2 (residual-stream statistics: C / 64 = 16), 0 .. 47 in front of w3 (hidden units: 43); the register-capped tiles
+            // (OCC > 1: 64 / 80 / 128 registers for 8 / 6 / 4 waves per SIMD) run this at the very top of the tile, before the accumulators exist (PREP_EARLY)
+            constexpr int PRE = epi_is_swiglu(EPI) ? 4 : 12;
+            f32x2 pv[PRE > 0 ? PRE : 1];
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                const int sl = part + 4 * j;
+                pv[j] = sp[sl < nslots ? sl : part];
+            }
+#pragma unroll
+            for (int j = 0; j < PRE; ++j)
+                if (part + 4 * j < nslots) { s1 += (double)pv[j][0]; s2 += (double)pv[j][1]; }
+            for (int sl = part + 4 * PRE; sl < nslots; sl += 4) {
+                const f32x2 v = sp[sl];
+                s1 += (double)v[0];
+                s2 += (double)v[1];
+            }
+            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+            const double mean = s1 * (double)a.ln_inv_n;
+            double var = s2 * (double)a.ln_inv_n - mean * mean;      // biased variance (F.layer_norm)
+            var = var > 0.0 ? var : 0.0;
+            if (part == 0) lnrow[r] = f32x2{(float)mean, 1.0f / sqrtf((float)var + a.ln_eps)};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // table rows written before this wave reaches the K loop's first barrier
+    };
+    // Register-capped tiles: the table is formed FIRST, while nothing else of the tile is live -- behind the first operand request (where the uncapped tiles do
+    // it, overlapped with that request's flight) its batch of loads spills.  One exposed L2 round trip instead of 4-11 dependent ones.
+    constexpr bool PREP_EARLY = epi_ln_stats_in(EPI) && OCC > 1;
+    if constexpr (PREP_EARLY) {
+        ln_rows_prepare();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
     const T* A = reinterpret_cast<const T*>(a.A);
     const T* W = reinterpret_cast<const T*>(a.W);
     constexpr int BK = RB / (int)sizeof(T);
@@ -812,45 +859,6 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
-    f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
-    auto ln_rows_prepare = [&]() {
-        const int nslots = a.stats_in_slots > 0 ? a.stats_in_slots : *reinterpret_cast<const int*>(a.stats_in);
-        const f32x2* base = reinterpret_cast<const f32x2*>(a.stats_in + 4);
-        for (int w = tid; w < BM * 4; w += NTHR) {
-            const int r = w >> 2, part = w & 3;
-            int row = m0 + r;
-            row = row < a.M ? row : a.M - 1;
-            const f32x2* sp = base + (int64_t)row * a.stats_in_cap;
-            double s1 = 0.0, s2 = 0.0;
-            // every slot of the thread requested before the first is added: the plain loop (load, wait, add per slot) was nslots / 4 = 4-11 DEPENDENT L2 round
-            // trips in front of every workgroup's K loop (round 4: +7.5 us on the w1|w2 launch at M = 6000).  Unconditional loads (clamped index), the validity
-            // test on the value: a per-element "load or not" makes hipcc branch and wait per element (cdna_hip_programming.md, traps (c)).  Same order of additions.
-            // slots 0 .. 15 in front of w1|w2 (residual-stream statistics: C / 64 = 16), 0 .. 47 in front of w3 (hidden units: 43); the register-capped tiles
-            // (OCC > 1: 64 / 80 / 128 registers for 8 / 6 / 4 waves per SIMD) would spill the batch and keep the plain loop
-            constexpr int PRE = OCC > 1 ? 0 : (epi_is_swiglu(EPI) ? 4 : 12);
-            f32x2 pv[PRE > 0 ? PRE : 1];
-#pragma unroll
-            for (int j = 0; j < PRE; ++j) {
-                const int sl = part + 4 * j;
-                pv[j] = sp[sl < nslots ? sl : part];
-            }
-#pragma unroll
-            for (int j = 0; j < PRE; ++j)
-                if (part + 4 * j < nslots) { s1 += (double)pv[j][0]; s2 += (double)pv[j][1]; }
-            for (int sl = part + 4 * PRE; sl < nslots; sl += 4) {
-                const f32x2 v = sp[sl];
-                s1 += (double)v[0];
-                s2 += (double)v[1];
-            }
-            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
-            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
-            const double mean = s1 * (double)a.ln_inv_n;
-            double var = s2 * (double)a.ln_inv_n - mean * mean;      // biased variance (F.layer_norm)
-            var = var > 0.0 ? var : 0.0;
-            if (part == 0) lnrow[r] = f32x2{(float)mean, 1.0f / sqrtf((float)var + a.ln_eps)};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // table rows written before this wave reaches the K loop's first barrier
-    };
     // (Round 4, measured and removed: the statistics rows brought to LDS by DMA beside the first operand tile instead of through registers.  No gain on any tile --
     // with the table stubbed out the whole cost of this epilogue disappears, with the rows in LDS it stays: what costs is the f64 reduction between the first
     // barrier and the first MFMA, paid by every one of the 43 column tiles of a row panel, not the loads -- and the extra LDS and registers halved the 4-wave tile.
@@ -882,7 +890,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
         for (int kt = 0; kt < nk; ++kt) {
             request(kt);
-            if constexpr (epi_ln_stats_in(EPI)) { if (kt == 0) ln_rows_prepare(); }
+            if constexpr (epi_ln_stats_in(EPI) && !PREP_EARLY) { if (kt == 0) ln_rows_prepare(); }
             if constexpr (epi_is_rope(EPI)) { if (kt == 0) rope_stage(smem + STAGE_BYTES + (epi_ln_in(EPI) ? BM * 8 : 0)); }
             wait_vmcnt<0>();
             split_rows_x3(kt);
@@ -894,7 +902,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
             if (t < nk) request(t);
-        if constexpr (epi_ln_stats_in(EPI)) ln_rows_prepare();
+        if constexpr (epi_ln_stats_in(EPI) && !PREP_EARLY) ln_rows_prepare();
         for (int kt = 0; kt < nk; ++kt) {
             if (nk - 1 - kt >= STAGES - 2) wait_vmcnt<(STAGES >= 2 ? STAGES - 2 : 0) * LOADS>();   // tiles kt+1 .. kt+STAGES-2 may stay in flight
             else wait_vmcnt<0>();                                                                   // pipeline tail
