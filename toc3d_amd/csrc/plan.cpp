@@ -111,8 +111,12 @@ namespace {
 // fence), 1 = hipEventReleaseToDevice, 2 = hipEventDisableSystemFence.
 unsigned event_flags() {
     static const unsigned flags = [] {
-        const char* e = getenv("TOC3D_EVENT_FENCE");
+#ifdef TOC3D_EXPERIMENTAL
+        const char* e = getenv("TOC3D_EVENT_FENCE");       // (EXPERIMENTAL=1 builds only: measured 0.4-0.7 % slower, profiles/r03_event_fence.txt)
         const int mode = e ? atoi(e) : 0;
+#else
+        const int mode = 0;
+#endif
         return (unsigned)hipEventDisableTiming | (mode == 1 ? (unsigned)hipEventReleaseToDevice : mode == 2 ? (unsigned)hipEventDisableSystemFence : 0u);
     }();
     return flags;
