@@ -44,9 +44,12 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 enum { CHAIN_ERR_SPIN = 1, CHAIN_ERR_SCHED = 2 };
 
-template <typename C>
+// OCC: the kernel's register cap, as gemm_kernel passes it -- a capped tile forms its (mean, rstd) table before anything else of the tile is live.
+// (Round 4: with the table's batch of statistics loads behind the first operand request -- the uncapped form -- family 1 / tiling 0 came back wrong in the
+// lanes hipcc keeps spilled SGPRs in: 46 SGPR + 77 VGPR spills under the 80-register cap, tools/gpu/r4_chain_dbg.py.  No product kernel spills an SGPR.)
+template <typename C, int OCC>
 TOC3D_DEV void chain_tile(const GemmArgs& a, int mt, int nt, char* smem) {
-    if constexpr (C::EPI >= 0) gemm_tile<bf16_t, C::EPI, C::BM, C::BN, C::STAGES, C::RB, C::WM, C::WN>(a, mt * C::BM, nt * C::BN, smem);
+    if constexpr (C::EPI >= 0) gemm_tile<bf16_t, C::EPI, C::BM, C::BN, C::STAGES, C::RB, C::WM, C::WN, 0, OCC>(a, mt * C::BM, nt * C::BN, smem);
 }
 
 template <typename C0, typename C1, typename C2, int OCC>
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(512, OCC) void gemm_chain_kernel(ChainArgs c) {
             lds_barrier();
         }
         if (c.trace && tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
-        if (op == 0) chain_tile<C0>(c.op[0].a, mt, nt, smem);
-        else if (op == 1) chain_tile<C1>(c.op[1].a, mt, nt, smem);
-        else if (op == 2) chain_tile<C2>(c.op[2].a, mt, nt, smem);
+        if (op == 0) chain_tile<C0, OCC>(c.op[0].a, mt, nt, smem);
+        else if (op == 1) chain_tile<C1, OCC>(c.op[1].a, mt, nt, smem);
+        else if (op == 2) chain_tile<C2, OCC>(c.op[2].a, mt, nt, smem);
         else if (tid == 0) __hip_atomic_store(state + 1, (unsigned)CHAIN_ERR_SCHED, TOC3D_RLX_AGENT);
         if (c.trace && tid == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
         // ---- publish the tile: its stores are acknowledged by the L2 before the counter moves ----

@@ -952,7 +952,9 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         static_assert(BN % SLOT == 0 && (epi_is_swiglu(EPI) ? NT % 2 == 0 : true), "statistics need N-tiles of whole slots");
         float gs[MT * G], gq[MT * G];
         gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq, lnrow + wm * TM);
-        tile_barrier();                                  // every wave is done with the operand tiles (their reads fed MFMAs) and with the row table
+        // `red` overlays the operand stages: every wave must be done reading them.  The single-buffer loop ends on that barrier already (behind its last
+        // multiply); the rings end on a multiply.  (The row table lives behind the stages and is not touched.)
+        if constexpr (STAGES > 1) tile_barrier();
         f32x2* red = reinterpret_cast<f32x2*>(smem);     // [GPT][BM]
 #pragma unroll
         for (int i = 0; i < MT; ++i)
