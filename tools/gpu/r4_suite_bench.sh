@@ -2,7 +2,7 @@
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 cd "$GRAFT_REPO_ROOT"
-timeout 1500 python bench.py > gpurun_out/r4_bench.json 2> gpurun_out/r4_bench.err; tail -3 gpurun_out/r4_bench.err
+T0=$(date +%s); timeout 1500 python bench.py > gpurun_out/r4_bench.json 2> gpurun_out/r4_bench.err; echo "default bench.py wall time: $(( $(date +%s) - T0 )) s"; tail -3 gpurun_out/r4_bench.err
 python - <<'PY'
 import json
 d = json.loads(open('gpurun_out/r4_bench.json').read().strip().splitlines()[-1])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Refine a tile table IN PLACE: the per-shape autotuner times isolated cold launches; here every GEMM shape of the frame is re-decided by
 the frame time itself (replayed launch plan, everything else in its real cache / prefetch context).  Greedy, one shape at a time:
-    python tools/tune_in_place.py <table.json> [out.json] [config] [frames per measurement] [tiles|orders] [HxW]
+    python tools/tune_in_place.py <table.json> [out.json] [config] [frames per measurement] [tiles|orders] [HxW] [precision, default bf16]
 A candidate replaces the current variant of a shape only if it beats it in two independent measurements."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,11 +15,12 @@ name = sys.argv[3] if len(sys.argv) > 3 else "toc3d_faster"
 frames = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 cand_mode = sys.argv[5] if len(sys.argv) > 5 else "tiles"      # "tiles": the tile shapes of CANDS; "orders": the shape's own tile in the four XCD orders (+0 / +100 / +200 / +300)
 hw = tuple(int(v) for v in sys.argv[6].split("x")) if len(sys.argv) > 6 else (320, 800)
+precision = sys.argv[7] if len(sys.argv) > 7 else "bf16"
 cfg = configs.get(name)
-m = toc3d_amd.build_backbone(dict(cfg, precision="bf16")); m.load_state_dict(synth.make_state_dict(cfg)); m = m.cuda().eval()
+m = toc3d_amd.build_backbone(dict(cfg, precision=precision)); m.load_state_dict(synth.make_state_dict(cfg)); m = m.cuda().eval()
 m.alias_outputs, m.autotune = True, False
 m.load_tuning(table)
-neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision="bf16")); neck.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG)); neck = neck.cuda().eval()
+neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision=precision)); neck.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG)); neck = neck.cuda().eval()
 neck.alias_outputs, neck.autotune = True, False
 neck._tuned = m._tuned                                   # one shared table
 inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
@@ -98,4 +99,4 @@ os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
 d = json.load(open(table))
 tab = {tuple(k): v for k, v in d["table"]}
 tab.update({k: int(v) for k, v in m._tuned.items()})
-json.dump({"precision": "bf16", "table": [[list(k), v] for k, v in tab.items()]}, open(out, "w"))
+json.dump({"precision": d.get("precision", precision), "table": [[list(k), v] for k, v in tab.items()]}, open(out, "w"))
