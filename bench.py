@@ -31,7 +31,7 @@ from toc3d_amd import configs, lib, synth  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PAPER_FPS = 1000.0 / 209.0      # ToC3D-Faster ViT-L 6x(800x320) backbone 209.0 ms, fp32, GPU unstated
-REF_BOX_TFLOPS, REF_BOX_COPY_GBS = None, None    # calibrate() on the box the committed round-4 profiles were taken on (filled in from profiles/r04_bench_final.json)
+REF_BOX_TFLOPS, REF_BOX_COPY_GBS, REF_BOX_FPS = 790.4, 5013.2, 201.6    # calibrate() and the headline on the box profiles/r04_bench_final.json was taken on (boxes of the pool spread ~5 %: 795 TF / 5264 GB/s -> 203.9)
 
 
 def flop_model(cfg, V, h, w):
@@ -147,8 +147,8 @@ def calibrate(dev):
     med = lambda v: sorted(v)[len(v) // 2]
     return {"gemm_yardstick_tflops": med(tf), "gemm_yardstick": "toc3d_linear_ex variant 16, 6016x3072x1024 bf16 + bias, 30 back-to-back launches, median of 5",
             "copy_gb_s": med(gb), "copy": "toc3d_copy_bytes 256 MiB (read + write bytes), 4 back-to-back launches, median of 5",
-            "reference_box": {"gemm_yardstick_tflops": REF_BOX_TFLOPS, "copy_gb_s": REF_BOX_COPY_GBS,
-                              "note": "the builder's round-4 box on which profiles/r04_* were taken; value / reference = how fast this box is"},
+            "reference_box": {"gemm_yardstick_tflops": REF_BOX_TFLOPS, "copy_gb_s": REF_BOX_COPY_GBS, "frames_per_s": REF_BOX_FPS,
+                              "note": "the builder's box of profiles/r04_bench_final.json; this box's yardsticks / these = how fast this box is next to it"},
             **(clocks or {"sclk_mhz": None, "mclk_mhz": None})}
 
 
