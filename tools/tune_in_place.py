@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Refine a tile table IN PLACE: the per-shape autotuner times isolated cold launches; here every GEMM shape of the frame is re-decided by
 the frame time itself (replayed launch plan, everything else in its real cache / prefetch context).  Greedy, one shape at a time:
-    python tools/tune_in_place.py <table.json> [out.json] [config] [frames per measurement] [tiles|orders] [HxW] [precision, default bf16]
+    python tools/tune_in_place.py <table.json> [out.json] [config] [frames per measurement] [tiles|orders] [HxW] [precision, default bf16] [frames per forward, default 1]
 A candidate replaces the current variant of a shape only if it beats it in two independent measurements."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,7 @@ frames = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 cand_mode = sys.argv[5] if len(sys.argv) > 5 else "tiles"      # "tiles": the tile shapes of CANDS; "orders": the shape's own tile in the four XCD orders (+0 / +100 / +200 / +300)
 hw = tuple(int(v) for v in sys.argv[6].split("x")) if len(sys.argv) > 6 else (320, 800)
 precision = sys.argv[7] if len(sys.argv) > 7 else "bf16"
+B = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 cfg = configs.get(name)
 m = toc3d_amd.build_backbone(dict(cfg, precision=precision)); m.load_state_dict(synth.make_state_dict(cfg)); m = m.cuda().eval()
 m.alias_outputs, m.autotune = True, False
@@ -23,7 +24,7 @@ m.load_tuning(table)
 neck = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision=precision)); neck.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG)); neck = neck.cuda().eval()
 neck.alias_outputs, neck.autotune = True, False
 neck._tuned = m._tuned                                   # one shared table
-inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
+inp = synth.make_inputs(cfg, n_frames=B, views_per_frame=6, hw=hw)
 kw = {k: inp[k].cuda() for k in ("temp_queries", "temp_ref_points", "temp_vel", "temp_timestamp", "temp_ego_pose", "ego_pose_inv")}
 g = [t.cuda() for t in inp["gumbel"]]
 x = inp["x"].cuda()
@@ -74,7 +75,7 @@ forget_plans(); step(); step()
 lib.call = orig
 torch.cuda.synchronize()
 base = measure()
-print(f"start: {1e3 * base:.4f} ms/frame = {1 / base:.1f} frames/s, {len(used)} GEMM shapes", flush=True)
+print(f"start: {1e3 * base:.4f} ms/forward = {B / base:.1f} frames/s ({B} frame(s) per forward), {len(used)} GEMM shapes", flush=True)
 for key, cur in used.items():
     best_v, best_t = cur, base
     for v in (CANDS if cand_mode == "tiles" else [cur % 100 + o for o in (0, 100, 200, 300)]):
@@ -94,7 +95,7 @@ for key, cur in used.items():
         print(f"  {key}: v{cur} -> v{best_v}   {1e3 * base:.4f} -> {1e3 * best_t:.4f} ms", flush=True)
         base = best_t
 final = measure()
-print(f"end: {1e3 * final:.4f} ms/frame = {1 / final:.1f} frames/s", flush=True)
+print(f"end: {1e3 * final:.4f} ms/forward = {B / final:.1f} frames/s", flush=True)
 os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
 d = json.load(open(table))
 tab = {tuple(k): v for k, v in d["table"]}
