@@ -579,7 +579,7 @@ def main():
         # memory-side bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on
         # gfx950 + WRITE_SIZE, see profiles/r01_gemm_hbm_traffic.json); only valid for the profiled workload
         roof["algorithmic_bytes_per_launch"] = gemm_bytes / gemm_n
-        for tag_ in ("r04", "r03", "r02", "r01"):                      # newest committed PMC pass of this workload (tools/run_gpu_r2prof.sh + tools/summarize_prof.py)
+        for tag_ in ("r04", "r03", "r02", "r01"):                      # newest committed PMC pass of this workload (tools/gpu/profile.sh + tools/summarize_prof.py)
             tpath = os.path.join(ROOT, "profiles", f"{tag_}_gemm_hbm_traffic.json")
             if os.path.exists(tpath) and args.config == "toc3d_faster" and (H, W) == (320, 800) and args.precision == "bf16":
                 tj = json.load(open(tpath))

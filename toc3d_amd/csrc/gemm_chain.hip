@@ -46,7 +46,7 @@ enum { CHAIN_ERR_SPIN = 1, CHAIN_ERR_SCHED = 2 };
 
 // OCC: the kernel's register cap, as gemm_kernel passes it -- a capped tile forms its (mean, rstd) table before anything else of the tile is live.
 // (Round 4: with the table's batch of statistics loads behind the first operand request -- the uncapped form -- family 1 / tiling 0 came back wrong in the
-// lanes hipcc keeps spilled SGPRs in: 46 SGPR + 77 VGPR spills under the 80-register cap, tools/gpu/r4_chain_dbg.py.  No product kernel spills an SGPR.)
+// lanes hipcc keeps spilled SGPRs in: 46 SGPR + 77 VGPR spills under the 80-register cap, tools/gpu/chain_dbg.py.  No product kernel spills an SGPR.)
 template <typename C, int OCC>
 TOC3D_DEV void chain_tile(const GemmArgs& a, int mt, int nt, char* smem) {
     if constexpr (C::EPI >= 0) gemm_tile<bf16_t, C::EPI, C::BM, C::BN, C::STAGES, C::RB, C::WM, C::WN, 0, OCC>(a, mt * C::BM, nt * C::BN, smem);

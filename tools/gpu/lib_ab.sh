@@ -1,4 +1,4 @@
-# round 4: library A/B by frame time: libtoc3d_prev.so (built from HEAD) against libtoc3d_gfx950.so (working tree), N alternations of the default bench step
+# library A/B by frame time: libtoc3d_prev.so (built from HEAD) against libtoc3d_gfx950.so (working tree), N alternations of the default bench step
 export PYTHONUNBUFFERED=1
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -12,11 +12,11 @@ for i in $(seq 1 $N); do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', round(d['value'],2), [round(x,4) for x in d['repetitions']['ms_per_step_each']])"
   done
-done | tee gpurun_out/r4_lib_ab.txt
+done | tee gpurun_out/lib_ab.txt
 python - <<'PY'
 import re
 v={}
-for l in open('gpurun_out/r4_lib_ab.txt'):
+for l in open('gpurun_out/lib_ab.txt'):
     k,x=l.split()[:2]; v.setdefault(k,[]).append(float(x))
 for k,x in v.items(): print(k, 'median', sorted(x)[len(x)//2], 'mean', sum(x)/len(x))
 PY
