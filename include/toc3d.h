@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TOC3D_ABI_VERSION 5   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
+#define TOC3D_ABI_VERSION 6   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
 
 #define TOC3D_OK 0
 #define TOC3D_ERR_ARG (-1)
@@ -50,6 +50,16 @@ extern "C" {
 /* ... and with a THREE-way split (hi, mid, lo = all 24 mantissa bits) and six products hi.hi + hi.mid + mid.hi + mid.mid + hi.lo + lo.hi: f32-grade
  * products (dropped terms <= 2^-26) from 6 bf16 MFMAs instead of 8 f32 ones (precision="fp32x6"). */
 #define TOC3D_DTYPE_F32X6 3
+/* TOC3D_DTYPE_F32X3 on (hi, lo) PLANES (round 4).  The F32X3 kernel splits every operand tile into its bf16 (hi, lo) pair in LDS: 9-15 % of a launch for the
+ * weights, 26-36 % for both operands (profiles/r04_x3_split_cost.txt) -- work that depends on the operand, not on the launch.  A buffer "in planes" has the
+ * size and leading dimension of the f32 buffer; element c of a row lives in the 128-byte group c / 32: hi = bf16(x) at byte 2 (c % 32), lo = bf16(x - hi) at
+ * byte 64 + 2 (c % 32) (toc3d_x3_planes converts; the kernel's own split writes exactly this image into LDS, so results are bit-identical to F32X3).
+ *   F32X3W: W in planes (packed once: toc3d_pack_* with TOC3D_DTYPE_F32, then toc3d_x3_planes in place); A and every output plain f32.
+ *   F32X3P: W and A in planes; the outputs a later GEMM multiplies -- the SwiGLU epilogues' `out`, `out_act` -- are written as planes, all others (bias / GELU /
+ *           residual outputs, statistics) stay f32.  toc3d_layernorm_rows / toc3d_rebase_layernorm_rows / toc3d_gather_merge_ln* / toc3d_window_attention
+ *           take this dtype too: f32 arithmetic, output rows written as planes (they produce the A operands). */
+#define TOC3D_DTYPE_F32X3W 4
+#define TOC3D_DTYPE_F32X3P 5
 
 /* toc3d_linear epilogues */
 #define TOC3D_EPI_BIAS 0      /* out(act)  = A.W^T + bias                                            */
@@ -192,6 +202,10 @@ int toc3d_pack_swiglu_lnfold(int dtype, const float* w1, const float* w2, const 
  * that the mean term cancels exactly what the GEMM accumulated), c2 f32 [N]. */
 int toc3d_pack_weight_lnfold(int dtype, const float* w3, const float* gamma, const float* beta, const float* b3, int64_t N, int64_t K,
                              void* out_w, int64_t Np, int64_t Kp, float* c1, float* c2, toc3d_stream_t stream);
+
+/* f32 rows [rows, K] (leading dim ld_src) -> (hi, lo) planes (TOC3D_DTYPE_F32X3W / F32X3P above) in dst (leading dim ld_dst, a multiple of 32; K a multiple of 32).
+ * dst == src converts in place (equal leading dims). */
+int toc3d_x3_planes(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t K, toc3d_stream_t stream);
 
 /* f32 [N, K] state-dict weight -> act [Np, Kp], zero padded (Np multiple of 128, Kp multiple of 64). */
 int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out, int64_t Np, int64_t Kp, toc3d_stream_t stream);

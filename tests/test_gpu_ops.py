@@ -1116,3 +1116,94 @@ def test_linear_bf16x3_products_on_f32_operands(M, N, K):
     assert relerr(out, torch.nn.functional.gelu(ref)) < 2e-5
     with pytest.raises(RuntimeError, match="bf16 x 3"):
         lib.call("toc3d_linear_fused", lib.F32X6, lib.EPI_RESIDUAL_STATS, 0, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, *lib.NO_FUSED, S())   # (x 3 serves the folded-LayerNorm epilogues 4-7 since rounds 3 / 4; x 6 does not)
+
+
+def to_planes(t):
+    """f32 [rows, K] on the device -> a new buffer in (hi, lo) planes (toc3d_x3_planes, out of place)."""
+    out = torch.empty_like(t)
+    lib.call("toc3d_x3_planes", t, t.shape[1], out, out.shape[1], t.shape[0], t.shape[1], S())
+    return out
+
+
+def planes_decode(p):
+    """(hi, lo) planes -> (hi, lo) as f32 tensors [rows, K] (the layout of include/toc3d.h, TOC3D_DTYPE_F32X3W / F32X3P, read back on the host side)."""
+    rows, K = p.shape
+    b = p.contiguous().view(torch.bfloat16).view(rows, K // 32, 2, 32)
+    return b[:, :, 0, :].reshape(rows, K).float(), b[:, :, 1, :].reshape(rows, K).float()
+
+
+def test_x3_planes_layout_and_in_place():
+    x = (rnd(300, 256, seed=1) * 37.0).to(DEV)
+    p = to_planes(x)
+    hi, lo = planes_decode(p)
+    assert torch.equal(hi, x.to(torch.bfloat16).float()), "hi plane = bf16(x)"
+    assert torch.equal(lo, (x - hi).to(torch.bfloat16).float()), "lo plane = bf16(x - hi)"
+    assert ((hi + lo) - x).abs().max() <= 2.0 ** -16 * x.abs().max()
+    q = x.clone()
+    lib.call("toc3d_x3_planes", q, 256, q, 256, 300, 256, S())       # in place
+    assert torch.equal(q.view(torch.int32), p.view(torch.int32))
+    wide = torch.zeros(300, 320, device=DEV)                           # leading dimension > K: the tail of the row is not touched
+    lib.call("toc3d_x3_planes", x, 256, wide, 320, 300, 256, S())
+    assert torch.equal(wide[:, :256].contiguous().view(torch.int32), p.view(torch.int32)) and torch.count_nonzero(wide[:, 256:]) == 0
+
+
+def test_bf16x3_on_planes_is_bit_identical_to_the_in_kernel_split():
+    """TOC3D_DTYPE_F32X3W / F32X3P (round 4): the same products on operands that arrive as (hi, lo) planes -- W packed once, A written as planes by its
+    producer -- return the bits of TOC3D_DTYPE_F32X3, for the plain epilogues and through the whole folded block half (eva_vit.py:44-51,262-263):
+    proj (+ residual, f32 copy as planes, statistics) -> w1|w2 (norm2 folded; hidden units as planes, statistics) -> w3 (ffn_ln folded, + residual)."""
+    dt, tdt = lib.F32, torch.float32
+    M, C, Hd, Hp = 777, 384, 300, 320
+    eps = 1e-6
+    att = rnd(M, C, seed=1).to(DEV)
+    Wp, bp = rnd(C, C, seed=2, scale=C ** -0.5), rnd(C, seed=3).to(DEV)
+    wproj = pack(Wp, dt, tdt)
+    x0 = (3.0 * rnd(M, C, seed=4) + 0.7).to(DEV)
+    g2, b2 = (1.0 + 0.3 * rnd(C, seed=5)).to(DEV), (0.2 * rnd(C, seed=6)).to(DEV)
+    w1, w2 = rnd(Hd, C, seed=7, scale=C ** -0.5).to(DEV), rnd(Hd, C, seed=8, scale=C ** -0.5).to(DEV)
+    bb1, bb2 = rnd(Hd, seed=9).to(DEV), rnd(Hd, seed=10).to(DEV)
+    w12f = torch.empty(2 * Hp, C, dtype=tdt, device=DEV)
+    c1, c2 = torch.empty(2 * Hp, device=DEV), torch.empty(2 * Hp, device=DEV)
+    lib.call("toc3d_pack_swiglu_lnfold", dt, w1, w2, bb1, bb2, g2, b2, Hd, C, w12f, c1, c2, Hp, C, S())
+    gf, bf = (1.0 + 0.3 * rnd(Hd, seed=11)).to(DEV), (0.2 * rnd(Hd, seed=12)).to(DEV)
+    W3, b3 = rnd(C, Hd, seed=13, scale=Hd ** -0.5).to(DEV), rnd(C, seed=14).to(DEV)
+    w3f = torch.zeros(ru(C, 128), Hp, dtype=tdt, device=DEV)
+    c1_3, c2_3 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    lib.call("toc3d_pack_weight_lnfold", dt, W3.contiguous(), gf, bf, b3, C, Hd, w3f, w3f.shape[0], Hp, c1_3, c2_3, S())
+    cap2, cap = C // 64, 6
+
+    def half(mode, v):
+        """mode 0: F32X3 on f32 buffers; 1: F32X3W (weights as planes); 2: F32X3P (weights, A operands and the GEMM-to-GEMM activations as planes)."""
+        d = (lib.F32X3, lib.F32X3W, lib.F32X3P)[mode]
+        wp, w12, w3 = (wproj, w12f, w3f) if mode == 0 else (to_planes(wproj), to_planes(w12f), to_planes(w3f))
+        a_in = to_planes(att) if mode == 2 else att
+        x = x0.clone()
+        a_raw = torch.full((M, C), 9.0, dtype=tdt, device=DEV)
+        st2 = torch.zeros(4 + M * cap2 * 2, device=DEV)
+        hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
+        st = torch.zeros(4 + M * cap * 2, device=DEV)
+        q = torch.zeros(M, C, device=DEV)
+        lib.call("toc3d_linear_ex", d, lib.EPI_BIAS, v, a_in, C, wp, C, bp, q, C, None, 0, 0, None, None, M, C, C, 0, S())        # a plain epilogue: f32 output in every mode
+        lib.call("toc3d_linear_fused", d, lib.EPI_RESIDUAL_STATS, v, a_in, C, wp, C, bp, x, C, x, C, 0, None, None, M, C, C, 0,
+                 st2, cap2, None, 0, None, 0, 0.0, a_raw, C, None, S())
+        x1 = x.clone()
+        lib.call("toc3d_linear_fused", d, lib.EPI_SWIGLU_STATS_LN, v, a_raw, C, w12, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
+                 st, cap, st2, cap2 | (C // 64) << 32, c1, C, eps, None, 0, None, S())
+        lib.call("toc3d_linear_fused", d, lib.EPI_RESIDUAL_LN, v, hid, Hp, w3, Hp, c2_3, x, C, x, C, 0, None, None, M, C, Hp, 0,
+                 None, 0, st, cap | 5 << 32, c1_3, Hd, eps, None, 0, None, S())
+        return q, x1, a_raw, st2, hid, st, x
+
+    ref = half(0, 16)
+    names = ("bias epilogue", "proj + residual", "f32 copy", "norm2 statistics", "hidden units", "ffn_ln statistics", "w3 + residual")
+    for v in (16, 17, 49, 126, 1):
+        got_w = half(1, v)
+        for n, g_, r_ in zip(names, got_w, ref):
+            assert torch.equal(g_, r_), f"F32X3W variant {v}: {n} differs from F32X3"
+        got_p = half(2, v)
+        for k, (n, g_, r_) in enumerate(zip(names, got_p, ref)):
+            if k in (2, 4):      # the GEMM-to-GEMM activations left as planes: the planes of the f32 values F32X3 wrote
+                assert torch.equal(g_.view(torch.int32), to_planes(r_).view(torch.int32)), f"F32X3P variant {v}: {n} is not the planes image of the F32X3 output"
+            else:
+                assert torch.equal(g_, r_), f"F32X3P variant {v}: {n} differs from F32X3"
+    with pytest.raises(RuntimeError):      # rows of planes are whole 32-element groups
+        bad = torch.zeros(M, C + 8, device=DEV)
+        lib.call("toc3d_linear_ex", lib.F32X3P, lib.EPI_BIAS, 16, bad, C + 8, to_planes(wproj), C, bp, torch.zeros(M, C, device=DEV), C, None, 0, 0, None, None, M, C, C, 0, S())

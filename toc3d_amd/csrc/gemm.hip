@@ -42,6 +42,18 @@ int launch_gemm(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_
 }
 
 // ---- weight packing ---------------------------------------------------------------------------------
+// f32 rows -> (hi, lo) bf16 planes (gemm_kernels.h, store_planes4): eight lanes per 32-element group, 16 bytes in, 8 + 8 bytes out per lane.  In place is fine:
+// a group is read by one load instruction of one wavefront before that wavefront's stores can issue.
+__global__ __launch_bounds__(256) void x3_planes_kernel(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int gpr) {
+    const int64_t grp = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (grp >= rows * gpr) return;
+    const int64_t row = grp / gpr;
+    const int g = (int)(grp % gpr), q = threadIdx.x & 7;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * ld_src + g * 32 + q * 4);
+    const float x[4] = {v[0], v[1], v[2], v[3]};
+    store_planes4(dst + row * ld_dst, g * 32 + q * 4, x);
+}
+
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, int N, int K, T* __restrict__ out, int Np, int Kp) {
     const int64_t total = (int64_t)Np * Kp;
@@ -245,7 +257,10 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
                       float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                       float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
                       void* out_act, int64_t ld_act, const int32_t* residual_index) {
-    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3 || dtype == TOC3D_F32X6, "toc3d_linear: bad dtype %d", dtype);
+    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3 || dtype == TOC3D_F32X6 || dtype == TOC3D_F32X3W || dtype == TOC3D_F32X3P,
+                  "toc3d_linear: bad dtype %d", dtype);
+    const int planes = dtype == TOC3D_F32X3W ? 1 : (dtype == TOC3D_F32X3P ? 2 : 0);      // W as (hi, lo) planes; 2: A too, and the outputs a later GEMM multiplies
+    if (planes) dtype = TOC3D_F32X3;
     const bool x3_fold = dtype == TOC3D_F32X3 && (epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS ||
                                                   epilogue == TOC3D_EPI_SWIGLU_STATS_LN);
     TOC3D_REQUIRE((dtype != TOC3D_F32X3 && dtype != TOC3D_F32X6) || epilogue <= TOC3D_EPI_GELU || epilogue == TOC3D_EPI_CONV3X3 || x3_fold,
@@ -305,7 +320,12 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
     a = GemmArgs{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, vec8 ? 1 : 0,
                stats_out, (int)stats_out_cap, stats_in, (int)(stats_in_cap & 0xffffffff), (int)(stats_in_cap >> 32), col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
-               0, 0, nullptr, nullptr, nullptr, 0, 1.0f};
+               0, 0, nullptr, nullptr, nullptr, 0, 1.0f, planes == 2, planes >= 1, planes == 2};
+    if (planes) {
+        TOC3D_REQUIRE(epilogue != TOC3D_EPI_CONV3X3 || planes == 1, "toc3d_linear: the 3x3 conv gathers f32 activations (TOC3D_DTYPE_F32X3W, not F32X3P)");
+        TOC3D_REQUIRE(planes == 1 || ((!e_swiglu || ldo % 32 == 0) && (!out_act || ld_act % 32 == 0) && lda % 32 == 0),
+                      "toc3d_linear: rows of (hi, lo) planes are whole 32-element groups: lda, ldo (SwiGLU) and ld_act must be multiples of 32");
+    }
     if (epilogue == TOC3D_EPI_CONV3X3) {
         // A = NHWC act tensor [V, h, w, lda]; ld_act carries h << 32 | w and out_act the zero line (toc3d_conv3x3_nhwc fills them in)
         a.conv_h = (int)(ld_act >> 32); a.conv_w = (int)(ld_act & 0xffffffff); a.zeros = out_act;
@@ -326,7 +346,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     if (rc_args != TOC3D_OK) return rc_args;
     if (M == 0) return TOC3D_OK;
     g_bad_variant = false;
-    int rc = dtype == TOC3D_F32X3 ? toc3d_gemm_launch_x3(epilogue, variant, a, as_stream(stream))
+    int rc = (dtype == TOC3D_F32X3 || dtype == TOC3D_F32X3W || dtype == TOC3D_F32X3P) ? toc3d_gemm_launch_x3(epilogue, variant, a, as_stream(stream))
              : dtype == TOC3D_F32X6 ? toc3d_gemm_launch_x6(epilogue, variant, a, as_stream(stream)) : launch_gemm(dtype == TOC3D_BF16, epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
     if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab not a multiple of 32, or N-tile not a multiple of 128 for the statistics)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }
@@ -456,6 +476,17 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
                  toc3d_stream_t stream) {
     return toc3d_linear_ex(dtype, epilogue, 0, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index,
                            M, N, K, n_valid, stream);
+}
+
+int toc3d_x3_planes(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t K, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(src && dst && rows >= 0 && K > 0 && K % 32 == 0 && ld_src >= K && ld_dst >= K && ld_dst % 32 == 0, "toc3d_x3_planes: K and ld_dst are multiples of 32, leading dims >= K");
+    TOC3D_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0 && ld_src % 4 == 0, "toc3d_x3_planes: 16-byte aligned rows");
+    TOC3D_REQUIRE(src != dst || ld_src == ld_dst, "toc3d_x3_planes: in place needs equal leading dims");
+    if (rows == 0) return TOC3D_OK;
+    const int64_t groups = rows * (K / 32);
+    toc3d_launch(x3_planes_kernel, dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, as_stream(stream), src, ld_src, dst, ld_dst, rows, (int)(K / 32));
+    TOC3D_LAUNCH_CHECK("toc3d_x3_planes");
+    return TOC3D_OK;
 }
 
 int toc3d_pack_weight(int dtype, const float* w, int64_t N, int64_t K, void* out, int64_t Np, int64_t Kp, toc3d_stream_t stream) {

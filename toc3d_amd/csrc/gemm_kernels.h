@@ -47,6 +47,9 @@ struct GemmArgs {
     const int32_t* rope_rc;                              // [M] (table row of dims 0..31) << 16 | (table row of dims 32..63)
     const float* rope_tab;                               // compact axial tables [cos | sin][2][rope_L][16]
     int rope_L; float rope_scale;
+    // bf16 x 3 on (hi, lo) PLANES (TOC3D_DTYPE_F32X3W / F32X3P, include/toc3d.h): an operand that already is in the planes layout is DMA'd as it lies and
+    // not split in LDS; out_planes: the act-dtype outputs that a later GEMM multiplies (SwiGLU hidden units, out_act) are written as planes
+    int a_planes, w_planes, out_planes;
 };
 
 extern thread_local bool g_bad_variant;                // set by a launch_cfg whose tile variant cannot serve the requested epilogue (gemm.hip)
@@ -291,6 +294,29 @@ TOC3D_DEV void store_pair_wide(bf16_t* dst_a, bf16_t* dst_b, Pack4 pa, Pack4 pb,
 }
 TOC3D_DEV void store_pair_wide(float*, float*, Pack4, Pack4, bool, bool, int) {}
 
+// (hi, lo) bf16 planes of a row of f32 values (the A / W operand layout of the bf16 x 3 GEMM once split: split_rows_x3 below): element c of the row lives in
+// the 128-byte group c / 32 -- hi = bf16(x) at byte 2 (c % 32), lo = bf16(x - hi) at byte 64 + 2 (c % 32).  Same bytes per row as f32, same arithmetic as the
+// in-LDS split, so a GEMM on planes returns the bits of the GEMM that splits.  col % 4 == 0.
+TOC3D_DEV void store_planes4(float* row, int col, const float (&v)[4]) {
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16_t h = (bf16_t)v[e];
+        hi[e] = h;
+        lo[e] = (bf16_t)(v[e] - (float)h);
+    }
+    char* p = reinterpret_cast<char*>(row) + (col >> 5) * 128 + (col & 31) * 2;
+    *reinterpret_cast<bf16x4_t*>(p) = hi;
+    *reinterpret_cast<bf16x4_t*>(p + 64) = lo;
+}
+TOC3D_DEV void store_planes1(float* row, int col, float v) {
+    const bf16_t h = (bf16_t)v;
+    char* p = reinterpret_cast<char*>(row) + (col >> 5) * 128 + (col & 31) * 2;
+    *reinterpret_cast<bf16_t*>(p) = h;
+    *reinterpret_cast<bf16_t*>(p + 64) = (bf16_t)(v - (float)h);
+}
+
 // ---- epilogue of one wavefront's (MT*16) x (NT*16) accumulator block whose first row / column are row0 / col0.  The MFMA is issued
 // with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
 // .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
@@ -370,7 +396,12 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                 if (in) {
                     const int unit0 = ((col0 + jp * 32 + g * 4) >> 5) * 16 + g * 4;
                     T* dst = out + (int64_t)(row0 + i * 16 + r16) * a.ldo + unit0;
-                    if (a.vec) epi_store4(dst, hs);
+                    bool planes = false;
+                    if constexpr (sizeof(T) == 4) {
+                        if (a.out_planes) { store_planes4(reinterpret_cast<float*>(dst - unit0), unit0, hs); planes = true; }
+                    }
+                    if (planes) {}
+                    else if (a.vec) epi_store4(dst, hs);
                     else { dst[0] = hs[0]; dst[1] = hs[1]; dst[2] = hs[2]; dst[3] = hs[3]; }
                 }
                 if (epi_stats_out(EPI)) { gs[i * G + jp] = ssum; gq[i * G + jp] = sq; }
@@ -526,7 +557,16 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                         ssum += hv;
                         sq = __builtin_fmaf(hv, hv, sq);
                     }
-                    if (nok[j] == 4) epi_store4(arow, o4);
+                    bool planes = false;
+                    if constexpr (sizeof(T) == 4) {
+                        if (a.out_planes) {
+                            if (nok[j] == 4) store_planes4(reinterpret_cast<float*>(arow - col), col, o4);
+                            else for (int r = 0; r < nok[j]; ++r) store_planes1(reinterpret_cast<float*>(arow - col), col + r, o4[r]);
+                            planes = true;
+                        }
+                    }
+                    if (planes) {}
+                    else if (nok[j] == 4) epi_store4(arow, o4);
                     else for (int r = 0; r < nok[j]; ++r) arow[r] = o4[r];
                     if (EPI == TOC3D_EPI_RESIDUAL_STATS) {
                         gs[i * G + j] = ssum;
@@ -833,12 +873,14 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
                 constexpr int PA = BM * CPR / NTHR;
                 const int cidx = (u < PA ? u : u - PA) * NTHR + wave * 64 + lane;
                 pos[u] = (u < PA ? 0 : BM * CPR) + cidx;                    // chunk position in the stage (row * CPR + stored chunk)
+                if (u < PA ? a.a_planes : a.w_planes) continue;             // the operand came as planes (wave-uniform): nothing to split
                 v[u] = *reinterpret_cast<const f32x4*>(slot + pos[u] * 16);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
+                if (u < BM * CPR / NTHR ? a.a_planes : a.w_planes) continue;
                 const int row = pos[u] / CPR, p = pos[u] % CPR;
                 const int rt = row < BM ? row : row - BM;                  // tile-local row: the swizzle of stage_tile
                 const int sw = swz<RB>(rt);
