@@ -596,3 +596,23 @@ def test_full_size_neck_matches_oracle(precision, tol):
     for _ in range(3):                                                 # eager, recorded, replayed
         m0, _ = neck([nhwc.permute(0, 3, 1, 2)])
     assert torch.equal(m0, n0)
+
+
+@pytest.mark.parametrize("name,prev", [("toc3d_tiny", True), ("toc3d_tiny", False), ("toc3d_faster", True), ("eva_dense", True)])
+def test_fp32x3_on_planes_is_bit_identical_to_the_in_kernel_split(name, prev):
+    """precision="fp32x3" ships with its GEMM operands as (hi, lo) bf16 planes (schedule switch x3_planes: weights packed once, activations written as planes by
+    their producers; include/toc3d.h TOC3D_DTYPE_F32X3W / F32X3P).  Same arithmetic as the in-LDS split of TOC3D_DTYPE_F32X3: the whole forward returns the
+    same bits (eager forward and replayed plan)."""
+    cfg = configs.get(name)
+    sd = synth.make_state_dict(cfg)
+    inp = synth.make_inputs(cfg, views_per_frame=2 if name == "toc3d_tiny" else 6)
+    outs = []
+    for planes in (False, True):
+        m = toc3d_amd.build_backbone(dict(cfg, precision="fp32x3", schedule=dict(x3_planes=planes)))
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV).eval()
+        assert m.x3_planes is planes
+        for _ in range(3):                   # eager, recording, replay
+            o = run_toc3d(m, inp, prev) if synth.is_toc3d(cfg) else m(inp["x"].to(DEV))
+        outs.append((o.img_feats["last_feat"] if synth.is_toc3d(cfg) else o["last_feat"]).clone())
+    assert torch.equal(outs[0], outs[1]), f"max abs difference {(outs[0] - outs[1]).abs().max().item():.3e}"

@@ -166,7 +166,7 @@ _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28,
                         154, 155, 156, 158, 159, 163),
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126),
              lib.F32X3: (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 114, 116, 117, 122, 126, 149)}
-_VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3]
+_VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3W] = _VARIANTS[lib.F32X3P] = _VARIANTS[lib.F32X3]
 
 
 def schedule_defaults(precision):
@@ -178,6 +178,7 @@ def schedule_defaults(precision):
     bf16 = precision == "bf16"
     fast = precision in ("bf16", "fp32x3")
     return dict(
+        x3_planes=precision == "fp32x3",   # fp32x3: packed weights, the GEMMs' A operands and the GEMM-to-GEMM activations as (hi, lo) bf16 planes (TOC3D_DTYPE_F32X3W / F32X3P)
         carry_compact=fast,          # consecutive accelerated blocks of one window type continue on the same compact rows (_accel_block)
         fold_ffn_ln=fast,            # SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused)
         fold_norm2=fast,             # norm2 folded across the attention-projection -> w1|w2 boundary the same way
@@ -193,14 +194,16 @@ def schedule_defaults(precision):
     )
 
 
-def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED):
+def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED, a_planes=False):
     """toc3d_linear_fused with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
     real operands the first time the shape is seen (never while a launch plan is being recorded: shapes are warmed up eagerly).
     ``self`` = the owner of the table: anything with ``_tuned`` (dict), ``autotune`` (bool) and ``_dt`` (the backbones, the neck).
     All variants accumulate K in the same order, so the choice does not change results."""
     global _flush
     dtg = getattr(self, "_dt_gemm", None)
-    dtg = self._dt if dtg is None else dtg                 # the linear layers' arithmetic: _dt, or F32X3 on the "fp32x3" precision
+    dtg = self._dt if dtg is None else dtg                 # the linear layers' arithmetic: _dt, or F32X3 / F32X3W on the "fp32x3" precision
+    if a_planes and dtg == lib.F32X3W:                      # A was written as (hi, lo) planes by its producer; this launch's GEMM-to-GEMM outputs leave as planes too
+        dtg = lib.F32X3P
     key = (epi, M, N, K)
     var = self._tuned.get(key)
     s = lib.stream_ptr()
@@ -369,7 +372,14 @@ class _BackboneBase(nn.Module):
     def _dt_gemm(self):
         """Arithmetic of the linear layers: "fp32x3" keeps every buffer in f32 and forms the GEMM products as three bf16 MFMAs on the operands'
         (hi, lo) splits (include/toc3d.h TOC3D_DTYPE_F32X3) -- the parity-grade path at a third of the bf16 MFMA rate instead of a sixteenth."""
-        return {"fp32x3": lib.F32X3, "fp32x6": lib.F32X6}.get(self.precision, self._dt)
+        return {"fp32x3": lib.F32X3W if self.x3_planes else lib.F32X3, "fp32x6": lib.F32X6}.get(self.precision, self._dt)
+
+    def _planes(self, w):
+        """fp32x3 with x3_planes: a packed f32 weight -> (hi, lo) bf16 planes, in place (include/toc3d.h, TOC3D_DTYPE_F32X3W): the GEMM then DMAs the planes
+        instead of splitting the W tile in LDS in every workgroup of every launch."""
+        if self.precision == "fp32x3" and self.x3_planes:
+            lib.call("toc3d_x3_planes", w, w.shape[1], w, w.shape[1], w.shape[0], w.shape[1], lib.stream_ptr())
+        return w
 
     @property
     def _tdt(self):
@@ -385,7 +395,7 @@ class _BackboneBase(nn.Module):
         Np, Kp = _round_up(N, 128), _round_up(K, 64)
         out = torch.empty(Np, Kp, dtype=self._tdt, device=w.device)
         lib.call("toc3d_pack_weight", self._dt, w, N, K, out, Np, Kp, lib.stream_ptr())
-        return out
+        return self._planes(out)
 
     @staticmethod
     def _f32(t):
@@ -409,7 +419,7 @@ class _BackboneBase(nn.Module):
             b12 = torch.empty(2 * Hp, dtype=torch.float32, device=dev)
             lib.call("toc3d_pack_swiglu", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias),
                      self._f32(m.w2.bias), Hd, C, w12, b12, Hp, C, lib.stream_ptr())
-            p["w12"], p["b12"] = w12, b12
+            p["w12"], p["b12"] = w12, b12                         # (-> planes below, after the lnfold pack may have rewritten it)
             if self.fold_norm2:                                   # gamma2-scaled interleaved weights + (c1, c2) in packed column order; replaces w12 / b12
                 p["c1_12"], p["c2_12"] = torch.empty(2 * Hp, device=dev), torch.empty(2 * Hp, device=dev)
                 lib.call("toc3d_pack_swiglu_lnfold", self._dt, self._f32(m.w1.weight), self._f32(m.w2.weight), self._f32(m.w1.bias), self._f32(m.w2.bias),
@@ -420,9 +430,10 @@ class _BackboneBase(nn.Module):
                 p["c1"], p["c2"] = torch.empty(N3, device=dev), torch.empty(N3, device=dev)
                 lib.call("toc3d_pack_weight_lnfold", self._dt, self._f32(m.w3.weight), self._f32(m.ffn_ln.weight), self._f32(m.ffn_ln.bias),
                          self._f32(m.w3.bias), N3, K3, w3f, w3f.shape[0], Hp, p["c1"], p["c2"], lib.stream_ptr())
-                p["w3"] = w3f                                     # gamma-scaled; c1 / c2 carry the mean and beta / bias terms
+                p["w3"] = self._planes(w3f)                       # gamma-scaled; c1 / c2 carry the mean and beta / bias terms
             else:
                 p["w3"], p["b3"] = self._pack_linear(m.w3.weight), self._f32(m.w3.bias)
+            self._planes(w12)
             for n, mod in (("ln1", blk.norm1), ("ln2", blk.norm2), ("lnf", m.ffn_ln)):
                 p[n + "_w"], p[n + "_b"] = self._f32(mod.weight), self._f32(mod.bias)
             p["cos"], p["sin"] = self._f32(a.rope.freqs_cos), self._f32(a.rope.freqs_sin)
@@ -530,8 +541,8 @@ class _BackboneBase(nn.Module):
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
-    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED):
-        tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused)
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED, a_planes=False):
+        tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused, a_planes)
 
     def save_packed(self, path):
         """Write the packed device weights (what the kernels consume) to a safetensors file; see ``packed_io``."""

@@ -58,7 +58,7 @@ class CPFPN(nn.Module):
 
     @property
     def _dt_gemm(self):
-        return {"fp32x3": lib.F32X3, "fp32x6": lib.F32X6}.get(self.precision, self._dt)
+        return {"fp32x3": lib.F32X3W, "fp32x6": lib.F32X6}.get(self.precision, self._dt)      # fp32x3: weights as (hi, lo) planes (include/toc3d.h)
 
     def load_state_dict(self, *a, **k):
         self._packed = None
@@ -101,6 +101,8 @@ class CPFPN(nn.Module):
             N, K = w2d.shape
             out = torch.empty(_round_up(N, 128), _round_up(K, 64), dtype=tdt, device=dev)
             lib.call("toc3d_pack_weight", dt, w2d, N, K, out, out.shape[0], out.shape[1], s)
+            if self.precision == "fp32x3":
+                lib.call("toc3d_x3_planes", out, out.shape[1], out, out.shape[1], out.shape[0], out.shape[1], s)
             return out
 
         lw = self.lateral_convs[0].conv

@@ -66,6 +66,7 @@ def fingerprint(model) -> Dict[str, Any]:
               fold_ffn_ln=bool(getattr(model, "fold_ffn_ln", False)),      # w3 packed gamma-scaled + c1 / c2 instead of w3 / b3
               fold_norm2=bool(getattr(model, "fold_norm2", False)),        # w12 packed gamma2-scaled + c1_12 / c2_12
               attn_rot=bool(getattr(model, "attn_rot", False)),            # compact RoPE tables + per-slot rotated pad rows (pad_rot)
+              x3_planes=bool(getattr(model, "x3_planes", False)),          # fp32x3: GEMM weights stored as (hi, lo) bf16 planes
               abi=int(lib.load().toc3d_abi_version()))
     for k in ("pruning_loc", "token_ratio", "pruning_num_queries", "accelerate_global", "pruning_attn_scale"):
         if hasattr(model, k):
