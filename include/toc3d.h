@@ -60,6 +60,10 @@ extern "C" {
  *           take this dtype too: f32 arithmetic, output rows written as planes (they produce the A operands). */
 #define TOC3D_DTYPE_F32X3W 4
 #define TOC3D_DTYPE_F32X3P 5
+/* ... the two mixed forms: F32X3WO = W in planes, A plain f32, the GEMM-to-GEMM outputs as planes (a producer whose own A is not split yet);
+ * F32X3WA = W and A in planes, every output plain f32. */
+#define TOC3D_DTYPE_F32X3WO 6
+#define TOC3D_DTYPE_F32X3WA 7
 
 /* toc3d_linear epilogues */
 #define TOC3D_EPI_BIAS 0      /* out(act)  = A.W^T + bias                                            */

@@ -1172,8 +1172,10 @@ def test_bf16x3_on_planes_is_bit_identical_to_the_in_kernel_split():
     cap2, cap = C // 64, 6
 
     def half(mode, v):
-        """mode 0: F32X3 on f32 buffers; 1: F32X3W (weights as planes); 2: F32X3P (weights, A operands and the GEMM-to-GEMM activations as planes)."""
-        d = (lib.F32X3, lib.F32X3W, lib.F32X3P)[mode]
+        """mode 0: F32X3 on f32 buffers; 1: F32X3W (weights as planes); 2: F32X3P (weights, A operands and the GEMM-to-GEMM activations as planes);
+        3: the mixed forms, as a block whose attention output is still f32 launches them: proj F32X3WO, w1|w2 F32X3P, w3 F32X3WA."""
+        d = (lib.F32X3, lib.F32X3W, lib.F32X3P, lib.F32X3WO)[mode]
+        d12, d3 = (d, d) if mode < 3 else (lib.F32X3P, lib.F32X3WA)
         wp, w12, w3 = (wproj, w12f, w3f) if mode == 0 else (to_planes(wproj), to_planes(w12f), to_planes(w3f))
         a_in = to_planes(att) if mode == 2 else att
         x = x0.clone()
@@ -1186,9 +1188,9 @@ def test_bf16x3_on_planes_is_bit_identical_to_the_in_kernel_split():
         lib.call("toc3d_linear_fused", d, lib.EPI_RESIDUAL_STATS, v, a_in, C, wp, C, bp, x, C, x, C, 0, None, None, M, C, C, 0,
                  st2, cap2, None, 0, None, 0, 0.0, a_raw, C, None, S())
         x1 = x.clone()
-        lib.call("toc3d_linear_fused", d, lib.EPI_SWIGLU_STATS_LN, v, a_raw, C, w12, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
+        lib.call("toc3d_linear_fused", d12, lib.EPI_SWIGLU_STATS_LN, v, a_raw, C, w12, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,
                  st, cap, st2, cap2 | (C // 64) << 32, c1, C, eps, None, 0, None, S())
-        lib.call("toc3d_linear_fused", d, lib.EPI_RESIDUAL_LN, v, hid, Hp, w3, Hp, c2_3, x, C, x, C, 0, None, None, M, C, Hp, 0,
+        lib.call("toc3d_linear_fused", d3, lib.EPI_RESIDUAL_LN, v, hid, Hp, w3, Hp, c2_3, x, C, x, C, 0, None, None, M, C, Hp, 0,
                  None, 0, st, cap | 5 << 32, c1_3, Hd, eps, None, 0, None, S())
         return q, x1, a_raw, st2, hid, st, x
 
@@ -1198,12 +1200,13 @@ def test_bf16x3_on_planes_is_bit_identical_to_the_in_kernel_split():
         got_w = half(1, v)
         for n, g_, r_ in zip(names, got_w, ref):
             assert torch.equal(g_, r_), f"F32X3W variant {v}: {n} differs from F32X3"
-        got_p = half(2, v)
-        for k, (n, g_, r_) in enumerate(zip(names, got_p, ref)):
-            if k in (2, 4):      # the GEMM-to-GEMM activations left as planes: the planes of the f32 values F32X3 wrote
-                assert torch.equal(g_.view(torch.int32), to_planes(r_).view(torch.int32)), f"F32X3P variant {v}: {n} is not the planes image of the F32X3 output"
-            else:
-                assert torch.equal(g_, r_), f"F32X3P variant {v}: {n} differs from F32X3"
+        for mode, tag in ((2, "F32X3P"), (3, "F32X3WO / P / WA")):
+            got_p = half(mode, v)
+            for k, (n, g_, r_) in enumerate(zip(names, got_p, ref)):
+                if k in (2, 4):      # the GEMM-to-GEMM activations left as planes: the planes of the f32 values F32X3 wrote
+                    assert torch.equal(g_.view(torch.int32), to_planes(r_).view(torch.int32)), f"{tag} variant {v}: {n} is not the planes image of the F32X3 output"
+                else:
+                    assert torch.equal(g_, r_), f"{tag} variant {v}: {n} differs from F32X3"
     with pytest.raises(RuntimeError):      # rows of planes are whole 32-element groups
         bad = torch.zeros(M, C + 8, device=DEV)
         lib.call("toc3d_linear_ex", lib.F32X3P, lib.EPI_BIAS, 16, bad, C + 8, to_planes(wproj), C, bp, torch.zeros(M, C, device=DEV), C, None, 0, 0, None, None, M, C, C, 0, S())

@@ -166,7 +166,7 @@ _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28,
                         154, 155, 156, 158, 159, 163),
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126),
              lib.F32X3: (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 114, 116, 117, 122, 126, 149)}
-_VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3W] = _VARIANTS[lib.F32X3P] = _VARIANTS[lib.F32X3]
+_VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3W] = _VARIANTS[lib.F32X3P] = _VARIANTS[lib.F32X3WO] = _VARIANTS[lib.F32X3WA] = _VARIANTS[lib.F32X3]
 
 
 def schedule_defaults(precision):
@@ -194,7 +194,7 @@ def schedule_defaults(precision):
     )
 
 
-def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED, a_planes=False):
+def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED, a_planes=False, o_planes=False):
     """toc3d_linear_fused with the fastest tile/pipeline variant for this (epilogue, M, N, K), measured once on the
     real operands the first time the shape is seen (never while a launch plan is being recorded: shapes are warmed up eagerly).
     ``self`` = the owner of the table: anything with ``_tuned`` (dict), ``autotune`` (bool) and ``_dt`` (the backbones, the neck).
@@ -202,8 +202,8 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
     global _flush
     dtg = getattr(self, "_dt_gemm", None)
     dtg = self._dt if dtg is None else dtg                 # the linear layers' arithmetic: _dt, or F32X3 / F32X3W on the "fp32x3" precision
-    if a_planes and dtg == lib.F32X3W:                      # A was written as (hi, lo) planes by its producer; this launch's GEMM-to-GEMM outputs leave as planes too
-        dtg = lib.F32X3P
+    if dtg == lib.F32X3W:                                   # fp32x3 on (hi, lo) planes: W always; A when its producer wrote planes; the SwiGLU hidden units / out_act when the consuming GEMM reads planes
+        dtg = {(False, False): lib.F32X3W, (True, False): lib.F32X3WA, (False, True): lib.F32X3WO, (True, True): lib.F32X3P}[(bool(a_planes), bool(o_planes))]
     key = (epi, M, N, K)
     var = self._tuned.get(key)
     s = lib.stream_ptr()
@@ -541,8 +541,13 @@ class _BackboneBase(nn.Module):
         return plan
 
     # -- linear layers with a per-shape autotuned tile variant -----------------------------------------------
-    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED, a_planes=False):
-        tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused, a_planes)
+    def _linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused=lib.NO_FUSED, a_planes=False, o_planes=False):
+        tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused, a_planes, o_planes)
+
+    @property
+    def _x3p(self):
+        """fp32x3 with its GEMM operands as (hi, lo) planes (schedule switch x3_planes)."""
+        return self.precision == "fp32x3" and self.x3_planes
 
     def save_packed(self, path):
         """Write the packed device weights (what the kernels consume) to a safetensors file; see ``packed_io``."""
@@ -641,10 +646,11 @@ class _BackboneBase(nn.Module):
         res = out if res is None else res
         if self.fold_norm2:
             self._linear(lib.EPI_RESIDUAL_STATS, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
-                         fused=(plan["stats2"], plan["stats2_cap"], None, 0, None, 0, 0.0, plan["a"], C, res_index))
+                         fused=(plan["stats2"], plan["stats2_cap"], None, 0, None, 0, 0.0, plan["a"], C, res_index),
+                         a_planes=self._x3p and plan.get("att_planes", False), o_planes=self._x3p)     # the f32 copy leaves as planes: the w1|w2 GEMM's A operand
         else:
             self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
-                         fused=lib.NO_FUSED[:9] + (res_index,))
+                         fused=lib.NO_FUSED[:9] + (res_index,), a_planes=self._x3p and plan.get("att_planes", False))
 
     def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
         """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
@@ -658,13 +664,15 @@ class _BackboneBase(nn.Module):
             st, cap = plan["stats"], plan["stats_cap"]
             if self.fold_norm2:
                 self._linear(lib.EPI_SWIGLU_STATS_LN, plan["a"], C, bp["w12"], C, bp["c2_12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                             fused=(st, cap, plan["stats2"], plan["stats2_cap"] | (C // 64) << 32, bp["c1_12"], C, self.LN_EPS, None, 0, None))
+                             fused=(st, cap, plan["stats2"], plan["stats2_cap"] | (C // 64) << 32, bp["c1_12"], C, self.LN_EPS, None, 0, None),
+                             a_planes=self._x3p, o_planes=self._x3p)       # A = the projection's copy (planes), hidden units as planes for w3
             else:
                 lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
                 self._linear(lib.EPI_SWIGLU_STATS, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd,
-                             fused=(st, cap, None, 0, None, 0, 0.0, None, 0, None))
+                             fused=(st, cap, None, 0, None, 0, 0.0, None, 0, None), o_planes=self._x3p)
             self._linear(lib.EPI_RESIDUAL_LN, plan["hid"], Hp, bp["w3"], bp["w3"].shape[1], bp["c2"], res, C, res, C, 0,
-                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, st, cap | (-(-2 * Hp // 128)) << 32, bp["c1"], Hd, self.LN_EPS, None, 0, None))
+                         rep_out, rep_index, rows, C, Hp, 0, fused=(None, 0, st, cap | (-(-2 * Hp // 128)) << 32, bp["c1"], Hd, self.LN_EPS, None, 0, None),
+                         a_planes=self._x3p)
             return
         lib.call("toc3d_layernorm_rows", dt, res, C, None, None, bp["ln2_w"], bp["ln2_b"], self.LN_EPS, plan["a"], C, rows, C, s)
         self._linear(lib.EPI_SWIGLU, plan["a"], C, bp["w12"], C, bp["b12"], plan["hid"], Hp, None, 0, 0, None, None, rows, 2 * Hp, C, Hd)

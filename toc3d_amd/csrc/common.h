@@ -17,7 +17,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define TOC3D_DEV __device__ __forceinline__
 
-enum { TOC3D_F32 = 0, TOC3D_BF16 = 1, TOC3D_F32X3 = 2, TOC3D_F32X6 = 3, TOC3D_F32X3W = 4, TOC3D_F32X3P = 5 };       // F32X3: f32 buffers, GEMM products as three bf16 MFMAs (linear layers only)
+enum { TOC3D_F32 = 0, TOC3D_BF16 = 1, TOC3D_F32X3 = 2, TOC3D_F32X6 = 3, TOC3D_F32X3W = 4, TOC3D_F32X3P = 5, TOC3D_F32X3WO = 6, TOC3D_F32X3WA = 7 };       // F32X3: f32 buffers, GEMM products as three bf16 MFMAs (linear layers only)
 
 // ---- element traits -------------------------------------------------------------------------------
 template <typename T> struct Frag;

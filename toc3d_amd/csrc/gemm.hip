@@ -257,9 +257,11 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
                       float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                       float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
                       void* out_act, int64_t ld_act, const int32_t* residual_index) {
-    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3 || dtype == TOC3D_F32X6 || dtype == TOC3D_F32X3W || dtype == TOC3D_F32X3P,
+    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3 || dtype == TOC3D_F32X6 || (dtype >= TOC3D_F32X3W && dtype <= TOC3D_F32X3WA),
                   "toc3d_linear: bad dtype %d", dtype);
-    const int planes = dtype == TOC3D_F32X3W ? 1 : (dtype == TOC3D_F32X3P ? 2 : 0);      // W as (hi, lo) planes; 2: A too, and the outputs a later GEMM multiplies
+    // bf16 x 3 on (hi, lo) planes: W always; A (F32X3P, F32X3WA); the outputs a later GEMM multiplies (F32X3P, F32X3WO)
+    const bool planes = dtype >= TOC3D_F32X3W && dtype <= TOC3D_F32X3WA;
+    const bool planes_a = dtype == TOC3D_F32X3P || dtype == TOC3D_F32X3WA, planes_o = dtype == TOC3D_F32X3P || dtype == TOC3D_F32X3WO;
     if (planes) dtype = TOC3D_F32X3;
     const bool x3_fold = dtype == TOC3D_F32X3 && (epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS ||
                                                   epilogue == TOC3D_EPI_SWIGLU_STATS_LN);
@@ -320,10 +322,10 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
     a = GemmArgs{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, vec8 ? 1 : 0,
                stats_out, (int)stats_out_cap, stats_in, (int)(stats_in_cap & 0xffffffff), (int)(stats_in_cap >> 32), col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
-               0, 0, nullptr, nullptr, nullptr, 0, 1.0f, planes == 2, planes >= 1, planes == 2};
+               0, 0, nullptr, nullptr, nullptr, 0, 1.0f, planes_a, planes, planes_o};
     if (planes) {
-        TOC3D_REQUIRE(epilogue != TOC3D_EPI_CONV3X3 || planes == 1, "toc3d_linear: the 3x3 conv gathers f32 activations (TOC3D_DTYPE_F32X3W, not F32X3P)");
-        TOC3D_REQUIRE(planes == 1 || ((!e_swiglu || ldo % 32 == 0) && (!out_act || ld_act % 32 == 0) && lda % 32 == 0),
+        TOC3D_REQUIRE(epilogue != TOC3D_EPI_CONV3X3 || !planes_a, "toc3d_linear: the 3x3 conv gathers f32 activations (A cannot be planes)");
+        TOC3D_REQUIRE((!planes_o || ((!e_swiglu || ldo % 32 == 0) && (!out_act || ld_act % 32 == 0))) && (!planes_a || lda % 32 == 0),
                       "toc3d_linear: rows of (hi, lo) planes are whole 32-element groups: lda, ldo (SwiGLU) and ld_act must be multiples of 32");
     }
     if (epilogue == TOC3D_EPI_CONV3X3) {
@@ -346,7 +348,7 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     if (rc_args != TOC3D_OK) return rc_args;
     if (M == 0) return TOC3D_OK;
     g_bad_variant = false;
-    int rc = (dtype == TOC3D_F32X3 || dtype == TOC3D_F32X3W || dtype == TOC3D_F32X3P) ? toc3d_gemm_launch_x3(epilogue, variant, a, as_stream(stream))
+    int rc = (dtype == TOC3D_F32X3 || (dtype >= TOC3D_F32X3W && dtype <= TOC3D_F32X3WA)) ? toc3d_gemm_launch_x3(epilogue, variant, a, as_stream(stream))
              : dtype == TOC3D_F32X6 ? toc3d_gemm_launch_x6(epilogue, variant, a, as_stream(stream)) : launch_gemm(dtype == TOC3D_BF16, epilogue, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear: bad epilogue %d or variant %d", epilogue, variant); return rc; }
     if (g_bad_variant) { toc3d_set_error("toc3d_linear: variant %d cannot serve epilogue %d (per-wave column slab not a multiple of 32, or N-tile not a multiple of 128 for the statistics)", variant, epilogue); return TOC3D_ERR_UNSUPPORTED; }

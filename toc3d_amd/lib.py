@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
 ABI_VERSION = 6                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
-F32, BF16, F32X3, F32X6, F32X3W, F32X3P = 0, 1, 2, 3, 4, 5          # F32X3: linear layers only -- f32 buffers, products as three bf16 MFMAs (include/toc3d.h)
+F32, BF16, F32X3, F32X6, F32X3W, F32X3P, F32X3WO, F32X3WA = 0, 1, 2, 3, 4, 5, 6, 7          # F32X3: linear layers only -- f32 buffers, products as three bf16 MFMAs (include/toc3d.h)
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF = 10, 11, 12, 13
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3

@@ -1,6 +1,6 @@
 export PYTHONUNBUFFERED=1
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_e2e.py -m gpu -q -x --tb=short -p no:cacheprovider -k "planes or (fp32x3 and vitl and faster) or packed" 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_ops.py -m gpu -q -x --tb=short -p no:cacheprovider -k "planes or (fp32x3 and vitl and faster) or packed" 2>&1 | tail -8
 for P in 0 1; do
 X3P=$P timeout 600 python - <<'PY'
 import os, torch, toc3d_amd
