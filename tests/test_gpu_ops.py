@@ -1210,3 +1210,18 @@ def test_bf16x3_on_planes_is_bit_identical_to_the_in_kernel_split():
     with pytest.raises(RuntimeError):      # rows of planes are whole 32-element groups
         bad = torch.zeros(M, C + 8, device=DEV)
         lib.call("toc3d_linear_ex", lib.F32X3P, lib.EPI_BIAS, 16, bad, C + 8, to_planes(wproj), C, bp, torch.zeros(M, C, device=DEV), C, None, 0, 0, None, None, M, C, C, 0, S())
+
+
+def test_layernorm_rows_writes_planes():
+    """toc3d_layernorm_rows with TOC3D_DTYPE_F32X3P: the f32 result written as (hi, lo) planes (the q|k|v GEMM's A operand on the fp32x3 path) is the planes
+    image of the f32 kernel's output; misaligned rows are refused."""
+    M, C = 333, 384
+    x = (rnd(M, C, seed=1) * 3.0 + 0.5).to(DEV)
+    g, b = (1.0 + 0.3 * rnd(C, seed=2)).to(DEV), (0.2 * rnd(C, seed=3)).to(DEV)
+    o32, opl = torch.zeros(M, C, device=DEV), torch.zeros(M, C, device=DEV)
+    lib.call("toc3d_layernorm_rows", lib.F32, x, C, None, None, g, b, 1e-6, o32, C, M, C, S())
+    lib.call("toc3d_layernorm_rows", lib.F32X3P, x, C, None, None, g, b, 1e-6, opl, C, M, C, S())
+    assert torch.equal(opl.view(torch.int32), to_planes(o32).view(torch.int32))
+    with pytest.raises(RuntimeError, match="128-byte"):
+        bad = torch.zeros(M, C + 8, device=DEV)
+        lib.call("toc3d_layernorm_rows", lib.F32X3P, x, C, None, None, g, b, 1e-6, bad, C + 8, M, C, S())

@@ -545,6 +545,12 @@ class _BackboneBase(nn.Module):
         tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, fused, a_planes, o_planes)
 
     @property
+    def _dt_rows(self):
+        """dtype handed to the row kernels that produce a GEMM's A operand (LayerNorm / gather / rebase, the f32 attention): f32 arithmetic either way,
+        the output rows as (hi, lo) planes on fp32x3 with x3_planes (include/toc3d.h, TOC3D_DTYPE_F32X3P)."""
+        return lib.F32X3P if self._x3p else self._dt
+
+    @property
     def _x3p(self):
         """fp32x3 with its GEMM operands as (hi, lo) planes (schedule switch x3_planes)."""
         return self.precision == "fp32x3" and self.x3_planes
@@ -634,8 +640,8 @@ class _BackboneBase(nn.Module):
             lib.call("toc3d_window_attention_rot", dt, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad, stride, nwin, max_count,
                      self.num_heads, v_bias, len(ts), ptrs, nb, self.prefetch_weights, lib.stream_ptr())
             return
-        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0)
-        self._attention(P, i, dt, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad,
+        self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0, a_planes=self._x3p)
+        self._attention(P, i, self._dt_rows, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad,
                         stride, nwin, max_count, self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], v_bias, 64 ** -0.5)
 
     def _proj(self, bp, plan, rows, out, rep_out, rep_index, res=None, res_index=None):
@@ -647,10 +653,10 @@ class _BackboneBase(nn.Module):
         if self.fold_norm2:
             self._linear(lib.EPI_RESIDUAL_STATS, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
                          fused=(plan["stats2"], plan["stats2_cap"], None, 0, None, 0, 0.0, plan["a"], C, res_index),
-                         a_planes=self._x3p and plan.get("att_planes", False), o_planes=self._x3p)     # the f32 copy leaves as planes: the w1|w2 GEMM's A operand
+                         a_planes=self._x3p, o_planes=self._x3p)     # the f32 copy leaves as planes: the w1|w2 GEMM's A operand
         else:
             self._linear(lib.EPI_RESIDUAL, plan["att"], C, bp["wproj"], C, bp["bproj"], out, C, res, C, 0, rep_out, rep_index, rows, C, C, 0,
-                         fused=lib.NO_FUSED[:9] + (res_index,), a_planes=self._x3p and plan.get("att_planes", False))
+                         fused=lib.NO_FUSED[:9] + (res_index,), a_planes=self._x3p)
 
     def _mlp(self, bp, plan, rows, res, rep_out, rep_index):
         """norm2 -> SwiGLU (w1|w2, ffn_ln, w3) -> + residual (eva_vit.py:263, toc3d_eva_vit.py:381-384); res is f32 [rows, C]."""
@@ -687,7 +693,7 @@ class _BackboneBase(nn.Module):
         C, M, dt = self.embed_dim, plan["M"], self._dt
         x = plan["x"]
         dm = plan["dense"][self._block_side(i)]
-        lib.call("toc3d_layernorm_rows", dt, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
+        lib.call("toc3d_layernorm_rows", self._dt_rows, x, C, None, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, M, C, s)
         self._qkv_attention(P, i, plan, M, dm.get("rc"), dm["rows"], dm["slots"], dm["count"], None, dm["npad"], None, dm["N"], dm["nW"], dm["max_count"], bp["v_bias"])
         self._proj(bp, plan, M, x, None, None)
         self._mlp(bp, plan, M, x, None, None)
@@ -1116,14 +1122,14 @@ class ToC3DEVAViT(_BackboneBase):
         nW, N, k, rows = sel["nW"], sel["N"], sel["k"], sel["rows"]
         slow = plan["slow"]
         if carry_in:
-            lib.call("toc3d_rebase_layernorm_rows", dt, slow, C, sel["rep_index"], sel["tok"], sel["wgt"], N, k, plan["rep1"], plan["rep2"],
+            lib.call("toc3d_rebase_layernorm_rows", self._dt_rows, slow, C, sel["rep_index"], sel["tok"], sel["wgt"], N, k, plan["rep1"], plan["rep2"],
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, plan["a"], C, rows, s)
         elif self.gather_split:
-            lib.call("toc3d_gather_merge_ln_split", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
+            lib.call("toc3d_gather_merge_ln_split", self._dt_rows, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1,
                      plan["gm_scratch"], plan["gm_scratch"].numel() * 4, int(self.gather_split) if self.gather_split is not True else 0, s)
         else:
-            lib.call("toc3d_gather_merge_ln_ex", dt, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
+            lib.call("toc3d_gather_merge_ln_ex", self._dt_rows, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1, s)
         rot = self.attn_rot and k + 1 <= 416
         self._qkv_attention(P, i, plan, rows, sel["crow_rc"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], None,

@@ -34,6 +34,7 @@ struct AttnArgs {
     // weight prefetch riding on this launch (toc3d_window_attention_pf): the first pf_rows rows of the grid's window dimension stream these
     // buffers through the caches and discard them; nwin = number of real windows (the grid is pf_rows + nwin in its window dimension)
     const f32x4* pf_ptr[4]; int64_t pf_n16[4]; int nwin, pf_rows;
+    int out_planes;                              // f32 kernels: the output rows leave as (hi, lo) bf16 planes (TOC3D_DTYPE_F32X3P: the projection GEMM's A operand)
 };
 
 // The attention kernels are latency-bound and leave HBM idle, and the GEMMs that follow them start on weights that were last touched a frame
@@ -338,7 +339,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                     if (np > 0) v += padw_q * a.v_bias[head * HD + r16 * 4 + d];
                     o4[d] = to_act<T>(v * inv_q);
                 }
-                store4(dst, o4);
+                if constexpr (sizeof(T) == 4) {
+                    if (a.out_planes) store4_planes(dst, o4);
+                    else store4(dst, o4);
+                } else {
+                    store4(dst, o4);
+                }
             }
         }
     }
@@ -545,7 +551,12 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
                     if (np > 0) v += padw_q * a.v_bias[head * HD + r16 * 4 + d];
                     o4[d] = to_act<T>(v * inv_q);
                 }
-                store4(dst, o4);
+                if constexpr (sizeof(T) == 4) {
+                    if (a.out_planes) store4_planes(dst, o4);
+                    else store4(dst, o4);
+                } else {
+                    store4(dst, o4);
+                }
             }
         }
     }
@@ -616,7 +627,12 @@ int toc3d_window_attention_pf(int dtype, const void* qkv, int64_t ldqkv, void* o
                               const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
                               int64_t n_prefetch, const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int64_t prefetch_workgroups,
                               toc3d_stream_t stream) {
-    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16, "toc3d_window_attention: bad dtype %d", dtype);
+    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3P, "toc3d_window_attention: bad dtype %d", dtype);
+    const bool out_planes = dtype == TOC3D_F32X3P;        // f32 arithmetic on f32 q|k|v, the output as (hi, lo) planes
+    if (out_planes) {
+        dtype = TOC3D_F32;
+        TOC3D_REQUIRE(((uintptr_t)out % 128) == 0 && ldo % 32 == 0, "toc3d_window_attention: rows of (hi, lo) planes start on 128-byte boundaries (out aligned, ldo a multiple of 32)");
+    }
     TOC3D_REQUIRE(qkv && out && rows && slots && count && rope_cos && rope_sin, "toc3d_window_attention: null buffer");
     TOC3D_REQUIRE(!npad || v_bias, "toc3d_window_attention: npad given without v_bias");
     TOC3D_REQUIRE(!count_k || pad_qkv, "toc3d_window_attention: count_k given without pad_qkv");
@@ -631,7 +647,7 @@ int toc3d_window_attention_pf(int dtype, const void* qkv, int64_t ldqkv, void* o
     if (nwin == 0 || max_count == 0) return TOC3D_OK;
     TOC3D_REQUIRE(n_prefetch >= 0 && n_prefetch <= 4 && (n_prefetch == 0 || (prefetch_ptrs && prefetch_bytes)), "toc3d_window_attention: at most 4 prefetch buffers (host arrays)");
     AttnArgs a{qkv, ldqkv, out, ldo, rows, slots, count, count_k, npad, pad_qkv, stride, (int)C, (int)rope_side, rope_cos, rope_sin, v_bias, scale,
-               {nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, (int)nwin, 0};
+               {nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, (int)nwin, 0, out_planes ? 1 : 0};
     int64_t pf_total = 0;
     for (int64_t i = 0; i < n_prefetch; ++i) {
         TOC3D_REQUIRE(prefetch_bytes[i] >= 0 && ((uintptr_t)prefetch_ptrs[i] % 16) == 0, "toc3d_window_attention: prefetch buffers must be 16-byte aligned");

@@ -116,6 +116,26 @@ TOC3D_DEV void store4(bf16_t* p, const bf16_t (&v)[4]) {
 }
 TOC3D_DEV void store4(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
 
+// An f32 buffer held as (hi, lo) bf16 PLANES (include/toc3d.h, TOC3D_DTYPE_F32X3P: the A operands of the bf16 x 3 GEMM, written by their producers): the size
+// and leading dimension of the f32 buffer; element c of a row lives in the 128-byte group c / 32 -- hi = bf16(x) at byte 2 (c % 32), lo = bf16(x - hi) at byte
+// 64 + 2 (c % 32).  f32p_t tags such a buffer in the row kernels' templates (pointer arithmetic as for float).  Rows start on 128-byte boundaries (host-checked),
+// so group and position follow from the address the f32 element would have.
+struct f32p_t { float v; };
+TOC3D_DEV void store4_planes(void* f32_addr, const float (&v)[4]) {      // 4 consecutive elements, the first at a multiple of 4
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16_t h = (bf16_t)v[e];
+        hi[e] = h;
+        lo[e] = (bf16_t)(v[e] - (float)h);
+    }
+    const uintptr_t a = reinterpret_cast<uintptr_t>(f32_addr);
+    char* g = reinterpret_cast<char*>(a & ~(uintptr_t)127) + ((a & 127) >> 1);
+    *reinterpret_cast<bf16x4_t*>(g) = hi;
+    *reinterpret_cast<bf16x4_t*>(g + 64) = lo;
+}
+
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md T1): blocks that land on one XCD
 // (bid % 8) get a contiguous chunk of work ids so neighbouring tiles share that XCD's L2.
 TOC3D_DEV int xcd_remap(int bid, int nwg) {

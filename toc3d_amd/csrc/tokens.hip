@@ -35,8 +35,11 @@ TOC3D_DEV void wave_ln_stats(const f32x4 (&v)[MAXV], int nvec, int lane, int C, 
     rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
 }
 
+static bool planes_rows_ok(const void* p, int64_t ld) { return ((uintptr_t)p % 128) == 0 && ld % 32 == 0; }
+
 template <typename T> TOC3D_DEV void store4(T* p, f32x4 v);
 template <> TOC3D_DEV void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> TOC3D_DEV void store4<f32p_t>(f32p_t* p, f32x4 v) { const float x[4] = {v[0], v[1], v[2], v[3]}; store4_planes(p, x); }
 template <> TOC3D_DEV void store4<bf16_t>(bf16_t* p, f32x4 v) {
     bf16x4 b;
     b[0] = (bf16_t)v[0]; b[1] = (bf16_t)v[1]; b[2] = (bf16_t)v[2]; b[3] = (bf16_t)v[3];
@@ -764,6 +767,10 @@ int toc3d_layernorm_rows(int dtype, const float* x, int64_t ldx, const int32_t* 
 #define LNR(T, MV) toc3d_launch((ln_rows_kernel<T, MV>), grid, block, 0, s, x, ldx, row_index, row_scale, gamma, beta, eps, (T*)out, ldo, (int)M, (int)C)
     if (dtype == TOC3D_BF16) { if (C <= 1024) LNR(bf16_t, 4); else LNR(bf16_t, 8); }
     else if (dtype == TOC3D_F32) { if (C <= 1024) LNR(float, 4); else LNR(float, 8); }
+    else if (dtype == TOC3D_F32X3P) {            // f32 arithmetic, rows written as (hi, lo) planes: the A operand of a bf16 x 3 GEMM
+        TOC3D_REQUIRE(planes_rows_ok(out, ldo), "toc3d_layernorm_rows: rows of (hi, lo) planes start on 128-byte boundaries (out aligned, ldo a multiple of 32)");
+        if (C <= 1024) LNR(f32p_t, 4); else LNR(f32p_t, 8);
+    }
     else { toc3d_set_error("toc3d_layernorm_rows: bad dtype"); return TOC3D_ERR_ARG; }
 #undef LNR
     TOC3D_LAUNCH_CHECK("toc3d_layernorm_rows");
@@ -853,6 +860,10 @@ static int launch_gather(int dtype, const float* x, int64_t C, const int32_t* to
 #endif
     if (dtype == TOC3D_BF16) TOC3D_GATHER(bf16_t, false);
     else if (dtype == TOC3D_F32) TOC3D_GATHER(float, false);
+    else if (dtype == TOC3D_F32X3P) {            // a_out as (hi, lo) planes (the q|k|v GEMM's A operand); shortcut stays f32
+        TOC3D_REQUIRE(planes_rows_ok(a_out, lda), "toc3d_gather_merge_ln: rows of (hi, lo) planes start on 128-byte boundaries (a_out aligned, lda a multiple of 32)");
+        TOC3D_GATHER(f32p_t, false);
+    }
     else { toc3d_set_error("toc3d_gather_merge_ln: bad dtype"); return TOC3D_ERR_ARG; }
 #undef TOC3D_GATHER
     TOC3D_LAUNCH_CHECK("toc3d_gather_merge_ln");
@@ -903,6 +914,10 @@ int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int3
     do { if (sp == 2) TOC3D_GSPLIT(T, 2); else if (sp == 4) TOC3D_GSPLIT(T, 4); else if (sp == 8) TOC3D_GSPLIT(T, 8); else TOC3D_GSPLIT(T, 16); } while (0)
     if (dtype == TOC3D_BF16) TOC3D_GSPLIT_T(bf16_t);
     else if (dtype == TOC3D_F32) TOC3D_GSPLIT_T(float);
+    else if (dtype == TOC3D_F32X3P) {
+        TOC3D_REQUIRE(planes_rows_ok(a_out, lda), "toc3d_gather_merge_ln_split: rows of (hi, lo) planes start on 128-byte boundaries (a_out aligned, lda a multiple of 32)");
+        TOC3D_GSPLIT_T(f32p_t);
+    }
     else { toc3d_set_error("toc3d_gather_merge_ln_split: bad dtype"); return TOC3D_ERR_ARG; }
 #undef TOC3D_GSPLIT_T
 #undef TOC3D_GSPLIT
@@ -966,6 +981,10 @@ int toc3d_rebase_layernorm_rows(int dtype, float* slow, int64_t C, const int32_t
 #define LNB(T, MV) toc3d_launch((ln_rebase_kernel<T, MV>), grid, block, 0, s, slow, (int)C, rep_index, tok, wgt, (int)N, (int)k, rep_raw1, rep_raw2, gamma, beta, eps, (T*)out, ldo, (int)rows)
     if (dtype == TOC3D_BF16) { if (C <= 1024) LNB(bf16_t, 4); else LNB(bf16_t, 8); }
     else if (dtype == TOC3D_F32) { if (C <= 1024) LNB(float, 4); else LNB(float, 8); }
+    else if (dtype == TOC3D_F32X3P) {
+        TOC3D_REQUIRE(planes_rows_ok(out, ldo), "toc3d_rebase_layernorm_rows: rows of (hi, lo) planes start on 128-byte boundaries (out aligned, ldo a multiple of 32)");
+        if (C <= 1024) LNB(f32p_t, 4); else LNB(f32p_t, 8);
+    }
     else { toc3d_set_error("toc3d_rebase_layernorm_rows: bad dtype"); return TOC3D_ERR_ARG; }
 #undef LNB
     TOC3D_LAUNCH_CHECK("toc3d_rebase_layernorm_rows");
