@@ -31,7 +31,7 @@ from toc3d_amd import configs, lib, synth  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PAPER_FPS = 1000.0 / 209.0      # ToC3D-Faster ViT-L 6x(800x320) backbone 209.0 ms, fp32, GPU unstated
-REF_BOX_TFLOPS, REF_BOX_COPY_GBS, REF_BOX_FPS = 790.4, 5013.2, 201.6    # calibrate() and the headline on the box profiles/r04_bench_final.json was taken on (boxes of the pool spread ~5 %: 795 TF / 5264 GB/s -> 203.9)
+REF_BOX_TFLOPS, REF_BOX_COPY_GBS, REF_BOX_FPS = 795.4, 5011.8, 210.5    # calibrate() and the headline on the box profiles/r04_bench_final.json was taken on (boxes of the pool spread ~5 %: 771-774 TF -> 200.7-201.1, profiles/r04_bench_final_second_box.json)
 
 
 def flop_model(cfg, V, h, w):
@@ -584,7 +584,9 @@ def main():
             if os.path.exists(tpath) and args.config == "toc3d_faster" and (H, W) == (320, 800) and args.precision == "bf16":
                 tj = json.load(open(tpath))
                 # counters cannot be collected inside the run: the committed pass is only quoted while it describes THIS launch schedule
-                if tj.get("schedule") == model_schedule:
+                # (a switch that did not exist when the pass was taken and is OFF in this model changes nothing: only the recorded keys must agree)
+                rec = tj.get("schedule") or {}
+                if rec and all(model_schedule.get(k) == v for k, v in rec.items()) and not any(model_schedule[k] for k in model_schedule if k not in rec):
                     roof["traffic"] = tj["hbm_bytes_per_launch"]
                     roof["traffic_source"] = f"profiles/{tag_}_gemm_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not collected inside this run)"
                 else:
