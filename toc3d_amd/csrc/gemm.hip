@@ -325,8 +325,9 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
                0, 0, nullptr, nullptr, nullptr, 0, 1.0f, planes_a, planes, planes_o};
     if (planes) {
         TOC3D_REQUIRE(epilogue != TOC3D_EPI_CONV3X3 || !planes_a, "toc3d_linear: the 3x3 conv gathers f32 activations (A cannot be planes)");
-        TOC3D_REQUIRE((!planes_o || ((!e_swiglu || ldo % 32 == 0) && (!out_act || ld_act % 32 == 0))) && (!planes_a || lda % 32 == 0),
-                      "toc3d_linear: rows of (hi, lo) planes are whole 32-element groups: lda, ldo (SwiGLU) and ld_act must be multiples of 32");
+        TOC3D_REQUIRE((!planes_o || ((!e_swiglu || (ldo % 32 == 0 && (uintptr_t)out % 16 == 0)) && (!out_act || (ld_act % 32 == 0 && (uintptr_t)out_act % 16 == 0)))) &&
+                      (!planes_a || lda % 32 == 0),
+                      "toc3d_linear: rows of (hi, lo) planes are whole 32-element groups on 16-byte boundaries: lda, ldo (SwiGLU) and ld_act must be multiples of 32");
     }
     if (epilogue == TOC3D_EPI_CONV3X3) {
         // A = NHWC act tensor [V, h, w, lda]; ld_act carries h << 32 | w and out_act the zero line (toc3d_conv3x3_nhwc fills them in)
