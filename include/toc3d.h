@@ -56,8 +56,11 @@ extern "C" {
  * byte 64 + 2 (c % 32) (toc3d_x3_planes converts; the kernel's own split writes exactly this image into LDS, so results are bit-identical to F32X3).
  *   F32X3W: W in planes (packed once: toc3d_pack_* with TOC3D_DTYPE_F32, then toc3d_x3_planes in place); A and every output plain f32.
  *   F32X3P: W and A in planes; the outputs a later GEMM multiplies -- the SwiGLU epilogues' `out`, `out_act` -- are written as planes, all others (bias / GELU /
- *           residual outputs, statistics) stay f32.  toc3d_layernorm_rows / toc3d_rebase_layernorm_rows / toc3d_gather_merge_ln* / toc3d_window_attention
- *           take this dtype too: f32 arithmetic, output rows written as planes (they produce the A operands). */
+ *           residual outputs, statistics) stay f32.  toc3d_layernorm_rows / toc3d_rebase_layernorm_rows / toc3d_gather_merge_ln* take this dtype too: f32
+ *           arithmetic, output rows written as planes (they produce the A operands).
+ * toc3d_window_attention on f32 q|k|v: TOC3D_DTYPE_F32 = exact-f32 products, f32 output; F32X3WO = the same with the output rows as planes; F32X3 = both contractions
+ * (q.k, p.v) as bf16 x 3 products -- f32 RoPE, softmax and accumulation; 48 instead of 256 matrix-core cycles per 16x16x32 step -- f32 output; F32X3P = those
+ * products and the output as planes (what precision="fp32x3" launches). */
 #define TOC3D_DTYPE_F32X3W 4
 #define TOC3D_DTYPE_F32X3P 5
 /* ... the two mixed forms: F32X3WO = W in planes, A plain f32, the GEMM-to-GEMM outputs as planes (a producer whose own A is not split yet);

@@ -1225,3 +1225,40 @@ def test_layernorm_rows_writes_planes():
     with pytest.raises(RuntimeError, match="128-byte"):
         bad = torch.zeros(M, C + 8, device=DEV)
         lib.call("toc3d_layernorm_rows", lib.F32X3P, x, C, None, None, g, b, 1e-6, bad, C + 8, M, C, S())
+
+
+@pytest.mark.parametrize("n", [77, 129, 201, 256, 400])
+def test_window_attention_with_bf16x3_products(n):
+    """toc3d_window_attention on f32 q|k|v with TOC3D_DTYPE_F32X3 / F32X3P / F32X3WO (the attention of precision "fp32x3"): both contractions as bf16 x 3
+    products (hi.hi + hi.lo + lo.hi), RoPE / softmax / accumulation in f32 -- parity grade against the oracle (toc3d_eva_vit.py:484-518), close to the
+    exact-f32 kernel; the planes forms return the planes image of the f32 forms (small-window and flash kernels: n <= 208 / larger)."""
+    cfg = configs.get("toc3d_tiny")
+    sd = synth.make_state_dict(cfg)
+    C, heads, nW = cfg["embed_dim"], cfg["num_heads"], 5
+    pre = "blocks.5.attn."
+    cosT, sinT = sd[pre + "rope.freqs_cos"], sd[pre + "rope.freqs_sin"]        # 400-row table
+    y = rnd(nW, n, C, seed=11)
+    g = torch.Generator().manual_seed(12)
+    slots = torch.stack([torch.randperm(400, generator=g)[:n] for _ in range(nW)])
+    sd2 = dict(sd)
+    sd2[pre + "proj.weight"], sd2[pre + "proj.bias"] = torch.eye(C), torch.zeros(C)
+    ref = O.attention(y, sd2, pre, heads, cosT[slots], sinT[slots]).reshape(-1, C)
+    wqkv = torch.cat([sd[pre + "q_proj.weight"], sd[pre + "k_proj.weight"], sd[pre + "v_proj.weight"]])
+    bqkv = torch.cat([sd[pre + "q_bias"], torch.zeros(C), sd[pre + "v_bias"]])
+    M = nW * n
+    qkv = torch.empty(M, 3 * C, dtype=torch.float32, device=DEV)
+    lib.call("toc3d_linear", lib.F32, lib.EPI_BIAS, as_act(y.reshape(M, C), torch.float32), C, pack(wqkv, lib.F32, torch.float32), C, bqkv.to(DEV), qkv, 3 * C, None, 0, 0,
+             None, None, M, 3 * C, C, 0, S())
+    rows = torch.arange(M, dtype=torch.int32).reshape(nW, n).to(DEV)
+    count = torch.full((nW,), n, dtype=torch.int32, device=DEV)
+    outs = {}
+    for dt in (lib.F32, lib.F32X3, lib.F32X3P, lib.F32X3WO):
+        out = torch.zeros(M, C, dtype=torch.float32, device=DEV)
+        lib.call("toc3d_window_attention", dt, qkv, 3 * C, out, C, rows, slots.int().to(DEV), count, None, None, None, n, nW, n, heads,
+                 cosT.to(DEV), sinT.to(DEV), 20, None, 64 ** -0.5, S())
+        outs[dt] = out
+    e32, ex3 = relerr(outs[lib.F32], ref), relerr(outs[lib.F32X3], ref)
+    print(f"[attention n={n}] rel err vs oracle: exact f32 {e32:.3e}, bf16 x 3 products {ex3:.3e}; x3 vs exact {relerr(outs[lib.F32X3], outs[lib.F32].cpu()):.3e}")
+    assert e32 < 5e-5 and ex3 < 1e-4
+    assert torch.equal(outs[lib.F32X3P].view(torch.int32), to_planes(outs[lib.F32X3]).view(torch.int32))
+    assert torch.equal(outs[lib.F32X3WO].view(torch.int32), to_planes(outs[lib.F32]).view(torch.int32))

@@ -178,6 +178,7 @@ def schedule_defaults(precision):
     bf16 = precision == "bf16"
     fast = precision in ("bf16", "fp32x3")
     return dict(
+        x3_attention=precision == "fp32x3",  # fp32x3: the attention's two contractions as bf16 x 3 products too (f32 RoPE / softmax / accumulation; TOC3D_DTYPE_F32X3 of toc3d_window_attention)
         x3_planes=precision == "fp32x3",   # fp32x3: packed weights, the GEMMs' A operands and the GEMM-to-GEMM activations as (hi, lo) bf16 planes (TOC3D_DTYPE_F32X3W / F32X3P)
         carry_compact=fast,          # consecutive accelerated blocks of one window type continue on the same compact rows (_accel_block)
         fold_ffn_ln=fast,            # SwiGLU.ffn_ln folded across the w1|w2 -> w3 GEMM boundary (include/toc3d.h, toc3d_linear_fused)
@@ -551,6 +552,14 @@ class _BackboneBase(nn.Module):
         return lib.F32X3P if self._x3p else self._dt
 
     @property
+    def _dt_attn(self):
+        """dtype of the f32-buffer attention launch: exact f32 products or, on fp32x3 with x3_attention, bf16 x 3 products; output rows plain or as planes."""
+        if self.precision != "fp32x3":
+            return self._dt
+        x3a = bool(self.x3_attention)
+        return {(False, False): lib.F32, (False, True): lib.F32X3WO, (True, False): lib.F32X3, (True, True): lib.F32X3P}[(x3a, self._x3p)]
+
+    @property
     def _x3p(self):
         """fp32x3 with its GEMM operands as (hi, lo) planes (schedule switch x3_planes)."""
         return self.precision == "fp32x3" and self.x3_planes
@@ -641,7 +650,7 @@ class _BackboneBase(nn.Module):
                      self.num_heads, v_bias, len(ts), ptrs, nb, self.prefetch_weights, lib.stream_ptr())
             return
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0, a_planes=self._x3p)
-        self._attention(P, i, self._dt_rows, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad,
+        self._attention(P, i, self._dt_attn, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad,
                         stride, nwin, max_count, self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], v_bias, 64 ** -0.5)
 
     def _proj(self, bp, plan, rows, out, rep_out, rep_index, res=None, res_index=None):

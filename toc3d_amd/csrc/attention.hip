@@ -140,7 +140,47 @@ TOC3D_DEV float g4_max(float v) {
     return v;
 }
 
-template <typename T, int QM>
+// ---- bf16 x 3 products inside the f32 kernels (TOC3D_DTYPE_F32X3 / F32X3P: the attention of precision "fp32x3") -------------------------------------
+// The exact-f32 form multiplies on v_mfma_f32_16x16x4_f32: 8 instructions (256 cycles) per 16x16x32 step, and these kernels are bound by them (the
+// fp32x3 frame spent 14 % of its time here once its GEMMs ran on planes).  X3 keeps every buffer, the RoPE, the softmax and the accumulation in f32 and
+// forms the two contractions like the GEMMs of that precision do: a . b = hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 (48 cycles; relative error of a
+// product <= ~2^-16).  Nothing is split inside the MFMA loops: the staged K and V^T tiles keep their f32 LDS image (same addresses, same bank pattern) but
+// every aligned 8-element chunk of K [32 bytes] holds [8 x hi | 8 x lo] and every aligned 4-key group of a V^T row [16 bytes] holds [4 x hi | 4 x lo],
+// written once by the thread that stages the element; Q is split once per query tile, P once per 32 keys (it feeds four MFMA steps).
+struct X3Frag { bf16x8 hi, lo; };
+TOC3D_DEV X3Frag x3_split(const float (&x)[8]) {
+    X3Frag f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bf16_t h = (bf16_t)x[e];
+        f.hi[e] = h;
+        f.lo[e] = (bf16_t)(x[e] - (float)h);
+    }
+    return f;
+}
+TOC3D_DEV void x3_chunk_bits(const float (&x)[8], float (&bits)[8]) {       // the 32 bytes of a K chunk: [8 x hi | 8 x lo]
+    const X3Frag f = x3_split(x);
+    const f32x4 a = __builtin_bit_cast(f32x4, f.hi), b = __builtin_bit_cast(f32x4, f.lo);
+    bits[0] = a[0]; bits[1] = a[1]; bits[2] = a[2]; bits[3] = a[3]; bits[4] = b[0]; bits[5] = b[1]; bits[6] = b[2]; bits[7] = b[3];
+}
+TOC3D_DEV X3Frag x3_from_chunk(const Frag<float>& f) { return X3Frag{__builtin_bit_cast(bf16x8, f.lo), __builtin_bit_cast(bf16x8, f.hi)}; }
+TOC3D_DEV X3Frag x3_from_halves(const float* p0, const float* p1) {        // two 4-key groups of a V^T row: [4 x hi | 4 x lo] each
+    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(p0)), b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(p1));
+    return X3Frag{__builtin_shufflevector(a, b, 0, 1, 2, 3, 8, 9, 10, 11), __builtin_shufflevector(a, b, 4, 5, 6, 7, 12, 13, 14, 15)};
+}
+TOC3D_DEV void x3_store_vt(float* elem, int key, float v) {                // element (row, key) of V^T; elem = the address the f32 element would have
+    const bf16_t h = (bf16_t)v;
+    char* grp = reinterpret_cast<char*>(elem - (key & 3));
+    *reinterpret_cast<bf16_t*>(grp + 2 * (key & 3)) = h;
+    *reinterpret_cast<bf16_t*>(grp + 8 + 2 * (key & 3)) = (bf16_t)(v - (float)h);
+}
+TOC3D_DEV void x3_mma(f32x4& acc, const X3Frag& a, const X3Frag& b) {      // small terms first, like the GEMM
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
+template <typename T, int QM, bool X3 = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     constexpr int LD = Pad<T>::ld;
     constexpr int QB = 64 * QM;                  // query rows per workgroup
@@ -188,6 +228,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     __syncthreads();
     // ---- Q fragments (A operand: row = r16, k = g*8 + j + 32*s), RoPE + scale applied in f32 ----
     Frag<T> qf[QM][2];
+    X3Frag qx[X3 ? QM : 1][2];                   // X3: the same fragments as (hi, lo) pairs (qf unused)
 #pragma unroll
     for (int mi = 0; mi < QM; ++mi) {
         const int qi = q0 + mi * 16 + r16;
@@ -201,7 +242,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             rope8_lds(x, s_cos, s_sin, L, qrc, d0 >> 3);
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = ok ? x[j] * a.scale : 0.f;
-            qf[mi][s] = make_frag(x, T());
+            if constexpr (X3) qx[mi][s] = x3_split(x);
+            else qf[mi][s] = make_frag(x, T());
         }
     }
     // software pipeline: tile kt+1 is fetched into registers while tile kt is multiplied
@@ -244,14 +286,25 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                 float kx[8];
                 frag_to_float(pre[it].k, kx);
                 rope8_lds(kx, s_cos, s_sin, L, s_slots[kt * KT + key], dc);          // rotate_half pairs (eva_utils.py:318-322,379)
-                store8(Ks + key * LD + dc * 8, kx);
+                if constexpr (X3) {
+                    float kb[8];
+                    x3_chunk_bits(kx, kb);
+                    store8(Ks + key * LD + dc * 8, kb);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LD] = frag_elem(pre[it].v, j);   // V moves as stored: no conversion
+                    for (int j = 0; j < 8; ++j) x3_store_vt(reinterpret_cast<float*>(vdst + ((j & 3) * 16 + (j >> 2)) * LD), key, (float)frag_elem(pre[it].v, j));
+                } else {
+                    store8(Ks + key * LD + dc * 8, kx);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LD] = frag_elem(pre[it].v, j);   // V moves as stored: no conversion
+                }
             } else {
                 const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 store8(Ks + key * LD + dc * 8, z);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LD] = to_act<T>(0.f);
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (X3) x3_store_vt(reinterpret_cast<float*>(vdst + ((j & 3) * 16 + (j >> 2)) * LD), key, 0.f);   // (a 4-byte zero would clobber a neighbour's lo half)
+                    else vdst[((j & 3) * 16 + (j >> 2)) * LD] = to_act<T>(0.f);
+                }
             }
         }
         __syncthreads();
@@ -268,7 +321,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             for (int t = 0; t < 4; ++t) {
                 sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < 2; ++s) mma_step(sc[t], read_frag(Ks + (t * 16 + r16) * LD + s * 32 + g * 8), qf[mi][s]);
+                for (int s = 0; s < 2; ++s) {
+                    if constexpr (X3) x3_mma(sc[t], x3_from_chunk(read_frag(reinterpret_cast<const float*>(Ks) + (t * 16 + r16) * LD + s * 32 + g * 8)), qx[mi][s]);
+                    else mma_step(sc[t], read_frag(Ks + (t * 16 + r16) * LD + s * 32 + g * 8), qf[mi][s]);
+                }
                 if (kt * KT + t * 16 + 16 > nkeys) {              // mask keys past the window: only a tile that straddles the end (wave-uniform)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sc[t][r] = kt * KT + t * 16 + g * 4 + r < nkeys ? sc[t][r] : NEG_BIG;
@@ -281,6 +337,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             const float alpha = softmax_exp<T>(m[mi] - mn);
             float ps = 0.f;
             Frag<T> pf[2];
+            X3Frag px[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 float pv[8];
@@ -289,7 +346,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
                     pv[j] = softmax_exp<T>(sc[2 * c + (j >> 2)][j & 3] - mn);
                     ps += pv[j];
                 }
-                pf[c] = make_frag(pv, T());
+                if constexpr (X3) px[c] = x3_split(pv);
+                else pf[c] = make_frag(pv, T());
             }
             l[mi] = l[mi] * alpha + ps;              // per-lane partial; the 4 lane groups are summed at the end
             m[mi] = mn;
@@ -306,7 +364,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const T* vrow = Vt + (d * 16 + r16) * LD + c * 32 + g * 4;
-                    mma_step(o[mi][d], pf[c], frag_from_halves(vrow, vrow + 16));
+                    if constexpr (X3) x3_mma(o[mi][d], px[c], x3_from_halves(reinterpret_cast<const float*>(vrow), reinterpret_cast<const float*>(vrow) + 16));
+                    else mma_step(o[mi][d], pf[c], frag_from_halves(vrow, vrow + 16));
                 }
         }
     }
@@ -365,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 // q = (lane >> 4)*4 + r fetches 1/sum from lane q.
 // Dense blocks (npad): the analytic zero-pad keys of the header comment enter the single pass as max(m, 0), sum += npad * exp(-m).
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int MAXSUB>
+template <typename T, int MAXSUB, bool X3 = false>
 __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
     constexpr int LD = Pad<T>::ld;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -452,14 +511,25 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
                 float kx[8];
                 frag_to_float(kraw[i], kx);
                 rope8_lds(kx, s_cos, s_sin, L, s_slots[key], dc);
-                store8(Ks + key * LD + dc * 8, kx);
+                if constexpr (X3) {
+                    float kb[8];
+                    x3_chunk_bits(kx, kb);
+                    store8(Ks + key * LD + dc * 8, kb);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LDP] = frag_elem(vraw[i], j);   // V moves as stored: no conversion
+                    for (int j = 0; j < 8; ++j) x3_store_vt(reinterpret_cast<float*>(vdst + ((j & 3) * 16 + (j >> 2)) * LDP), key, (float)frag_elem(vraw[i], j));
+                } else {
+                    store8(Ks + key * LD + dc * 8, kx);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LDP] = frag_elem(vraw[i], j);   // V moves as stored: no conversion
+                }
             } else {
                 const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (key < nsub * 16) store8(Ks + key * LD + dc * 8, z);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vdst[((j & 3) * 16 + (j >> 2)) * LDP] = to_act<T>(0.f);
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (X3) x3_store_vt(reinterpret_cast<float*>(vdst + ((j & 3) * 16 + (j >> 2)) * LDP), key, 0.f);
+                    else vdst[((j & 3) * 16 + (j >> 2)) * LDP] = to_act<T>(0.f);
+                }
             }
         }
     }
@@ -472,6 +542,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
         if (mt >= nmt) break;
         // Q fragment of this 16-row tile (RoPE + scale in f32); B operand: column = query r16
         Frag<T> qf[2];
+        X3Frag qx[2];
         {
             const bool ok = mt * 16 + r16 < n;
             const int qrc = ok ? s_slots[mt * 16 + r16] : 0;
@@ -483,7 +554,8 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
                 rope8_lds(x, s_cos, s_sin, L, qrc, d0 >> 3);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = ok ? x[j] * a.scale : 0.f;
-                qf[s2] = make_frag(x, T());
+                if constexpr (X3) qx[s2] = x3_split(x);
+                else qf[s2] = make_frag(x, T());
             }
         }
         // S^T = K Q^T over all keys; lane holds S[q = r16][key = t*16 + g*4 + r]
@@ -495,7 +567,10 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
             if (t < nsub) {
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) mma_step(acc, read_frag(Ks + (t * 16 + r16) * LD + s2 * 32 + g * 8), qf[s2]);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if constexpr (X3) x3_mma(acc, x3_from_chunk(read_frag(reinterpret_cast<const float*>(Ks) + (t * 16 + r16) * LD + s2 * 32 + g * 8)), qx[s2]);
+                    else mma_step(acc, read_frag(Ks + (t * 16 + r16) * LD + s2 * 32 + g * 8), qf[s2]);
+                }
                 if (t * 16 + 16 > nkeys) {                        // only the last tile can straddle the end of the key list (wave-uniform)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] = t * 16 + g * 4 + r < nkeys ? acc[r] : NEG_BIG;
@@ -524,13 +599,17 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnArgs a) {
                         pv[tt * 4 + r] = e;
                     }
                 }
-                const Frag<T> pf = make_frag(pv, T());
+                Frag<T> pf;
+                X3Frag px;
+                if constexpr (X3) px = x3_split(pv);
+                else pf = make_frag(pv, T());
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sum += pv[j];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const T* vrow = Vt + (d * 16 + r16) * LDP + c * 32 + g * 4;
-                    mma_step(o[d], pf, frag_from_halves(vrow, vrow + 16));
+                    if constexpr (X3) x3_mma(o[d], px, x3_from_halves(reinterpret_cast<const float*>(vrow), reinterpret_cast<const float*>(vrow) + 16));
+                    else mma_step(o[d], pf, frag_from_halves(vrow, vrow + 16));
                 }
             }
         }
@@ -568,14 +647,14 @@ size_t attn_small_lds(int64_t stride, int L) {
     return (size_t)(nsub * 16 * Pad<T>::ld + HD * ldp) * sizeof(T) + (size_t)((stride + 3) & ~3) * 8 + (size_t)L * 16 * 16;
 }
 
-template <typename T, int MAXSUB>
+template <typename T, int MAXSUB, bool X3 = false>
 void launch_small(const AttnArgs& a, size_t lds, int64_t num_heads, int64_t nwin, hipStream_t s) {
     static Toc3dLdsAttr attr;                    // per function instantiation, per device
-    attr.ensure(reinterpret_cast<const void*>(&attn_small_kernel<T, MAXSUB>), 96 * 1024);
-    toc3d_launch((attn_small_kernel<T, MAXSUB>), dim3((unsigned)num_heads, (unsigned)(nwin + a.pf_rows)), dim3(256), lds, s, a);
+    attr.ensure(reinterpret_cast<const void*>(&attn_small_kernel<T, MAXSUB, X3>), 96 * 1024);
+    toc3d_launch((attn_small_kernel<T, MAXSUB, X3>), dim3((unsigned)num_heads, (unsigned)(nwin + a.pf_rows)), dim3(256), lds, s, a);
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
     // windows of up to 208 keys (virtual kept-pad keys included; every accelerated block of the shipped configs): the whole-window-resident
     // kernel, one workgroup per (window, head), instantiated for 144 / 176 / 208 keys (score registers per lane).  Measured r02: the dense
@@ -583,9 +662,9 @@ void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_
     if (a.stride <= 208) {
         const size_t lds = attn_small_lds<T>(a.stride, a.L);
         if (lds <= 96 * 1024) {
-            if (a.stride <= 144) launch_small<T, 9>(a, lds, num_heads, nwin, s);
-            else if (a.stride <= 176) launch_small<T, 11>(a, lds, num_heads, nwin, s);
-            else launch_small<T, 13>(a, lds, num_heads, nwin, s);
+            if (a.stride <= 144) launch_small<T, 9, X3>(a, lds, num_heads, nwin, s);
+            else if (a.stride <= 176) launch_small<T, 11, X3>(a, lds, num_heads, nwin, s);
+            else launch_small<T, 13, X3>(a, lds, num_heads, nwin, s);
             return;
         }
     }
@@ -593,7 +672,7 @@ void launch_attn(const AttnArgs& a, int64_t max_count, int64_t num_heads, int64_
     // model, again in round 2 with P in registers: 256 keys 58.1 vs 55.9 us, 400 keys 60.9 vs 67.8 us, frames/s equal)
     const size_t lds = (size_t)(KT + HD) * Pad<T>::ld * sizeof(T) + (size_t)((a.stride + 3) & ~3) * 8 + (size_t)a.L * 16 * 4 * 4;
     dim3 grid((unsigned)((max_count + 63) / 64), (unsigned)num_heads, (unsigned)(nwin + a.pf_rows));
-    toc3d_launch((attn_kernel<T, 1>), grid, dim3(256), lds, s, a);
+    toc3d_launch((attn_kernel<T, 1, X3>), grid, dim3(256), lds, s, a);
 }
 
 // window_partition as index maps (backbones/eva_utils.py:89-110): real tokens of each window in slot order.
@@ -627,10 +706,12 @@ int toc3d_window_attention_pf(int dtype, const void* qkv, int64_t ldqkv, void* o
                               const float* rope_cos, const float* rope_sin, int64_t rope_side, const float* v_bias, float scale,
                               int64_t n_prefetch, const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int64_t prefetch_workgroups,
                               toc3d_stream_t stream) {
-    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3P, "toc3d_window_attention: bad dtype %d", dtype);
-    const bool out_planes = dtype == TOC3D_F32X3P;        // f32 arithmetic on f32 q|k|v, the output as (hi, lo) planes
+    TOC3D_REQUIRE(dtype == TOC3D_F32 || dtype == TOC3D_BF16 || dtype == TOC3D_F32X3 || dtype == TOC3D_F32X3P || dtype == TOC3D_F32X3WO, "toc3d_window_attention: bad dtype %d", dtype);
+    // f32 q|k|v, f32 RoPE / softmax / accumulation in all of these: F32X3 / F32X3P = the two contractions as bf16 x 3 products; F32X3P / F32X3WO = the
+    // output rows as (hi, lo) planes (the projection GEMM's A operand)
+    const bool out_planes = dtype == TOC3D_F32X3P || dtype == TOC3D_F32X3WO, x3_products = dtype == TOC3D_F32X3 || dtype == TOC3D_F32X3P;
+    if (dtype != TOC3D_BF16) dtype = TOC3D_F32;
     if (out_planes) {
-        dtype = TOC3D_F32;
         TOC3D_REQUIRE(((uintptr_t)out % 128) == 0 && ldo % 32 == 0, "toc3d_window_attention: rows of (hi, lo) planes start on 128-byte boundaries (out aligned, ldo a multiple of 32)");
     }
     TOC3D_REQUIRE(qkv && out && rows && slots && count && rope_cos && rope_sin, "toc3d_window_attention: null buffer");
@@ -662,6 +743,7 @@ int toc3d_window_attention_pf(int dtype, const void* qkv, int64_t ldqkv, void* o
         a.pf_rows = (int)(rows_pf < 1 ? 1 : (rows_pf > 128 ? 128 : rows_pf));
     }
     if (dtype == TOC3D_BF16) launch_attn<bf16_t>(a, max_count, num_heads, nwin, as_stream(stream));
+    else if (x3_products) launch_attn<float, true>(a, max_count, num_heads, nwin, as_stream(stream));
     else launch_attn<float>(a, max_count, num_heads, nwin, as_stream(stream));
     TOC3D_LAUNCH_CHECK("toc3d_window_attention");
     return TOC3D_OK;
