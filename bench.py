@@ -31,7 +31,7 @@ from toc3d_amd import configs, lib, synth  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PAPER_FPS = 1000.0 / 209.0      # ToC3D-Faster ViT-L 6x(800x320) backbone 209.0 ms, fp32, GPU unstated
-REF_BOX_TFLOPS, REF_BOX_COPY_GBS, REF_BOX_FPS = 795.4, 5011.8, 210.5    # calibrate() and the headline on the box profiles/r04_bench_final.json was taken on (boxes of the pool spread ~5 %: 771-774 TF -> 200.7-201.1, profiles/r04_bench_final_second_box.json)
+REF_BOX_TFLOPS, REF_BOX_COPY_GBS, REF_BOX_FPS = 769.0, 5056.2, 207.4    # calibrate() and the headline on the box profiles/r04_bench_final.json was taken on (boxes of the pool spread ~5 %: 200.7 ... 210.5 frames/s over the round's runs, profiles/r04_bench_final_second_box.json)
 
 
 def flop_model(cfg, V, h, w):
