@@ -31,7 +31,7 @@ from toc3d_amd import configs, lib, synth  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PAPER_FPS = 1000.0 / 209.0      # ToC3D-Faster ViT-L 6x(800x320) backbone 209.0 ms, fp32, GPU unstated
-REF_BOX_TFLOPS, REF_BOX_COPY_GBS, REF_BOX_FPS = 769.0, 5056.2, 207.4    # calibrate() and the headline on the box profiles/r04_bench_final.json was taken on (boxes of the pool spread ~5 %: 200.7 ... 210.5 frames/s over the round's runs, profiles/r04_bench_final_second_box.json)
+REF_BOX_TFLOPS, REF_BOX_COPY_GBS, REF_BOX_FPS = 773.4, 5017.9, 201.4    # calibrate() and the headline on the box profiles/r04_bench_final.json was taken on (boxes of the pool spread ~5 %: 200.7 ... 210.5 frames/s over the round's runs of the final code)
 
 
 def flop_model(cfg, V, h, w):
@@ -700,6 +700,29 @@ def main():
             res["parity_path_fast"] = {"precision": "fp32x3 (f32 buffers; a.w = hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16, f32 accumulate)",
                                        "value": frames_per_step * kx3 / ex3, "unit": "frames/s", "ms_per_step": 1e3 * ex3 / kx3, "steps": kx3,
                                        "parity": "<= 1e-3 rel. max err vs the reference's fp32 features on every full-size golden case (tests/test_gpu_e2e.py::test_vitl_fp32_matches_reference[fp32x3])"}
+        if not args.no_parity_path and args.precision == "bf16" and world == 1:
+            # ... and the f32-GRADE form of the same idea: a three-way split, six bf16 MFMAs per product (dropped terms <= 2^-26: as accurate as the exact-f32 MFMA
+            # in tests/test_gpu_ops.py::test_linear_bf16x3_products_on_f32_operands), every other kernel in its exact-f32 form
+            mx6 = toc3d_amd.build_backbone(dict(cfg, precision="fp32x6"))
+            mx6.load_state_dict(sd_cpu)
+            mx6 = mx6.to(dev).eval()
+            mx6.alias_outputs, mx6.launch_mode = True, args.launch
+            nx6 = toc3d_amd.build_neck(dict(configs.CPFPN_CFG, precision="fp32x6"))
+            nx6.load_state_dict(synth.neck_state_dict(configs.CPFPN_CFG))
+            nx6 = nx6.to(dev).eval()
+            nx6.alias_outputs, nx6.launch_mode = True, args.launch
+            tx6 = os.path.join(ROOT, "toc3d_amd", "tuned", f"{args.config}_{H}x{W}_fp32x6.json")
+            if os.path.exists(tx6):
+                mx6.load_tuning(tx6)
+                nx6._tuned.update(mx6._tuned)
+            model, neck = mx6, nx6
+            step()
+            torch.cuda.synchronize()
+            kx6 = max(3, min(args.steps, 10))
+            ex6 = tdist.timed_steps(step, kx6, 2, dev)
+            res["parity_path_x6"] = {"precision": "fp32x6 (f32 buffers; a.w from six bf16 MFMAs on (hi, mid, lo) splits: f32-grade products; exact-f32 attention)",
+                                     "value": frames_per_step * kx6 / ex6, "unit": "frames/s", "ms_per_step": 1e3 * ex6 / kx6, "steps": kx6,
+                                     "parity": "<= 1e-3 rel. max err vs the reference's fp32 features on every full-size golden case (tests/test_gpu_e2e.py::test_vitl_fp32_matches_reference[fp32x6])"}
         if not args.no_other_configs and world == 1 and args.config == "toc3d_faster" and (H, W) == (320, 800) and not args.frames_total:
             # BASELINE.json configs 3 and 4, driver-timed in the same line: the dense EVA_ViT baseline (keep ratio 1.0) and ToC3D_faster at 6 x 1600 x 640
             res["other_configs"] = [side_leg("eva_dense", 320, 800, args, dev, sd_cpu, tdist), side_leg("toc3d_faster", 640, 1600, args, dev, sd_cpu, tdist)]
