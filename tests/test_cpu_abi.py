@@ -346,3 +346,22 @@ def test_frame_timeline_cuts_frames_and_counts_idle_time():
     assert r["launches"] == 5 and r["span"] == 2200 and r["idle"] == 50 and r["foreign"] == 1
     assert r["families"]["gemm_kernel (all toc3d_linear* launches)"] == [2, 2000]
     assert r["families"]["motion_queries_kernel (side lane)"] == [1, 600]
+
+
+def test_header_constants_match_the_python_binding():
+    """dtype / epilogue codes of include/toc3d.h and their twins in toc3d_amd/lib.py (what the host passes through ctypes) and csrc/common.h (what the library
+    compares against) are one table."""
+    txt = open(lib.HEADER_PATH).read()
+    hdr = {m[1]: int(m[2]) for m in re.finditer(r"#define\s+(TOC3D_(?:DTYPE|EPI)_\w+)\s+(\d+)\b", txt)}
+    py = {"TOC3D_DTYPE_F32": lib.F32, "TOC3D_DTYPE_BF16": lib.BF16, "TOC3D_DTYPE_F32X3": lib.F32X3, "TOC3D_DTYPE_F32X6": lib.F32X6,
+          "TOC3D_DTYPE_F32X3W": lib.F32X3W, "TOC3D_DTYPE_F32X3P": lib.F32X3P, "TOC3D_DTYPE_F32X3WO": lib.F32X3WO, "TOC3D_DTYPE_F32X3WA": lib.F32X3WA,
+          "TOC3D_EPI_BIAS": lib.EPI_BIAS, "TOC3D_EPI_RESIDUAL": lib.EPI_RESIDUAL, "TOC3D_EPI_SWIGLU": lib.EPI_SWIGLU, "TOC3D_EPI_GELU": lib.EPI_GELU,
+          "TOC3D_EPI_SWIGLU_STATS": lib.EPI_SWIGLU_STATS, "TOC3D_EPI_RESIDUAL_LN": lib.EPI_RESIDUAL_LN, "TOC3D_EPI_RESIDUAL_STATS": lib.EPI_RESIDUAL_STATS,
+          "TOC3D_EPI_SWIGLU_STATS_LN": lib.EPI_SWIGLU_STATS_LN, "TOC3D_EPI_CONV3X3": lib.EPI_CONV3X3, "TOC3D_EPI_QKV_ROPE": lib.EPI_QKV_ROPE}
+    for k, v in py.items():
+        assert hdr.get(k) == v, (k, hdr.get(k), v)
+    common = open(os.path.join(os.path.dirname(os.path.abspath(toc3d_amd.__file__)), "csrc", "common.h")).read()
+    enum = dict((m[1], int(m[2])) for m in re.finditer(r"(TOC3D_(?:F32|BF16)\w*)\s*=\s*(\d+)", common))
+    for k, v in py.items():
+        if k.startswith("TOC3D_DTYPE_"):
+            assert enum.get("TOC3D_" + k[len("TOC3D_DTYPE_"):]) == v, (k, enum)
