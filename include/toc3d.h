@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TOC3D_ABI_VERSION 6   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
+#define TOC3D_ABI_VERSION 7   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
 
 #define TOC3D_OK 0
 #define TOC3D_ERR_ARG (-1)
@@ -169,6 +169,26 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
                        float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap,
                        const float* col_sums, int64_t ln_n, float ln_eps, void* out_act, int64_t ld_act, const int32_t* residual_index,
                        toc3d_stream_t stream);
+
+/* Deterministic split-K for the residual epilogues (TOC3D_EPI_RESIDUAL, _RESIDUAL_LN, _RESIDUAL_STATS: attn.proj eva_vit.py:115,262 / toc3d_eva_vit.py:514,379 and
+ * mlp.w3 eva_vit.py:49,263 / toc3d_eva_vit.py:384 -- N = C = 1024 outputs per row, i.e. 136-376 tiles of 128x128 for a 6-view frame on a 256-CU chip).
+ *   variant = 1000 * split + tile variant: `split` (2 .. TOC3D_SPLITK_MAX) workgroups per output tile, each multiplying its own range of K (cuts at multiples of
+ *   128 elements, the same for every tile variant); tile variants with a split-K form: 1, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 55, 56 (bf16; f32 / bf16 x 3: not 29, 55, 56).
+ *   The partial accumulators meet in `workspace`; the workgroup that arrives last at a tile's ticket adds them IN SLICE ORDER (its own from registers) and runs the
+ *   epilogue -- no atomics on data, no workgroup waits for another: outputs are bit-reproducible from run to run and identical for every tile variant of one
+ *   `split` (they differ from the unsplit variants in the last bits: another order of the K sum).
+ *   workspace: >= toc3d_linear_splitk_workspace_bytes(variant, M, N) bytes, 256-byte aligned; its first TOC3D_SPLITK_TICKET_BYTES hold the arrival tickets and must
+ *   be ZERO before the first launch (every launch leaves them zero again); the rest is scratch.  Launches on one stream may share a workspace, launches that can
+ *   run concurrently must not.  variant < 1000 = toc3d_linear_fused (workspace ignored). */
+#define TOC3D_SPLITK_MAX 4
+#define TOC3D_SPLITK_TICKET_BYTES 65536
+int64_t toc3d_linear_splitk_workspace_bytes(int variant, int64_t M, int64_t N);      /* < 0: not a split-K variant */
+int toc3d_linear_fused_ws(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw,
+                          const float* bias, void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                          float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                          float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap,
+                          const float* col_sums, int64_t ln_n, float ln_eps, void* out_act, int64_t ld_act, const int32_t* residual_index,
+                          void* workspace, int64_t workspace_bytes, toc3d_stream_t stream);
 
 #ifdef TOC3D_EXPERIMENTAL   /* round-3 experiment, measured 1.3-2x slower than the separate launches: only in `make EXPERIMENTAL=1` builds */
 /* Several dependent linear layers of one transformer-block half in ONE persistent launch (bf16): attn.proj + residual -> [norm2] -> mlp.w1 | mlp.w2
@@ -387,7 +407,9 @@ int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t
  *   dropped rows per window): same arguments, same results BIT FOR BIT (the partial sums are formed and added in the order of the single-workgroup
  *   kernel), plus `scratch` = toc3d_gather_merge_ln_scratch_bytes(nW, C) bytes of device memory, 256-byte aligned, zeroed ONCE by the caller (arrival
  *   counters + f32 partials; the kernel re-arms the counters itself, so a recorded launch plan replays it without a memset).  One scratch buffer per
- *   stream that may run the kernel. */
+ *   stream that may run the kernel; layout = [TOC3D_GATHER_SPLIT_COUNTER_BYTES of counters | partials], the same for every nW, so launches of different
+ *   window counts on one stream may share a buffer sized for the largest. */
+#define TOC3D_GATHER_SPLIT_COUNTER_BYTES 16384
 int64_t toc3d_gather_merge_ln_scratch_bytes(int64_t nW, int64_t C);
 int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                                 const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,

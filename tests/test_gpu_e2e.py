@@ -424,6 +424,31 @@ def test_carried_compact_set_matches_scatter_gather_between_blocks():
     assert not m32.carry_compact, "the strict-parity path keeps the reference's scatter / gather between all blocks by default"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_split_merge_shares_one_scratch_between_window_types(precision):
+    """gather_split=True end to end where the two window types of a plan have window counts in different 256-byte buckets of the old scratch layout
+    (two frames per forward at 800x320: 96 local and 36 global windows; ADVICE r04: the small launch's partials overwrote counter words 64.. of the
+    large one, whose representative rows were then never written).  The split merge must return the bits of the single-workgroup merge, on every
+    frame of a replayed plan."""
+    cfg = configs.get("toc3d_faster")
+    inp = synth.stack_frames([synth.make_inputs(cfg, n_frames=1, views_per_frame=6, seed=f) for f in range(2)])
+    outs = {}
+    for split in (False, True, 16):
+        _, m = build("toc3d_faster", precision)
+        m.gather_split, m.autotune = split, False
+        feats = []
+        for _ in range(3):                                   # eager warm-up, recording, replay
+            o = run_toc3d(m, inp, True)
+            feats.append(o.img_feats["last_feat"].float().clone())
+        assert torch.equal(feats[1], feats[2])
+        outs[split] = (feats[2], [k.clone() for k in o.keep_idx])
+        del m
+    for split in (True, 16):
+        assert torch.equal(outs[split][0], outs[False][0]), f"gather_split={split}: features differ from the single-workgroup merge"
+        for s in range(3):
+            assert torch.equal(outs[split][1][s], outs[False][1][s])
+
+
 def test_carried_compact_set_on_long_runs_of_one_window_type():
     """A layout the shipped configs do not have: up to six consecutive accelerated blocks of one window type within a stage
     (global_attn_indexes=(2, 11), pruning_loc=[3, 9]).  Carried sets must pair up (3,4) (5,6) (7,8); a block after a pair starts from

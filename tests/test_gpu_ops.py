@@ -805,7 +805,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
     assert relerr(c1, (gamma * W3).to(tdt).double().sum(1)) < 1e-5 and relerr(c2, (W3.double() * beta.double()).sum(1) + b3.double()) < 1e-5
     cap = 6
     ref_stats = ref_out = ref_rep = None
-    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 54, 55, 56, 57, 58, 116, 117, 119, 126, 149, 151, 154, 216, 219, 249, 316, 317, 349):      # incl. every variant a shipped table names for this epilogue
+    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 116, 117, 119, 126, 149, 151, 154, 160, 163, 216, 219, 249, 316, 317, 349):      # incl. every variant a shipped table names for this epilogue
         stats = torch.zeros(4 + M * cap * 2, device=DEV)
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd,
@@ -818,7 +818,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
             ref_stats = st.clone()
             assert relerr(st[..., 0].sum(1), hid0.double().sum(1)) < 1e-5 and relerr(st[..., 1].sum(1), (hid0.double() ** 2).sum(1)) < 1e-5
         assert torch.equal(st, ref_stats), f"variant {v}: row statistics depend on the tile variant"
-    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 110, 114, 116, 117, 126, 145, 149, 151, 152, 156, 214, 217, 226, 314, 317, 326):
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 60, 61, 62, 63, 110, 114, 116, 117, 126, 145, 149, 151, 152, 156, 160, 161, 214, 217, 226, 314, 317, 326):
         out = res.clone()
         rep = torch.zeros(nrep, C, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,
@@ -976,7 +976,7 @@ def test_norm2_folded_across_the_projection_boundary():
     lib.call("toc3d_pack_swiglu_lnfold", dt, w1, w2, bb1, bb2, g2, b2, Hd, C, w12f, c1, c2, Hp, C, S())
     cap2, cap = C // 64, 6
     ref_a = ref_st = ref_h = None
-    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 54, 55, 56, 57, 58, 114, 116, 117, 126, 145, 156):
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 114, 116, 117, 126, 145, 156, 160, 162):
         x = x0.clone()
         a_raw = torch.full((M, C), 9.0, dtype=tdt, device=DEV)
         st2 = torch.zeros(4 + M * cap2 * 2, device=DEV)
@@ -991,7 +991,7 @@ def test_norm2_folded_across_the_projection_boundary():
             ref_a, ref_st = a_raw.clone(), s2.clone()
             assert relerr(s2[..., 0].sum(1), a_raw.double().sum(1)) < 1e-5 and relerr(s2[..., 1].sum(1), (a_raw.double() ** 2).sum(1)) < 1e-5
         assert torch.equal(s2, ref_st), f"variant {v}: row statistics depend on the tile variant"
-    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 54, 55, 56, 57, 58, 116, 117, 126, 149, 154):
+    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 116, 117, 126, 149, 154, 160, 163):
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         st = torch.zeros(4 + M * cap * 2, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS_LN, v, ref_a, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,

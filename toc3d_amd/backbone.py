@@ -162,8 +162,8 @@ _flush = None                   # 256 MB scratch shared by all models: evicts L2
 
 # + 100: 8 row bands per XCD.  The 2-D XCD partitions (+ 200 / + 300, round 3) win 6-20 % on isolated cold w1|w2 / w3 launches and nothing inside the frame
 # (profiles/r03_xcd_order_sweep.txt): they stay available through the C ABI but are not tuning candidates.
-_VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 152,
-                        154, 155, 156, 158, 159, 163),
+_VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 152,
+                        154, 155, 156, 158, 159, 160, 161, 163),
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126),
              lib.F32X3: (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 114, 116, 117, 122, 126, 149)}
 _VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3W] = _VARIANTS[lib.F32X3P] = _VARIANTS[lib.F32X3WO] = _VARIANTS[lib.F32X3WA] = _VARIANTS[lib.F32X3]
@@ -213,8 +213,6 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
         rope = fused
         if var is None:
             var = self._tuned.get((lib.EPI_BIAS, M, N, K), 0)
-        if var % 100 in (60, 61, 62, 63):                        # the phased tiles do not carry the RoPE tables
-            var = 0
         lib.call("toc3d_linear_qkv_rope", dtg, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
         return
     if var is None:
@@ -232,9 +230,7 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
             if epi in (lib.EPI_SWIGLU, lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):
                 cands = [v for v in cands if v not in (33, 45, 145, 52, 53, 152)]   # wave slabs that are not whole (w1, w2) 32-column groups
             if epi in (lib.EPI_SWIGLU_STATS, lib.EPI_SWIGLU_STATS_LN):  # statistics slots are 128 packed columns: N-tiles of 128 / 256 only
-                cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47, 60, 63)]
-            if epi in (lib.EPI_RESIDUAL_LN, lib.EPI_RESIDUAL_STATS):   # the phased tiles do not carry the folded-LayerNorm epilogues
-                cands = [v for v in cands if v % 100 not in (60, 63)]
+                cands = [v for v in cands if v % 100 not in (9, 13, 14, 27, 33, 45, 47)]
             # Inside the block sequence every GEMM starts on cold operands (the previous kernels streamed tens of MB through
             # L2 / Infinity Cache): time single launches behind a cache-sized memset, not a warm back-to-back loop, or the
             # tuner prefers shallow pipelines that lose in place (tools/ubench/n1024_all_variants.py).
@@ -262,6 +258,18 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
             short = sorted((cold_time(v, 3), v) for v in cands)[:4]
             var = min((cold_time(v, 9), v) for _, v in short)[1]
         self._tuned[key] = var
+    if var >= 1000:
+        # a deterministic split-K pick (include/toc3d.h, toc3d_linear_fused_ws; only a table can name one: the tuner's candidates are the unsplit variants --
+        # measured slower on every launch of the frame, profiles/r05_splitk.txt).  One zeroed workspace per owner and stream: launches on one lane share it.
+        need = int(lib.load().toc3d_linear_splitk_workspace_bytes(var, M, N))
+        pool = self.__dict__.setdefault("_sk_ws", {})
+        ws = pool.get(s)
+        if ws is None or ws.numel() * 4 < need:
+            if ws is not None:
+                self.__dict__.setdefault("_sk_ws_old", []).append(ws)      # recorded plans may still name it
+            ws = pool[s] = torch.zeros((need + 3) // 4, dtype=torch.int32, device=out.device)
+        lib.call("toc3d_linear_fused_ws", dtg, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, ws, ws.numel() * 4, s)
+        return
     lib.call("toc3d_linear_fused", dtg, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
 
 
@@ -334,7 +342,7 @@ class _BackboneBase(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._packed = None
-        self._plans = {}                # (the Gumbel frame counter survives: plans on the same device keep naming it, _rng_state re-creates it on a new one)
+        self._plans = {}                # (the Gumbel frame counter survives: plans on the same device keep naming it, _rng_state carries its value to a new one)
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -344,13 +352,18 @@ class _BackboneBase(nn.Module):
 
     # -- copies / pickles: recorded launch plans (native handles with baked device pointers), workspaces and packed weights belong to
     # THIS instance's buffers; a copy starts without them and re-packs / re-records on its first forward -----------------------------
-    _TRANSIENT = ("_packed", "_plans", "_stream_pool", "_gumbel_rng")
+    _TRANSIENT = ("_packed", "_plans", "_stream_pool", "_gumbel_rng", "_sk_ws", "_sk_ws_old")
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_packed"], d["_plans"], d["_stream_pool"] = None, {}, []
-        if "_gumbel_rng" in d:
-            d["_gumbel_rng"] = None                    # a copy draws its own stream from frame 0 (same seed)
+        d.pop("_sk_ws", None)
+        d.pop("_sk_ws_old", None)
+        if d.get("_gumbel_rng") is not None:
+            # A copy CONTINUES the noise stream where this model stands (same key, the counter's value carried as a host tensor that _rng_state moves to
+            # the copy's device) instead of replaying it from frame 0: original and replica then draw the same noise for the frames that follow -- replicas
+            # of a model that has run share their noise; assign a different gumbel_seed to a replica that needs its own stream.
+            d["_gumbel_rng"] = d["_gumbel_rng"].detach().to("cpu").clone()
         return d
 
     def __deepcopy__(self, memo):
@@ -857,7 +870,7 @@ class ToC3DEVAViT(_BackboneBase):
         # forward, so torch.manual_seed() before inference is honoured like by the reference's generator), counter = ONE frame counter per model
         # (_gumbel_rng, device memory), shared by every launch plan -- a second input shape, or a plan rebuilt after eviction, continues the stream
         # instead of replaying it from frame 0.
-        self.gumbel_seed = None
+        self._gumbel_seed = None
         self._gumbel_rng = None
         half = embed_dim // num_heads // 2
         self.score_predictor = nn.ModuleList([_Scorer(embed_dim, pruning_num_queries, token_ratio[i], pc_range)
@@ -1026,12 +1039,26 @@ class ToC3DEVAViT(_BackboneBase):
             m["groups"].append(gp)
         return m
 
+    @property
+    def gumbel_seed(self):
+        return self._gumbel_seed
+
+    @gumbel_seed.setter
+    def gumbel_seed(self, seed):
+        # the key is an argument of the recorded toc3d_gumbel_noise launch: plans recorded with the old key must not be replayed
+        if seed != self._gumbel_seed:
+            self._plans = {}
+        self._gumbel_seed = seed
+
     def _rng_state(self, dev):
-        """The model's Gumbel frame counter (uint64 [2]: counter, ticket) on ``dev`` -- created once, named by every recorded plan."""
-        if self._gumbel_rng is None or self._gumbel_rng.device != dev:
+        """The model's Gumbel frame counter (uint64 [2]: counter, ticket) on ``dev`` -- created once, named by every recorded plan.  A model that
+        moves to another device (or a copy restored from __getstate__) takes the counter's VALUE along: the stream continues, it is not replayed."""
+        if self._gumbel_rng is None:
             self._gumbel_rng = torch.zeros(2, dtype=torch.int64, device=dev)
-            if self.gumbel_seed is None:
-                self.gumbel_seed = int(torch.initial_seed()) & 0x7fffffffffffffff
+        elif self._gumbel_rng.device != dev:
+            self._gumbel_rng = self._gumbel_rng.to(dev)
+        if self._gumbel_seed is None:
+            self._gumbel_seed = int(torch.initial_seed()) & 0x7fffffffffffffff
         return self._gumbel_rng
 
     # -- scorer stage (toc3d_eva_vit.py:264-285) -------------------------------------------------------

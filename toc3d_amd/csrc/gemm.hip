@@ -325,7 +325,8 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
                0, 0, nullptr, nullptr, nullptr, 0, 1.0f, planes_a, planes, planes_o};
     if (planes) {
         TOC3D_REQUIRE(epilogue != TOC3D_EPI_CONV3X3 || !planes_a, "toc3d_linear: the 3x3 conv gathers f32 activations (A cannot be planes)");
-        TOC3D_REQUIRE((!planes_o || ((!e_swiglu || (ldo % 32 == 0 && (uintptr_t)out % 16 == 0)) && (!out_act || (ld_act % 32 == 0 && (uintptr_t)out_act % 16 == 0)))) &&
+        const void* act_copy = epilogue == TOC3D_EPI_CONV3X3 ? nullptr : out_act;     // (the conv carries its zero line and h << 32 | w in these two slots)
+        TOC3D_REQUIRE((!planes_o || ((!e_swiglu || (ldo % 32 == 0 && (uintptr_t)out % 16 == 0)) && (!act_copy || (ld_act % 32 == 0 && (uintptr_t)act_copy % 16 == 0)))) &&
                       (!planes_a || lda % 32 == 0),
                       "toc3d_linear: rows of (hi, lo) planes are whole 32-element groups on 16-byte boundaries: lda, ldo (SwiGLU) and ld_act must be multiples of 32");
     }
@@ -338,11 +339,58 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
     return TOC3D_OK;
 }
 
+// Deterministic split-K (variant = 1000 * split + tile variant): workspace = [TOC3D_SPLITK_TICKET_BYTES of arrival tickets | f32 partial tiles].  The ticket
+// region has a FIXED size, so launches of different shapes may share one workspace on one stream (the partials are scratch between launches, the tickets are
+// zero between launches: every tile's last arriver re-arms its word).
+static_assert(TOC3D_SPLITK_TICKET_BYTES % 256 == 0, "the partial tiles start on a 256-byte boundary");
+int64_t toc3d_linear_splitk_workspace_bytes(int variant, int64_t M, int64_t N) {
+    const int split = variant / 1000;
+    const int64_t elems = toc3d_gemm_splitk_tile_elems(variant % 1000);
+    if (split < 2 || split > TOC3D_SPLITK_MAX || elems == 0 || M < 0 || N <= 0) return -1;
+    const int64_t bn = elems == 128 * 64 ? 64 : (elems == 64 * 64 ? 64 : 128), bm = elems / bn;
+    const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    if (tiles * 4 > TOC3D_SPLITK_TICKET_BYTES) return -1;
+    return TOC3D_SPLITK_TICKET_BYTES + tiles * split * elems * 4;
+}
+
+int toc3d_linear_fused_ws(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                          void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
+                          float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
+                          float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
+                          void* out_act, int64_t ld_act, const int32_t* residual_index, void* workspace, int64_t workspace_bytes, toc3d_stream_t stream) {
+    if (variant < 1000)
+        return toc3d_linear_fused(dtype, epilogue, variant, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index, M, N, K, n_valid,
+                                  stats_out, stats_out_cap, stats_in, stats_in_cap, col_sums, ln_n, ln_eps, out_act, ld_act, residual_index, stream);
+    TOC3D_REQUIRE(epilogue == TOC3D_EPI_RESIDUAL || epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS,
+                  "toc3d_linear_fused_ws: split-K serves the residual epilogues (1, 5, 6), not %d", epilogue);
+    const int64_t need = toc3d_linear_splitk_workspace_bytes(variant, M, N);
+    TOC3D_REQUIRE(need > 0, "toc3d_linear_fused_ws: variant %d has no split-K form (split 2..%d of tile variants 1, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 55, 56), or too many tiles", variant, TOC3D_SPLITK_MAX);
+    TOC3D_REQUIRE(workspace && ((uintptr_t)workspace % 256) == 0 && workspace_bytes >= need, "toc3d_linear_fused_ws: workspace of >= %lld bytes, 256-byte aligned (toc3d_linear_splitk_workspace_bytes)", (long long)need);
+    TOC3D_REQUIRE(K >= 128 * (variant / 1000), "toc3d_linear_fused_ws: K = %lld is too short for a split of %d", (long long)K, variant / 1000);
+    GemmArgs a;
+    const int rc_args = fused_args(a, dtype, epilogue, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index, M, N, K, n_valid,
+                                   stats_out, stats_out_cap, stats_in, stats_in_cap, col_sums, ln_n, ln_eps, out_act, ld_act, residual_index);
+    if (rc_args != TOC3D_OK) return rc_args;
+    if (M == 0) return TOC3D_OK;
+    a.split = variant / 1000;
+    a.sk_tickets = reinterpret_cast<unsigned*>(workspace);
+    a.sk_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + TOC3D_SPLITK_TICKET_BYTES);
+    const bool x3 = dtype == TOC3D_F32X3 || (dtype >= TOC3D_F32X3W && dtype <= TOC3D_F32X3WA);
+    TOC3D_REQUIRE(dtype == TOC3D_BF16 || dtype == TOC3D_F32 || x3, "toc3d_linear_fused_ws: split-K serves bf16, f32 and the bf16 x 3 forms");
+    g_bad_variant = false;
+    const int rc = toc3d_gemm_launch_splitk(x3 ? TOC3D_F32X3 : dtype, epilogue, variant % 1000, a, as_stream(stream));
+    if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear_fused_ws: tile variant %d has no split-K form for this dtype", variant % 1000); return rc; }
+    if (g_bad_variant) { toc3d_set_error("toc3d_linear_fused_ws: K = %lld is not a whole number of the K-tiles of variant %d", (long long)K, variant % 1000); return TOC3D_ERR_UNSUPPORTED; }
+    TOC3D_LAUNCH_CHECK("toc3d_linear_fused_ws");
+    return TOC3D_OK;
+}
+
 int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,
                        float* rep_out, const int32_t* rep_index, int64_t M, int64_t N, int64_t K, int64_t n_valid,
                        float* stats_out, int64_t stats_out_cap, const float* stats_in, int64_t stats_in_cap, const float* col_sums, int64_t ln_n, float ln_eps,
                        void* out_act, int64_t ld_act, const int32_t* residual_index, toc3d_stream_t stream) {
+    TOC3D_REQUIRE(variant < 1000, "toc3d_linear: variant %d is a split-K variant: it takes a workspace (toc3d_linear_fused_ws)", variant);
     GemmArgs a;
     const int rc_args = fused_args(a, dtype, epilogue, A, lda, W, ldw, bias, out, ldo, residual, ldr, residual_row_mod, rep_out, rep_index, M, N, K, n_valid,
                                    stats_out, stats_out_cap, stats_in, stats_in_cap, col_sums, ln_n, ln_eps, out_act, ld_act, residual_index);

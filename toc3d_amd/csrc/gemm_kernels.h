@@ -50,6 +50,9 @@ struct GemmArgs {
     // bf16 x 3 on (hi, lo) PLANES (TOC3D_DTYPE_F32X3W / F32X3P, include/toc3d.h): an operand that already is in the planes layout is DMA'd as it lies and
     // not split in LDS; out_planes: the act-dtype outputs that a later GEMM multiplies (SwiGLU hidden units, out_act) are written as planes
     int a_planes, w_planes, out_planes;
+    // deterministic split-K (toc3d_linear_fused_ws, variants >= 1000): `split` workgroups per output tile, each over its own range of K; f32 partial tiles
+    // through sk_slabs, arrival tickets in sk_tickets (zero before the first launch; the last arriver re-arms its word)
+    int split; float* sk_slabs; unsigned* sk_tickets;
 };
 
 extern thread_local bool g_bad_variant;                // set by a launch_cfg whose tile variant cannot serve the requested epilogue (gemm.hip)
@@ -62,6 +65,8 @@ int toc3d_gemm_launch_rope(int is_bf16, int epi, int variant, const GemmArgs& a,
 int toc3d_gemm_launch_lnself(int epi, int variant, const GemmArgs& a, hipStream_t s);                   // bf16: EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF
 int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 3 products on f32 operands: epilogues 0-3, 8
 int toc3d_gemm_launch_x6(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 6 (three-way split): f32-grade products
+int toc3d_gemm_launch_splitk(int dtype, int epi, int variant, const GemmArgs& a, hipStream_t s);       // residual epilogues with a.split > 1 (gemm_epi_splitk.hip); dtype: TOC3D_BF16 / TOC3D_F32 / TOC3D_F32X3
+int64_t toc3d_gemm_splitk_tile_elems(int variant);                                                      // BM * BN of a split-K tile variant (0: the variant has no split-K form)
 
 // ---- GEMM chains (gemm_chain.hip; include/toc3d.h, toc3d_linear_chain): several dependent GEMMs of one block half in ONE persistent launch ----
 constexpr int TOC3D_CHAIN_MAX_OPS = 3;
@@ -615,27 +620,10 @@ TOC3D_DEV void split_bf16x6(const Frag<float>& f, bf16x8& hi, bf16x8& mid, bf16x
     }
 }
 
-// One BM x BN output tile (rows m0.., columns n0..) by the calling workgroup of 64 * WM * WN threads: K loop + fused epilogue.  `smem` = the
-// workgroup's dynamic LDS.  gemm_kernel below runs one tile per workgroup; gemm_chain_kernel walks a queue of tiles of several GEMMs.
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int X3 = 0, int OCC = 1>
-TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* smem) {
-    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4) || (X3 == 32 && sizeof(T) == 2), "the bf16 x 3 / x 6 product forms run on f32 operands, the 32x32x16 MFMA form on bf16");
-    constexpr bool MF32 = X3 == 32;                     // v_mfma_f32_32x32x16_bf16 in the K loop (see lds_frag32); accumulators handed to the epilogue as 16x16 tiles
-    constexpr int SW = MF32 ? 1 : 0;
-    constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
-    constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
-    constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
-    constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;
-    constexpr int LOADS = (BM * (RB / 16) + NTHR - 1) / NTHR + (BN * (RB / 16) + NTHR - 1) / NTHR;   // global_load_lds per thread per K-tile (stage_tile rounds up)
-    static_assert(((BM * (RB / 16)) % NTHR == 0 && (BN * (RB / 16)) % NTHR == 0) || (X3 == 0 && EPI != TOC3D_EPI_CONV3X3),
-                  "tiles with a partial DMA round: plain bf16 / f32 operand loaders only");
-    constexpr int KS = RB / 32 / (int)sizeof(T);        // 32-wide K steps per K-tile
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r16 = lane & 15, g = lane >> 4;
-
-    f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
-    auto ln_rows_prepare = [&]() {
+// (mean, rstd) per tile row from the partial sums the producing GEMM left (include/toc3d.h), into the row table `lnrow` [BM] in LDS.  Four threads per row;
+// thread part p sums slots p, p + 4, ... in sequence, the parts meet in two butterfly steps; f64.  The order is fixed: the bits do not depend on the tile variant.
+template <int EPI, int BM, int NTHR>
+TOC3D_DEV void ln_rows_prepare_fn(const GemmArgs& a, const int m0, f32x2* lnrow, const int tid) {
         const int nslots = a.stats_in_slots > 0 ? a.stats_in_slots : *reinterpret_cast<const int*>(a.stats_in);
         const f32x2* base = reinterpret_cast<const f32x2*>(a.stats_in + 4);
         for (int w = tid; w < BM * 4; w += NTHR) {
@@ -654,7 +642,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
                 const int sl = part + 4 * j;
-                pv[j] = sp[sl < nslots ? sl : part];
+                pv[j] = sp[sl < nslots ? sl : 0];           // (slot 0 always exists: stats_in_cap >= 1; `part` itself may lie past the row when it has < 4 slots)
             }
 #pragma unroll
             for (int j = 0; j < PRE; ++j)
@@ -672,7 +660,149 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
             if (part == 0) lnrow[r] = f32x2{(float)mean, 1.0f / sqrtf((float)var + a.ln_eps)};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // table rows written before this wave reaches the K loop's first barrier
-    };
+}
+
+// The part of a tile behind its K loop: the fused epilogue of the workgroup's accumulators (+ the statistics hand-off of the folded LayerNorms).  Shared by
+// gemm_tile and the phased big-tile kernel.  PRE_BARRIER: the K loop did not end on a workgroup barrier (the statistics overlay the operand stages at `smem`).
+template <typename T, int EPI, int BM, int BN, int WM, int WN, bool PRE_BARRIER>
+TOC3D_DEV void tile_finish(const GemmArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], const int m0, const int n0, char* smem, const f32x2* lnrow,
+                           const int* rope_rcs, const float* rope_tab) {
+    constexpr int NTHR = 64 * WM * WN, TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, g = lane >> 4;
+    if constexpr (epi_stats_out(EPI)) {
+        // Row statistics of the act-dtype values this launch wrote, for the LayerNorm folded into the next GEMM (include/toc3d.h).  A slot is
+        // 128 packed columns (SwiGLU: 64 hidden units) or 64 output columns (residual), i.e. always four column groups of the epilogue, and is
+        // built in ONE fixed tree for every tile variant: lane -> its 4 values in order; group = butterfly over the 4 lane groups;
+        // slot = (g0 + g1) + (g2 + g3), combined through LDS whatever wave computed the groups.
+        constexpr int G = epi_stat_groups(EPI, NT);      // groups per wave-tile row
+        constexpr int GW = epi_is_swiglu(EPI) ? 32 : 16; // columns per group
+        constexpr int SLOT = 4 * GW, GPT = BN / GW;      // columns per slot, groups per tile row
+        static_assert(BN % SLOT == 0 && (epi_is_swiglu(EPI) ? NT % 2 == 0 : true), "statistics need N-tiles of whole slots");
+        float gs[MT * G], gq[MT * G];
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq, lnrow + wm * TM);
+        // `red` overlays the operand stages: every wave must be done reading them.  The single-buffer loop ends on that barrier already (behind its last
+        // multiply); the rings end on a multiply.  (The row table lives behind the stages and is not touched.)
+        if constexpr (PRE_BARRIER) tile_barrier();
+        f32x2* red = reinterpret_cast<f32x2*>(smem);     // [GPT][BM]
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jp = 0; jp < G; ++jp) {
+                const float s1 = g4_sum(gs[i * G + jp]), s2 = g4_sum(gq[i * G + jp]);
+                if (g == 0) red[(wn * G + jp) * BM + wm * TM + i * 16 + r16] = f32x2{s1, s2};
+            }
+        lds_barrier();
+        f32x2* data = reinterpret_cast<f32x2*>(a.stats + 4);
+        for (int w = tid; w < BM * (GPT / 4); w += NTHR) {
+            const int r = w % BM, sl = w / BM;
+            const int row = m0 + r;
+            if (row >= a.M) continue;
+            const f32x2 v0 = red[(4 * sl) * BM + r], v1 = red[(4 * sl + 1) * BM + r], v2 = red[(4 * sl + 2) * BM + r], v3 = red[(4 * sl + 3) * BM + r];
+            data[(int64_t)row * a.stats_cap + n0 / SLOT + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
+        }
+        if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + SLOT - 1) / SLOT;
+    } else if constexpr (epi_is_rope(EPI)) {
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM, rope_rcs, rope_tab);
+    } else if constexpr (epi_ln_in(EPI)) {
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM);
+    } else {
+        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
+    }
+}
+
+// ---- deterministic split-K: the exchange of the partial accumulators ---------------------------------------------------------------------
+// Every slice stores its f32 partial tile WRITE-THROUGH (sc1: the data leaves the XCD's L2 with the store, so no release fence -- cdna_hip_programming.md
+// Guideline 16, R1), in the accumulators' own register order ([MT * NT][NTHR] 16-byte pieces: perfectly coalesced, and the reader has the same order);
+// every wave drains its stores, the workgroup meets, ONE lane takes the tile's ticket (relaxed, agent scope).  The workgroup that draws S - 1 is the reducer:
+// it reads the other slices' partials with sc1 loads (L2-served, never a stale L1 line; valid because the producers stored sc1) and adds
+//     p(0) + p(1) + ... + p(S - 1)      left to right, its own partial from registers at its own position,
+// so the result does not depend on WHICH slice arrived last -- bit-reproducible, no atomics on data.  It re-arms the ticket for the next launch (a recorded
+// launch plan needs no memset node) and goes on to the epilogue.  No workgroup ever waits for another: nothing here depends on dispatch order or residency.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int S, int ME, int MT, int NT, int NTHR, int TILE_ELEMS>
+TOC3D_DEV void sk_combine(f32x4 (&acc)[MT][NT], const __amdgpu_buffer_rsrc_t rs, const int tid) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4 v[S];
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                if (q == ME) v[q] = acc[i][j];
+                else v[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (q * TILE_ELEMS + ((i * NT + j) * NTHR + tid) * 4) * 4, 0, 16));
+            }
+            f32x4 r = v[0];
+#pragma unroll
+            for (int q = 1; q < S; ++q) r += v[q];
+            acc[i][j] = r;
+        }
+}
+template <int MT, int NT, int NTHR, int TILE_ELEMS>
+TOC3D_DEV bool sk_exchange(const GemmArgs& a, f32x4 (&acc)[MT][NT], char* smem, const int tile, const int slice, const int tid) {
+    static_assert(MT * NT * NTHR * 4 == TILE_ELEMS, "the partial tile is the accumulators of the whole workgroup");
+    const int S = a.split;
+    // (a buffer descriptor on the tile's S partials: wave-uniform base, 32-bit offsets)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.sk_slabs + (size_t)tile * S * TILE_ELEMS, 0, S * TILE_ELEMS * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, (slice * TILE_ELEMS + ((i * NT + j) * NTHR + tid) * 4) * 4, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its own stores ...
+    tile_barrier();                                          // ... before the workgroup meets (also: every wave is done with the operand stages, smem is free)
+    unsigned* s_ticket = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(a.sk_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)(S - 1)) __hip_atomic_store(a.sk_tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // last arriver: re-armed for the next launch
+        *s_ticket = t;
+    }
+    lds_barrier();
+    const unsigned ticket = *s_ticket;
+    tile_barrier();                                          // every wave has read the word: smem is free again (the statistics epilogues overlay it)
+    if (ticket != (unsigned)(S - 1)) return false;
+    // all control of the sum is compile-time: S - 1 loads per accumulator and no branch around any of them (a run-time "register or load" select would
+    // make hipcc wait per element: cdna_hip_programming.md, traps (c))
+    switch (S * 8 + slice) {
+        case 2 * 8 + 0: sk_combine<2, 0, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+        case 2 * 8 + 1: sk_combine<2, 1, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+        case 3 * 8 + 0: sk_combine<3, 0, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+        case 3 * 8 + 1: sk_combine<3, 1, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+        case 3 * 8 + 2: sk_combine<3, 2, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+        case 4 * 8 + 0: sk_combine<4, 0, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+        case 4 * 8 + 1: sk_combine<4, 1, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+        case 4 * 8 + 2: sk_combine<4, 2, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+        default: sk_combine<4, 3, MT, NT, NTHR, TILE_ELEMS>(acc, rs, tid); break;
+    }
+    return true;
+}
+
+// One BM x BN output tile (rows m0.., columns n0..) by the calling workgroup of 64 * WM * WN threads: K loop + fused epilogue.  `smem` = the
+// workgroup's dynamic LDS.  gemm_kernel below runs one tile per workgroup; gemm_chain_kernel walks a queue of tiles of several GEMMs.
+// SK = 1: deterministic split-K (a.split workgroups per tile).  The calling workgroup multiplies K range `sk_slice` of tile `sk_tile` only; the partial
+// accumulators meet through a.sk_slabs and the workgroup that arrives LAST at the tile's ticket adds them in slice order (so the sum does not depend on which
+// one that is) and runs the epilogue; the others return after their store.  See sk_exchange below.
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int X3 = 0, int OCC = 1, int SK = 0>
+TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* smem, const int sk_tile = 0, const int sk_slice = 0) {
+    static_assert(SK == 0 || (EPI != TOC3D_EPI_CONV3X3 && !epi_is_rope(EPI) && !epi_ln_self(EPI) && X3 != 32), "split-K serves the plain linear epilogues on the 16x16x32 K loop");
+    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4) || (X3 == 32 && sizeof(T) == 2), "the bf16 x 3 / x 6 product forms run on f32 operands, the 32x32x16 MFMA form on bf16");
+    constexpr bool MF32 = X3 == 32;                     // v_mfma_f32_32x32x16_bf16 in the K loop (see lds_frag32); accumulators handed to the epilogue as 16x16 tiles
+    constexpr int SW = MF32 ? 1 : 0;
+    constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
+    constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
+    constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
+    constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;
+    constexpr int LOADS = (BM * (RB / 16) + NTHR - 1) / NTHR + (BN * (RB / 16) + NTHR - 1) / NTHR;   // global_load_lds per thread per K-tile (stage_tile rounds up)
+    static_assert(((BM * (RB / 16)) % NTHR == 0 && (BN * (RB / 16)) % NTHR == 0) || (X3 == 0 && EPI != TOC3D_EPI_CONV3X3),
+                  "tiles with a partial DMA round: plain bf16 / f32 operand loaders only");
+    constexpr int KS = RB / 32 / (int)sizeof(T);        // 32-wide K steps per K-tile
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, g = lane >> 4;
+
+    f32x2* lnrow = reinterpret_cast<f32x2*>(smem + STAGES * STAGE_BYTES);   // [BM], only allocated for EPI_RESIDUAL_LN
+    auto ln_rows_prepare = [&]() { ln_rows_prepare_fn<EPI, BM, NTHR>(a, m0, lnrow, tid); };
     // Register-capped tiles: the table is formed FIRST, while nothing else of the tile is live -- behind the first operand request (where the uncapped tiles do
     // it, overlapped with that request's flight) its batch of loads spills.  One exposed L2 round trip instead of 4-11 dependent ones.
     constexpr bool PREP_EARLY = epi_ln_stats_in(EPI) && OCC > 1;
@@ -684,7 +814,16 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     const T* A = reinterpret_cast<const T*>(a.A);
     const T* W = reinterpret_cast<const T*>(a.W);
     constexpr int BK = RB / (int)sizeof(T);
-    const int nk = a.K / BK;
+    // split-K: slice q of S multiplies elements [b(q), b(q + 1)) of K, b(q) = 128 * round(q * K / (128 S)) -- whole K-tiles of every variant (BK divides 128), and
+    // the same cut for every variant, so the bits depend on S alone (one bit class per S, like the unsplit variants among themselves)
+    static_assert(SK == 0 || 128 % BK == 0, "split-K cuts K at multiples of 128 elements");
+    int k_base = 0, nk = a.K / BK;
+    if constexpr (SK != 0) {
+        const int n64 = a.K / 64, S = a.split;
+        const int lo = sk_slice == 0 ? 0 : 128 * ((sk_slice * n64 + S) / (2 * S)), hi = sk_slice + 1 == S ? a.K : 128 * (((sk_slice + 1) * n64 + S) / (2 * S));
+        k_base = lo;
+        nk = (hi - lo) / BK;
+    }
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -754,9 +893,9 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + (u * NTHR + wave * 64) * 16), 16, 0, 0);
             }
         } else {
-            stage_tile<T, BM, RB, NTHR, SW>(A, a.lda, m0, a.M - 1, t * BK, slot, wave, lane);
+            stage_tile<T, BM, RB, NTHR, SW>(A, a.lda, m0, a.M - 1, k_base + t * BK, slot, wave, lane);
         }
-        stage_tile<T, BN, RB, NTHR, SW>(W, a.ldw, n0, w_max, t * BK, slot + A_BYTES, wave, lane);
+        stage_tile<T, BN, RB, NTHR, SW>(W, a.ldw, n0, w_max, k_base + t * BK, slot + A_BYTES, wave, lane);
     };
     auto multiply = [&](int t) {
         const char* sA = smem + (t % STAGES) * STAGE_BYTES;
@@ -957,6 +1096,9 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         if constexpr (epi_is_rope(EPI)) { wait_vmcnt<0>(); tile_barrier(); }
     }
     TOC3D_TRACE(1);
+    if constexpr (SK != 0) {
+        if (!sk_exchange<MT, NT, NTHR, BM * BN>(a, acc, smem, sk_tile, sk_slice, tid)) return;      // not the last arriver of this tile: the partial is stored, done
+    }
     if constexpr (MF32) {
 #pragma unroll
         for (int i = 0; i < MT32; ++i)
@@ -983,54 +1125,26 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         }
         lds_barrier();
     }
-    if constexpr (epi_stats_out(EPI)) {
-        // Row statistics of the act-dtype values this launch wrote, for the LayerNorm folded into the next GEMM (include/toc3d.h).  A slot is
-        // 128 packed columns (SwiGLU: 64 hidden units) or 64 output columns (residual), i.e. always four column groups of the epilogue, and is
-        // built in ONE fixed tree for every tile variant: lane -> its 4 values in order; group = butterfly over the 4 lane groups;
-        // slot = (g0 + g1) + (g2 + g3), combined through LDS whatever wave computed the groups.
-        constexpr int G = epi_stat_groups(EPI, NT);      // groups per wave-tile row
-        constexpr int GW = epi_is_swiglu(EPI) ? 32 : 16; // columns per group
-        constexpr int SLOT = 4 * GW, GPT = BN / GW;      // columns per slot, groups per tile row
-        static_assert(BN % SLOT == 0 && (epi_is_swiglu(EPI) ? NT % 2 == 0 : true), "statistics need N-tiles of whole slots");
-        float gs[MT * G], gq[MT * G];
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, gs, gq, lnrow + wm * TM);
-        // `red` overlays the operand stages: every wave must be done reading them.  The single-buffer loop ends on that barrier already (behind its last
-        // multiply); the rings end on a multiply.  (The row table lives behind the stages and is not touched.)
-        if constexpr (STAGES > 1) tile_barrier();
-        f32x2* red = reinterpret_cast<f32x2*>(smem);     // [GPT][BM]
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int jp = 0; jp < G; ++jp) {
-                const float s1 = g4_sum(gs[i * G + jp]), s2 = g4_sum(gq[i * G + jp]);
-                if (g == 0) red[(wn * G + jp) * BM + wm * TM + i * 16 + r16] = f32x2{s1, s2};
-            }
-        lds_barrier();
-        f32x2* data = reinterpret_cast<f32x2*>(a.stats + 4);
-        for (int w = tid; w < BM * (GPT / 4); w += NTHR) {
-            const int r = w % BM, sl = w / BM;
-            const int row = m0 + r;
-            if (row >= a.M) continue;
-            const f32x2 v0 = red[(4 * sl) * BM + r], v1 = red[(4 * sl + 1) * BM + r], v2 = red[(4 * sl + 2) * BM + r], v3 = red[(4 * sl + 3) * BM + r];
-            data[(int64_t)row * a.stats_cap + n0 / SLOT + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
-        }
-        if (m0 == 0 && n0 == 0 && tid == 0) *reinterpret_cast<int*>(a.stats) = (a.N + SLOT - 1) / SLOT;
-    } else if constexpr (epi_is_rope(EPI)) {
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM, rope_rcs, rope_tab);
-    } else if constexpr (epi_ln_in(EPI)) {
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g, nullptr, nullptr, lnrow + wm * TM);
-    } else {
-        gemm_epilogue<T, EPI, MT, NT>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
-    }
+    tile_finish<T, EPI, BM, BN, WM, WN, (STAGES > 1)>(a, acc, m0, n0, smem, lnrow, rope_rcs, rope_tab);
 }
 
-template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int OCC, int X3 = 0>
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int OCC, int X3 = 0, int SK = 0>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TOC3D_TRACE(0);
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tiles_m = (a.M + BM - 1) / BM;
     int m0, n0;
+    if constexpr (SK != 0) {
+        // split-K: grid = tiles * split.  Unit u = slice * tiles + tile, the units cut into 8 contiguous XCD chunks: an XCD works on neighbouring tiles of ONE
+        // K range (their A row panels and that range of W stay in its L2), and the slices of a tile run on different XCDs at about the same time.
+        const int tiles = tiles_m * tiles_n;
+        const int u = xcd_remap(blockIdx.x, tiles * a.split);
+        const int slice = u / tiles, tile = u - slice * tiles;
+        gemm_tile<T, EPI, BM, BN, STAGES, RB, WM, WN, X3, OCC, 1>(a, (tile / tiles_n) * BM, (tile % tiles_n) * BN, smem, tile, slice);
+        TOC3D_TRACE_END();
+        return;
+    }
     if (a.order == 0) {
         const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
         m0 = (tile / tiles_n) * BM;
@@ -1139,6 +1253,32 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
     const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
     const int nk = a.K / 64;
     const int a_max = a.M - 1, w_max = ((a.N + 127) / 128) * 128 - 1;
+    // behind the two-K-tile ring: the (mean, rstd) row table of the LayerNorm-consuming epilogues, then the RoPE tables of the rotating q|k|v epilogue
+    f32x2* lnrow = reinterpret_cast<f32x2*>(smem + 2 * KT);
+    const float* rope_tab = nullptr;
+    int rope_rcs[epi_is_rope(EPI) ? 2 * MT2 : 1];
+    if constexpr (epi_is_rope(EPI)) {
+        // requested FIRST: the oldest requests of the wave, so every counted s_waitcnt vmcnt of the K loop has retired them long before the epilogue
+        char* dst = smem + 2 * KT + (epi_ln_in(EPI) ? BM * 8 : 0);
+        const int nchunk = a.rope_L * 16;                // 16-byte pieces of [cos | sin]
+        for (int c0 = wave * 64; c0 < nchunk; c0 += NTHR) {
+            int c = c0 + lane;
+            c = c < nchunk ? c : 0;
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.rope_tab) + c * 16), (lptr_t)(dst + c0 * 16), 16, 0, 0);
+        }
+        rope_tab = reinterpret_cast<const float*>(dst);
+#pragma unroll
+        for (int i = 0; i < 2 * MT2; ++i) {
+            const int row = m0 + wm * TM + i * 16 + r16;
+            rope_rcs[i] = a.rope_rc[row < a.M ? row : a.M - 1];
+        }
+    }
+    // the row table before anything else of the tile is live (one exposed L2 round trip; behind the prologue's requests its loads would drain the whole
+    // DMA queue: hipcc waits vmcnt(0) for an ordinary load issued beside LDS-DMA)
+    if constexpr (epi_ln_stats_in(EPI)) {
+        ln_rows_prepare_fn<EPI, BM, NTHR>(a, m0, lnrow, tid);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     f32x4 acc[2 * MT2][2 * NT2];
 #pragma unroll
@@ -1214,10 +1354,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
         mfma(I1(), I0());
         tile_barrier();
     }
-    if (!late) tile_barrier();                            // every wave executes the same number of barriers
+    if (!late) tile_barrier();                            // every wave executes the same number of barriers (and is done with the ring: the statistics overlay it)
     TOC3D_TRACE(1);
 
-    gemm_epilogue<bf16_t, EPI, 2 * MT2, 2 * NT2>(a, acc, m0 + wm * TM, n0 + wn * TN, r16, g);
+    tile_finish<bf16_t, EPI, BM, BN, WM, WN, false>(a, acc, m0, n0, smem, lnrow, rope_rcs, rope_tab);
     TOC3D_TRACE_END();
 }
 
@@ -1249,14 +1389,56 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
     }
 }
 
+// split-K form of a tile variant (a.split = 2 .. TOC3D_SPLITK_MAX workgroups per tile; gemm_epi_splitk.hip instantiates the residual epilogues on a few tiles)
+template <typename T, int EPI, int BM, int BN, int STAGES, int RB = 128, int WM = 2, int WN = 2, int OCC = 1, int X3 = 0>
+void launch_cfg_sk(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);
+    static Toc3dLdsAttr attr;
+    if (lds > 48 * 1024) attr.ensure(reinterpret_cast<const void*>(&gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC, X3, 1>), lds);
+    if (a.K % (RB / (int)sizeof(T)) != 0) { g_bad_variant = true; return; }       // the last slice ends at K: K must be whole K-tiles (the cuts are multiples of 128)
+    const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
+    toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC, X3, 1>), dim3(tm * tn * a.split), dim3(64 * WM * WN), lds, s, a);
+}
+// tile variants that have a split-K form (variant mod 1000 of toc3d_linear_fused_ws; variant / 1000 = the split): BM * BN, or 0
+constexpr int64_t sk_tile_elems(int v) {
+    return (v == 16 || v == 17 || v == 28 || v == 29 || v == 1 || v == 51 || v == 22) ? 128 * 128 : (v == 55 || v == 56) ? 96 * 128 : v == 19 ? 256 * 128 : (v == 10 || v == 26) ? 64 * 128 : v == 9 ? 128 * 64 : v == 14 ? 64 * 64 : 0;
+}
+template <typename T, int EPI, int X3 = 0>
+int launch_epi_sk(int variant, const GemmArgs& a, hipStream_t s) {
+    constexpr bool B = sizeof(T) == 2;
+    switch (variant) {
+        case 1: launch_cfg_sk<T, EPI, 128, 128, 2, 128, 2, 2, 1, X3>(a, s); break;
+        case 9: launch_cfg_sk<T, EPI, 128, 64, 2, 128, 2, 2, 1, X3>(a, s); break;
+        case 10: launch_cfg_sk<T, EPI, 64, 128, 2, 128, 2, 2, 1, X3>(a, s); break;
+        case 14: launch_cfg_sk<T, EPI, 64, 64, 2, 128, 2, 2, 1, X3>(a, s); break;
+        case 16: launch_cfg_sk<T, EPI, 128, 128, 1, 128, 2, 4, (B ? 6 : 1), X3>(a, s); break;
+        case 17: launch_cfg_sk<T, EPI, 128, 128, 2, 128, 2, 4, 1, X3>(a, s); break;
+        case 19: launch_cfg_sk<T, EPI, 256, 128, 1, 128, 4, 2, 1, X3>(a, s); break;
+        case 22: launch_cfg_sk<T, EPI, 128, 128, 1, 256, 2, 4, 1, X3>(a, s); break;
+        case 26: launch_cfg_sk<T, EPI, 64, 128, 1, 256, 2, 4, 1, X3>(a, s); break;
+        case 28: launch_cfg_sk<T, EPI, 128, 128, 3, 128, 2, 4, 1, X3>(a, s); break;
+        case 29: if constexpr (X3 == 0) launch_cfg_sk<T, EPI, 128, 128, 4, 128, 2, 4, 1, X3>(a, s); else return TOC3D_ERR_ARG; break;
+        case 51: if constexpr (B) launch_cfg_sk<T, EPI, 128, 128, 1, 128, 2, 4, 8, X3>(a, s); else return TOC3D_ERR_ARG; break;
+        case 55: if constexpr (X3 == 0) launch_cfg_sk<T, EPI, 96, 128, 2, 128, 2, 4, 1, X3>(a, s); else return TOC3D_ERR_ARG; break;
+        case 56: if constexpr (X3 == 0) launch_cfg_sk<T, EPI, 96, 128, 4, 128, 2, 4, 1, X3>(a, s); else return TOC3D_ERR_ARG; break;
+        default: return TOC3D_ERR_ARG;
+    }
+    return TOC3D_OK;
+}
+
 template <int EPI, int BM, int BN, int WM, int WN>
 void launch_phased(const GemmArgs& a, hipStream_t s) {
-    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || EPI >= TOC3D_EPI_SWIGLU_STATS) {   // the phased kernel carries neither the folded-LayerNorm epilogues, the conv gather nor the RoPE tables
+    // round 5: every linear epilogue (the folded LayerNorms' statistics in and out, the rotating q|k|v epilogue); not the conv gather (its own operand loader)
+    // nor the experimental self-normalising forms (statistics inside the K loop)
+    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) || EPI == TOC3D_EPI_CONV3X3 || epi_ln_self(EPI) ||
+                  EPI == TOC3D_EPI_RESIDUAL_ACT) {
         g_bad_variant = true;
     } else {
-        constexpr int lds = 2 * (BM + BN) * 128;              // two K-tiles of 64 bf16
+        constexpr int lds_fixed = 2 * (BM + BN) * 128 + (epi_ln_in(EPI) ? BM * 8 : 0);              // two K-tiles of 64 bf16 (+ the row table)
+        const int lds = lds_fixed + (epi_is_rope(EPI) ? (a.rope_L * 256 + 1023) / 1024 * 1024 : 0);   // + the RoPE tables (cos | sin), whole DMA instructions
+        if (lds > 160 * 1024) { g_bad_variant = true; return; }
         static Toc3dLdsAttr attr;
-        attr.ensure(reinterpret_cast<const void*>(&gemm_phased_kernel<EPI, BM, BN, WM, WN>), lds);
+        attr.ensure(reinterpret_cast<const void*>(&gemm_phased_kernel<EPI, BM, BN, WM, WN>), lds_fixed + (epi_is_rope(EPI) ? 64 * 256 : 0));
         const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
         const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;
         toc3d_launch((gemm_phased_kernel<EPI, BM, BN, WM, WN>), dim3(tiles), dim3(512), lds, s, a);
@@ -1394,10 +1576,8 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
 #endif  // TOC3D_EXPERIMENTAL
         // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
         case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB
-#ifdef TOC3D_EXPERIMENTAL
         case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
         case 62: if (sizeof(T) == 2) launch_phased<EPI, 128, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
-#endif
         case 63: if (sizeof(T) == 2) launch_phased<EPI, 128, 128, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x32 per wave, 64 KiB: two per CU
         default: return TOC3D_ERR_ARG;
     }

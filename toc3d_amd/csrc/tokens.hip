@@ -885,9 +885,12 @@ int toc3d_gather_merge_ln_ex(int dtype, const float* x, int64_t C, const int32_t
 }
 
 
+// scratch = [TOC3D_GATHER_SPLIT_COUNTER_BYTES of arrival counters][nW][16][C] f32 partials.  The counter region has a FIXED size: launches of different nW
+// (the two window types of a plan: 126 and 60 windows at 640x1600, 96 and 36 at B = 2) may share one scratch buffer on one stream -- with a launch-dependent
+// start of the partials, the float data of the small-nW launch overwrote counter words of the large-nW one.
 int64_t toc3d_gather_merge_ln_scratch_bytes(int64_t nW, int64_t C) {
     if (nW <= 0 || C <= 0) return 0;
-    return 256 * ((nW * 4 + 255) / 256) + nW * 16 * C * 4;               // [counters, padded to 256 B][nW][16][C] f32 partials
+    return TOC3D_GATHER_SPLIT_COUNTER_BYTES + nW * 16 * C * 4;
 }
 
 int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
@@ -900,9 +903,10 @@ int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int3
     TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW && N - k <= 1024, "toc3d_gather_merge_ln_split: bad k / lda / rows");
     TOC3D_REQUIRE(scratch && ((uintptr_t)scratch % 256) == 0 && scratch_bytes >= toc3d_gather_merge_ln_scratch_bytes(nW, C),
                   "toc3d_gather_merge_ln_split: scratch of toc3d_gather_merge_ln_scratch_bytes(nW, C) bytes, 256-byte aligned, zeroed once by the caller");
+    TOC3D_REQUIRE(nW * 4 <= TOC3D_GATHER_SPLIT_COUNTER_BYTES, "toc3d_gather_merge_ln_split: at most %d windows per launch", TOC3D_GATHER_SPLIT_COUNTER_BYTES / 4);
     if (nW <= 0) return TOC3D_OK;
     unsigned* counters = reinterpret_cast<unsigned*>(scratch);
-    float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + 256 * ((nW * 4 + 255) / 256));
+    float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + TOC3D_GATHER_SPLIT_COUNTER_BYTES);
     const int sp = split == 0 ? 4 : (int)split, wpb = 16 / sp;
     dim3 grid((unsigned)(((nW + 7) / 8) * 8 * sp + (rows + wpb - 1) / wpb)), block(64 * wpb);
     const size_t lds = (size_t)C * 4 + 16;
@@ -935,6 +939,7 @@ int toc3d_gather_merge_ln_pending(int dtype, float* x, int64_t C, const int32_t*
     TOC3D_REQUIRE(prev_inverse && prev_slow && rep_raw1 && rep_raw2, "toc3d_gather_merge_ln_pending: the pending scatter needs its inverse map, compact rows and two updates");
     TOC3D_REQUIRE((rep_raw3 == nullptr) == (rep_raw4 == nullptr), "toc3d_gather_merge_ln_pending: rep_raw3 and rep_raw4 come as a pair");
     TOC3D_REQUIRE(prev_slow != shortcut, "toc3d_gather_merge_ln_pending: the previous compact rows are read while `shortcut` is written: two buffers");
+    TOC3D_REQUIRE(dtype == TOC3D_BF16 || dtype == TOC3D_F32, "toc3d_gather_merge_ln_pending: bf16 / f32 only (the planes form has no pending-scatter kernel: it would silently drop the scatter)");
     TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln_pending: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
     TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW && N - k <= 1024, "toc3d_gather_merge_ln_pending: bad k / lda / rows");
     if (nW <= 0) return TOC3D_OK;

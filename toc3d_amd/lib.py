@@ -14,14 +14,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so"))       # TOC3D_LIB: an experimental build beside the shipped one
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
-ABI_VERSION = 6                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
+ABI_VERSION = 7                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
 F32, BF16, F32X3, F32X6, F32X3W, F32X3P, F32X3WO, F32X3WA = 0, 1, 2, 3, 4, 5, 6, 7          # F32X3: linear layers only -- f32 buffers, products as three bf16 MFMAs (include/toc3d.h)
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF = 10, 11, 12, 13
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
 # GEMM tile variants (mod 100; + 100 / 200 / 300 select the XCD order at run time) the product library carries: every variant the autotuner may pick or a
 # shipped table names.  EXPERIMENTAL=1 builds add the rest (csrc/gemm_kernels.h launch_epi).
-PRODUCT_VARIANTS = (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 63)
+PRODUCT_VARIANTS = (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63)
 
 
 def has_variant(v: int) -> bool:
@@ -34,6 +34,7 @@ _SIGS = {
     "toc3d_linear": "iiplplpplpllppllllp",
     "toc3d_linear_ex": "iiiplplpplpllppllllp",
     "toc3d_linear_fused": "iiiplplpplpllppllll" + "plplplf" + "pl" + "p" + "p",
+    "toc3d_linear_fused_ws": "iiiplplpplpllppllll" + "plplplf" + "pl" + "p" + "pl" + "p",
     "toc3d_pack_swiglu_lnfold": "ippppppllpppllp",
     "toc3d_pack_weight_lnfold": "ippppllpllppp",
     "toc3d_conv3x3_nhwc": "iiplplpplllllpp",
@@ -143,6 +144,8 @@ def load():
     lib.toc3d_motion_weights_floats.restype = _I64
     lib.toc3d_window_topk_rows.restype = _I64
     lib.toc3d_window_topk_rows.argtypes = [_I64] * 5
+    lib.toc3d_linear_splitk_workspace_bytes.restype = _I64
+    lib.toc3d_linear_splitk_workspace_bytes.argtypes = [_I, _I64, _I64]
     lib.toc3d_gather_merge_ln_scratch_bytes.restype = _I64
     lib.toc3d_gather_merge_ln_scratch_bytes.argtypes = [_I64, _I64]
     lib.toc3d_plan_lane_stream.restype = _P
