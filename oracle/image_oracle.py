@@ -6,7 +6,10 @@ Follows, in order (``projects/configs/ToC3D/ToC3D_faster.py:206-214``):
   * ``PadMultiViewImage._pad_img``        (``datasets/pipelines/transform_3d.py:38-50``)  -> ``mmcv.impad_to_multiple``
   * ``DefaultFormatBundle`` image branch  (``mmdetection3d/mmdet3d/datasets/pipelines/formating.py:42-47``): HWC -> CHW, stack views
 
-PARITY UNPINNED for this file: the arithmetic lives in mmcv-full 1.6.0 (``README.md:52``) and OpenCV, neither of which
+PINNED AGAINST THE REFERENCE'S CLASSES since round 5: tests/golden/image_norm.npz is the output of the reference's own ``NormalizeMultiviewImage`` /
+``PadMultiViewImage`` (executed from /root/reference by oracle/gen_golden_image.py) and this file reproduces it bit for bit
+(tests/test_cpu_oracle_golden.py::test_image_oracle_against_the_reference_pipeline_classes).  What stays PARITY UNPINNED is the arithmetic of the two mmcv
+functions those classes call, which the generator had to stand in for from their published definitions: the arithmetic lives in mmcv-full 1.6.0 (``README.md:52``) and OpenCV, neither of which
 is vendored in /root/reference nor installed here, and the reference holds no test or golden vector for it.  Restated
 from the published sources:
   mmcv/image/photometric.py ``imnormalize_``:  ``mean = float64(mean); stdinv = 1 / float64(std);

@@ -365,3 +365,14 @@ def test_header_constants_match_the_python_binding():
     for k, v in py.items():
         if k.startswith("TOC3D_DTYPE_"):
             assert enum.get("TOC3D_" + k[len("TOC3D_DTYPE_"):]) == v, (k, enum)
+
+
+def test_unchanged_reference_config_builds_the_parity_grade_precision():
+    """A config without a `precision` key (a reference config dropped in unchanged) builds the path that meets the reference's 1e-3 tolerance, not the bf16
+    headline path (INTEGRATION.md "Precision"); backbone and neck agree."""
+    from toc3d_amd.backbone import DEFAULT_PRECISION
+    assert DEFAULT_PRECISION == "fp32x3"
+    for name in ("toc3d_tiny", "eva_tiny"):
+        assert toc3d_amd.build_backbone(configs.get(name)).precision == "fp32x3"
+        assert toc3d_amd.build_backbone(dict(configs.get(name), precision="bf16")).precision == "bf16"
+    assert toc3d_amd.build_neck(configs.CPFPN_TINY).precision == "fp32x3"

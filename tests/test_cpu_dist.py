@@ -201,3 +201,29 @@ def test_bench_py_launcher_contract_world2_dry_run():
         # the self-proving part of an N > 1 line: rank census + per-rank checksums through the collective itself
         assert d["config"]["ranks_seen"] == [0, 1] and d["config"]["gather_verified"] is True
         assert d["config"]["gather_bytes"] == 2 * 6 * 4 * 2 * 5 * 2         # two ranks x bf16 features
+
+
+def test_bench_py_launcher_contract_world8_dry_run():
+    """The driver's N = 8 launch (python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8) in dry-run mode: weak scaling (one frame per rank)
+    and strong scaling with --frames-total 64 (eight frames per rank as ONE forward of B = 8, samplers/distributed_sampler.py:41-44): every rank is seen, the
+    exchange is verified through the collective itself, value = frames / max-over-ranks time.  (No GPU node is available to this build: SURVEY.md 8e, BASELINE
+    config 5 -- this pins the control flow the driver's 8-GPU run will execute.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TOC3D_BENCH_DRY_RUN="1", OMP_NUM_THREADS="1")
+    for extra, scaling, fps, fpf in (([], "weak", 8, 1), (["--frames-total", "64"], "strong", 64, 8)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["frames_per_step"] == fps and d["config"]["frames_per_forward"] == fpf
+        assert d["config"]["ranks_seen"] == list(range(8)) and d["config"]["gather_verified"] is True
+        assert d["config"]["gather_bytes"] == 8 * 6 * 4 * 2 * 5 * 2
+        assert abs(d["value"] - fps * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+        if not extra:
+            assert d["config"]["last_exchange"] == [float(r_) for r_ in range(8)]

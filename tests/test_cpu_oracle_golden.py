@@ -129,6 +129,22 @@ def test_image_oracle_normalise_pad_format():
     assert np.array_equal(I.imnormalize(img[0].astype(np.float32), mean, std, False), I.imnormalize(img[0], mean, std, False))
 
 
+def test_image_oracle_against_the_reference_pipeline_classes(golden_dir):
+    """oracle/image_oracle.py bit-exact against tests/golden/image_norm.npz: the reference's own NormalizeMultiviewImage.__call__ / PadMultiViewImage._pad_img
+    (transform_3d.py:87-100,38-50) executed by oracle/gen_golden_image.py with the configs' mean / std / size_divisor, ragged sizes, both channel orders.
+    The classes are pinned by this; mmcv.imnormalize / impad_to_multiple themselves were stand-ins written from the published definitions (mmcv / OpenCV are
+    absent): that arithmetic stays unpinned upstream, as the fixture's `pinned` field says."""
+    from oracle import image_oracle as I
+    g = np.load(os.path.join(golden_dir, "image_norm.npz"))
+    assert "stand-ins" in str(g["pinned"]) and "executed" in str(g["pinned"])
+    mean, std, div = g["mean"].tolist(), g["std"].tolist(), int(g["size_divisor"])
+    for tag in "abcd":
+        u8, to_rgb, exp = g[f"{tag}_u8"], bool(g[f"{tag}_to_rgb"]), g[f"{tag}_expected"]
+        out = I.prepare_images(u8, mean, std, to_rgb, div)
+        assert out.shape == exp.shape and out.dtype == np.float32
+        assert np.array_equal(out.view(np.uint32), exp.view(np.uint32)), f"case {tag}: the oracle differs from the reference pipeline's output"
+
+
 def test_memory_bank_oracle_matches_reference_golden(golden_dir):
     """oracle/memory_oracle.py against tests/golden/memory_bank.npz, written by the reference's own
     StreamPETRHead.pre/post_update_memory (oracle/gen_golden_memory.py): bit-exact over a 4-frame sequence incl. a scene change."""

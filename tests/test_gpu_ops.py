@@ -663,6 +663,17 @@ def test_normalize_images_matches_oracle_bit_exact(to_rgb, V, H, W):
         prepare_images(torch.from_numpy(img), IMG_NORM["mean"], IMG_NORM["std"], to_rgb, 32)
 
 
+def test_normalize_images_matches_the_reference_pipeline_golden(golden_dir):
+    """toc3d_normalize_images against tests/golden/image_norm.npz -- the reference's own NormalizeMultiviewImage / PadMultiViewImage classes executed on the
+    configs' arguments (oracle/gen_golden_image.py; mmcv's two functions stood in for from their published definitions): bit-exact."""
+    from toc3d_amd.preprocess import prepare_images
+    g = np.load(os.path.join(golden_dir, "image_norm.npz"))
+    for tag in "abcd":
+        u8, to_rgb, exp = g[f"{tag}_u8"], bool(g[f"{tag}_to_rgb"]), g[f"{tag}_expected"]
+        out = prepare_images(torch.from_numpy(u8).to(DEV), g["mean"].tolist(), g["std"].tolist(), to_rgb, int(g["size_divisor"]))
+        assert torch.equal(out.cpu(), torch.from_numpy(exp)), f"case {tag}"
+
+
 @pytest.mark.parametrize("name,dt,tdt", DTYPES)
 @pytest.mark.parametrize("H,W", [(320, 800), (300, 790)])
 def test_im2col_u8_equals_im2col_of_normalized_images(name, dt, tdt, H, W):
@@ -836,7 +847,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
     lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, 16, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,
              None, 0, stats, cap | ((2 * Hp + 127) // 128) << 32, c1, Hd, eps, None, 0, None, S())
     assert torch.equal(out, ref_out) and torch.equal(rep, ref_rep)
-    for v, epi in ((47, lib.EPI_SWIGLU_STATS), (9, lib.EPI_SWIGLU_STATS), (60, lib.EPI_SWIGLU_STATS), (60, lib.EPI_RESIDUAL_LN)):
+    for v, epi in ((47, lib.EPI_SWIGLU_STATS), (9, lib.EPI_SWIGLU_STATS)):       # (the phased tiles 60-63 serve the folded epilogues since round 5: in the loops above)
         with pytest.raises(RuntimeError, match="cannot serve"):
             if epi == lib.EPI_SWIGLU_STATS:
                 lib.call("toc3d_linear_fused", dt, epi, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd, stats, cap, None, 0, None, 0, 0.0, None, 0, None, S())

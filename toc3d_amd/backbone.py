@@ -157,6 +157,13 @@ def _init_weights(m):
 # ------------------------------------------------------------------------------------------------
 # shared engine: weight packing + per-shape plan + the launch sequence
 # ------------------------------------------------------------------------------------------------
+# What a reference config dropped in UNCHANGED gets (no `precision` key): the fastest path that meets the reference's own tolerance -- north_star's
+# 1e-3 relative on the fp32 feature maps (tools/test.py:204-206 runs the reference in fp32): "fp32x3" (f32 buffers, every contraction as three bf16 MFMAs on (hi, lo)
+# operand splits: 3e-5 rel. max on the full-size goldens, ~0.5x the bf16 path's frames/s).  "bf16" -- BASELINE.json configs[1], the benchmarked headline: rel. L2
+# 1.3e-2 with the reference's token selection forced, like a torch-bf16 run of the reference -- is an explicit opt-in (`precision="bf16"` in the config dict);
+# "fp32" = exact-f32 MFMA (5e-6), "fp32x6" = f32-grade products from six bf16 MFMAs.  INTEGRATION.md, "Precision".
+DEFAULT_PRECISION = "fp32x3"
+
 _flush = None                   # 256 MB scratch shared by all models: evicts L2 + Infinity Cache between tuning launches
 
 
@@ -766,7 +773,7 @@ class EVA_ViT(_BackboneBase):
                  use_abs_pos=True, use_rel_pos=False, rope=True, pt_hw_seq_len=16, intp_freq=True, window_size=0,
                  global_window_size=20, use_checkpoint=True, global_attn_indexes=(), residual_block_indexes=(),
                  use_act_checkpoint=False, pretrain_img_size=224, pretrain_use_cls_token=True, return_intermediate=False,
-                 out_feature="last_feat", xattn=True, precision="bf16", **unused):
+                 out_feature="last_feat", xattn=True, precision=DEFAULT_PRECISION, **unused):
         super().__init__()
         if use_rel_pos or len(residual_block_indexes) or return_intermediate or not rope or not intp_freq or window_size <= 0:
             raise NotImplementedError("use_rel_pos / residual blocks / return_intermediate / rope=False / window_size=0 "
@@ -842,7 +849,7 @@ class ToC3DEVAViT(_BackboneBase):
                  use_act_checkpoint=False, pretrain_img_size=224, pretrain_use_cls_token=True, out_feature="last_feat",
                  return_intermediate=False, xattn=True, pruning_loc=None, pruning_score_type="attention", score_mask=True,
                  pruning_attn_scale=True, pruning_num_queries=256, accelerate_global=True, token_ratio=None,
-                 use_represent_tokens=True, pc_range=None, token_selection_loss=None, precision="bf16", **unused):
+                 use_represent_tokens=True, pc_range=None, token_selection_loss=None, precision=DEFAULT_PRECISION, **unused):
         super().__init__()
         if (use_rel_pos or len(residual_block_indexes) or return_intermediate or not rope or not rope_acc or not intp_freq
                 or pruning_score_type != "attention" or not score_mask or not use_represent_tokens or window_size <= 0):

@@ -695,10 +695,11 @@ TOC3D_DEV void tile_finish(const GemmArgs& a, f32x4 (&acc)[BM / WM / 16][BN / WN
             }
         lds_barrier();
         f32x2* data = reinterpret_cast<f32x2*>(a.stats + 4);
+        const int nslots = (a.N + SLOT - 1) / SLOT;      // (a 256-wide tile at the right edge covers slots that do not exist: they would land in the next row's slots)
         for (int w = tid; w < BM * (GPT / 4); w += NTHR) {
             const int r = w % BM, sl = w / BM;
             const int row = m0 + r;
-            if (row >= a.M) continue;
+            if (row >= a.M || n0 / SLOT + sl >= nslots) continue;
             const f32x2 v0 = red[(4 * sl) * BM + r], v1 = red[(4 * sl + 1) * BM + r], v2 = red[(4 * sl + 2) * BM + r], v3 = red[(4 * sl + 3) * BM + r];
             data[(int64_t)row * a.stats_cap + n0 / SLOT + sl] = f32x2{(v0[0] + v1[0]) + (v2[0] + v3[0]), (v0[1] + v1[1]) + (v2[1] + v3[1])};
         }

@@ -36,7 +36,7 @@ class _SE(nn.Module):                       # models/utils/misc.py:140-145
 
 class HeadTokenEmbedding(nn.Module):
     def __init__(self, in_channels=256, embed_dims=256, depth_num=64, depth_start=1.0, LID=True, stride=16,
-                 position_range: Sequence[float] = (-61.2, -61.2, -10.0, 61.2, 61.2, 10.0), precision="bf16", **unused):
+                 position_range: Sequence[float] = (-61.2, -61.2, -10.0, 61.2, 61.2, 10.0), precision="fp32", **unused):
         super().__init__()
         assert precision in ("bf16", "fp32") and embed_dims <= 1024 and depth_num >= 30
         self.in_channels, self.embed_dims, self.depth_num, self.stride, self.precision = in_channels, embed_dims, depth_num, stride, precision
