@@ -363,7 +363,9 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
  * toc3d_window_attention_rot: toc3d_window_attention_pf on such a buffer.  Same window lists (rows / count / count_k / npad, stride <= 416);
  *   virtual kept-pad keys (rows[j] < 0) read row slots[j] of pad_rot [window slots, ldqkv] -- the projection of LN(0) = beta rotated for every
  *   window slot, produced at pack time by toc3d_linear_qkv_rope itself (identical bits to an explicit pad row).  One workgroup per (window, head)
- *   holds the window's K and V of that head in LDS; scores transposed, P in registers, V read with ds_read_b64_tr_b16.  The prefetch buffers
+ *   holds the window's K and V of that head in LDS; scores transposed, P in registers, V read with ds_read_b64_tr_b16.  The softmax is EXP2-BASED (round 5):
+ *   pass q_scale = head_dim^-0.5 * log2(e) to toc3d_linear_qkv_rope for buffers this kernel reads (softmax(s) = exp2(s log2 e - m) / sum); one pass over the keys,
+ *   online softmax whose reference point moves only when a 32-key chunk's maximum exceeds it by more than 8 (deferred rescale): exact softmax up to rounding.  The prefetch buffers
  *   (as for toc3d_window_attention_pf; prefetch_workgroups != 0 enables them) are pulled through the caches by the attention wavefronts
  *   themselves, a few KB each by LDS-DMA while they compute -- no extra workgroups.
  */

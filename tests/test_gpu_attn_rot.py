@@ -35,7 +35,7 @@ def rope_ref(x, cos, sin):
 
 def qkv_rope(a_d, wqkv_p, bqkv, M, C, rc, tab, L, variant=0):
     out = torch.empty(M, 3 * C, dtype=TBF, device=DEV)
-    lib.call("toc3d_linear_qkv_rope", BF, variant, a_d, C, wqkv_p, C, bqkv, out, 3 * C, M, 3 * C, C, rc, tab, L, 64 ** -0.5, S())
+    lib.call("toc3d_linear_qkv_rope", BF, variant, a_d, C, wqkv_p, C, bqkv, out, 3 * C, M, 3 * C, C, rc, tab, L, lib.ATTN_ROT_Q_SCALE, S())
     return out
 
 
@@ -48,7 +48,7 @@ def test_qkv_projection_with_rope_in_the_epilogue(C, M, L):
     slots = torch.randint(0, L * L, (M,), generator=g)
     y = (A.to(TBF).double() @ W.to(TBF).double().T + b.double()).view(M, 3, heads, 64)
     cs, sn = cos[slots].double()[:, None, :], sin[slots].double()[:, None, :]
-    ref = torch.stack([rope_ref(y[:, 0], cs, sn) * 64 ** -0.5, rope_ref(y[:, 1], cs, sn), y[:, 2]], 1).reshape(M, 3 * C)
+    ref = torch.stack([rope_ref(y[:, 0], cs, sn) * lib.ATTN_ROT_Q_SCALE, rope_ref(y[:, 1], cs, sn), y[:, 2]], 1).reshape(M, 3 * C)      # (head_dim^-0.5 * log2(e): the attention's softmax is exp2-based)
     tab, _ = compact_tables(cos, sin)
     a_d, w_d = as_act(A, TBF), pack(W, BF, TBF)
     out = qkv_rope(a_d, w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L)
@@ -186,3 +186,48 @@ def test_rot_attention_is_bit_stable_and_rides_prefetch():
     for o in outs[1:]:
         assert torch.equal(o.view(torch.uint8), outs[0].view(torch.uint8))
     assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("n,np_pad", [(129, 0), (201, 0), (256, 0), (96, 160)])
+def test_rot_attention_deferred_rescale_is_the_exact_softmax(n, np_pad):
+    """The one-pass softmax of round 5 moves a query's reference point only when a 32-key chunk's maximum exceeds it by more than 8 (log2 units): the branch
+    that rescales sum and O^T is (almost) never taken after the first chunk on benign data, so it gets its own input (cdna_hip_programming.md rule 26): spikes
+    planted in LATER chunks -- one key far above everything before it, a second one above that, both only for some queries -- against an f64 softmax of the
+    same bf16 operands; plus the benign case and the analytic zero-pad keys (np_pad > 0: their score 0 is the starting reference point)."""
+    heads, nW = 2, 3
+    C = heads * 64
+    g = torch.Generator().manual_seed(n)
+    M = nW * n
+    q = torch.randn(M, heads, 64, generator=g) * 0.6
+    k = torch.randn(M, heads, 64, generator=g)
+    v = torch.randn(M, heads, 64, generator=g)
+    # window 0: key 70 spikes for queries 0..39, key n - 5 spikes higher for queries 20..59 (both in later chunks than the first)
+    for key, qs, amp in ((70, range(0, 40), 6.0), (n - 5, range(20, 60), 12.0)):
+        if key < n:
+            k[key] = 0.0
+            for qi in qs:
+                if qi < n:
+                    k[key] += q[qi] / 40.0
+            k[key] *= amp * 40.0 / 6.0
+    qkv = torch.cat([q.reshape(M, C), k.reshape(M, C), v.reshape(M, C)], 1).to(TBF).to(DEV).contiguous()
+    rows = torch.arange(M, dtype=torch.int32).view(nW, n)
+    stride = (n + 15) // 16 * 16
+    rows_p = torch.zeros(nW, stride, dtype=torch.int32)
+    rows_p[:, :n] = rows
+    count = torch.full((nW,), n, dtype=torch.int32)
+    npad = torch.full((nW,), np_pad, dtype=torch.int32) if np_pad else None
+    vb = (torch.randn(C, generator=g) * 0.3)
+    out = torch.zeros(M, C, dtype=TBF, device=DEV)
+    lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, out, C, rows_p.to(DEV), rows_p.to(DEV), count.to(DEV), None, None if npad is None else npad.to(DEV), None,
+             stride, nW, n, heads, vb.to(DEV) if np_pad else None, 0, None, None, 0, S())
+    qb, kb, vbf = (t.to(TBF).double().view(nW, n, heads, 64) for t in (q, k, v))
+    S_ = torch.einsum("wqhd,wkhd->whqk", qb, kb) * 0.6931471805599453          # the kernel exponentiates with exp2: exp2(s) = exp(s ln 2)
+    if np_pad:                                                                    # zero-pad keys: score 0, value = v_bias (attention.hip header)
+        S_ = torch.cat([S_, torch.zeros(nW, heads, n, np_pad, dtype=torch.float64)], -1)
+        vpad = vb.double().view(1, 1, heads, 64).expand(nW, np_pad, heads, 64)
+        vbf = torch.cat([vbf, vpad], 1)
+    P = torch.softmax(S_, -1)
+    ref = torch.einsum("whqk,wkhd->wqhd", P, vbf).reshape(M, C)
+    assert float(S_[0].max() - S_[0, :, :, :32].max()) > 8 * 0.69, "the planted spikes must exceed the first chunk's maximum by more than the threshold"
+    err = relerr(out.float(), ref)
+    assert err < 2e-2, err

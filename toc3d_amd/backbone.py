@@ -658,7 +658,7 @@ class _BackboneBase(nn.Module):
         C, dt = self.embed_dim, self._dt
         if self.attn_rot and stride <= 416:
             self._linear(lib.EPI_QKV_ROPE, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
-                         fused=(rope_rc, bp["rope_tab"], bp["rope_side"], 64 ** -0.5))
+                         fused=(rope_rc, bp["rope_tab"], bp["rope_side"], lib.ATTN_ROT_Q_SCALE))
             import ctypes
             nxt = P["blocks"][i + 1] if i + 1 < self.depth else None
             ts = [bp["wproj"], bp["w12"], bp["w3"]] + ([nxt["wqkv"]] if nxt is not None else [])
@@ -929,7 +929,7 @@ class ToC3DEVAViT(_BackboneBase):
                 a_rep = a_row.expand(L * L, C).contiguous()
                 bp["pad_rot"] = torch.empty(L * L, 3 * C, dtype=self._tdt, device=dev)
                 lib.call("toc3d_linear_qkv_rope", self._dt, 0, a_rep, C, bp["wqkv"], C, bp["bqkv"], bp["pad_rot"], 3 * C, L * L, 3 * C, C,
-                         rc, bp["rope_tab"], L, 64 ** -0.5, s)
+                         rc, bp["rope_tab"], L, lib.ATTN_ROT_Q_SCALE, s)
                 keep_alive += [a_rep, rc]
         torch.cuda.current_stream().synchronize()
         nfl = lib.load().toc3d_motion_weights_floats()

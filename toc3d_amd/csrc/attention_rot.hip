@@ -1,5 +1,6 @@
-// Windowed multi-head self-attention on PRE-ROTATED q / k (bf16, gfx950): the RoPE of q and k and the 1/sqrt(d) scale of q were applied
-// by the q|k|v projection's epilogue (gemm_kernels.h, EPI_QKV_ROPE), so this kernel does no arithmetic on its operands before the MFMAs.
+// Windowed multi-head self-attention on PRE-ROTATED q / k (bf16, gfx950): the RoPE of q and k and the scale of q -- head_dim^-0.5 * log2(e): the
+// softmax here is exp2-based (round 5) -- were applied by the q|k|v projection's epilogue (gemm_kernels.h, EPI_QKV_ROPE), so this kernel does no
+// arithmetic on its operands before the MFMAs.
 //
 // Reference: backbones/eva_vit.py:101-113 (dense windows), backbones/toc3d_eva_vit.py:499-512 (kept tokens + representative token,
 // RoPE rows gathered by slot index, backbones/eva_utils.py:396-403).
@@ -42,6 +43,7 @@ namespace {
 
 constexpr int HD = 64;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_THR = 8.0f;              // log2 units: the softmax reference point of a query moves only when a chunk's maximum exceeds it by more than this
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -78,21 +80,26 @@ TOC3D_DEV void prefetch_weights(const AttnRotArgs& a, char* dump, int64_t wave_i
     }
 }
 
+// max over the four lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48) WITHOUT the LDS: __shfl_xor lowers to ds_bpermute (an LDS round trip, ~100+ cycles of latency
+// each), and since round 5 this sits on every 32-key chunk's dependent chain.  v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32
+// of the second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second: with both operands = v the two results hold v[l] and
+// v[l ^ 32] (resp. v[l ^ 16]) between them in every lane.
 TOC3D_DEV float g4_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float m1 = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, m1);
+    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
 }
 
 TOC3D_DEV int v_swz(int r) { return ((r >> 1) & 3) << 1; }
 
-// One instantiation serves every window size up to 416 keys.  The softmax is exact and single-pass in effect, but the scores are computed
-// TWICE instead of being held: pass 1 = running max of S^T = K.Q^T over all keys, pass 2 = the same scores again, 32 keys at a time,
-// exp(S - max) straight into the P fragment of O^T = V^T.P^T.  The first version of this kernel kept every score of a query tile in
-// registers (94-176 VGPRs, 3-4 waves per SIMD, fully unrolled per-tile guards): its compute phase was latency-bound at 9-25 us per
-// workgroup (development timeline of that version, not kept) although the MFMA work is < 1 us -- dependent ds_read -> MFMA chains with nothing to
-// overlap them.  Recomputing costs 2 extra MFMAs per 16 keys and buys a 72-register kernel: 7 waves per SIMD, ONE query tile per
-// wavefront (the workgroup has as many waves as the window has 16-query tiles, up to 16), so the chains of 16-32 waves per CU overlap.
+// One instantiation serves every window size up to 416 keys.  Rounds 3-4 computed the scores TWICE (a first pass for the exact row maximum, a second one
+// for P = exp(S - max)) to stay at 72 registers = 7 waves per SIMD with ONE query tile per wavefront; the first version had kept every score of a query
+// tile in registers (94-176 VGPRs, 3-4 waves per SIMD) and was latency-bound at 9-25 us per workgroup.  Round 5: ONE pass -- an online softmax whose
+// reference point only moves when a chunk's maximum exceeds it by more than RESCALE_THR (see the loop) -- at the same 72 registers: a third of the
+// MFMAs and K-fragment reads and ~a quarter of the VALU instructions less per query tile (profiles/r05_attention.txt).
 constexpr int MAXPC = 8;                         // DMA pieces (8 keys x 128 B) per wave and operand: the host launches >= ceil(keys / 64) waves
 
 __global__ __launch_bounds__(1024, 7) void attn_rot_kernel(AttnRotArgs a) {      // 72 VGPRs: 7 waves per SIMD, 28 per CU
@@ -175,31 +182,18 @@ __global__ __launch_bounds__(1024, 7) void attn_rot_kernel(AttnRotArgs a) {     
     for (int u = 0; u < 2; ++u) {
         const int mt = wave + NW * u;
         if (mt >= nmt) break;
-        // ---- pass 1: max over the keys of S^T = K Q^T; lane holds S[q = r16][key = t*16 + g*4 + r] ----
-        float mx = np > 0 ? 0.f : NEG_BIG;
-#pragma unroll 4
-        for (int t = 0; t < nt16; ++t) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            Frag<bf16_t> k0, k1;
-            k0.v = *reinterpret_cast<const bf16x8*>(kf0 + t * 2048);
-            k1.v = *reinterpret_cast<const bf16x8*>(kf1 + t * 2048);
-            mma_step(acc, k0, qf[u][0]);
-            mma_step(acc, k1, qf[u][1]);
-            if (t * 16 + 16 > nkeys) {           // only the tail can reach past the key list (wave-uniform)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = t * 16 + g * 4 + r < nkeys ? acc[r] : NEG_BIG;
-            }
-            mx = fmaxf(mx, fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])));
-        }
-        mx = g4_max(mx);
-        // ---- pass 2: the same scores again, 32 keys at a time: P = exp(S - max) feeds O^T = V^T P^T from registers.  Key slot (g, j < 4) =
-        // key c*32 + g*4 + j, (g, j >= 4) = key c*32 + 16 + g*4 + (j - 4) for both operands ----
+        // ---- ONE pass over the keys, 32 at a time (round 5; rounds 3-4 computed every score twice: a first pass for the exact row maximum).  Online softmax with a
+        // DEFERRED maximum (cdna_hip_programming.md T13): the reference point m of a query only moves when a chunk's maximum exceeds it by more than RESCALE_THR
+        // (then sum and O^T are rescaled once); otherwise P = exp2(S - m) <= 2^RESCALE_THR stays far inside the f32 / bf16 range.  Softmax is invariant to m, so
+        // the result is the exact softmax up to rounding.  q arrives scaled by head_dim^-0.5 * log2(e) (the q|k|v epilogue), so exp2 needs no multiply.
+        // lane holds S[q = r16][keys of its lane group]; key slot (g, j < 4) = key c*32 + g*4 + j, (g, j >= 4) = key c*32 + 16 + g*4 + (j - 4) for both operands ----
         f32x4 o[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
         float sum = 0.f;
-#pragma unroll 2
-        for (int c = 0; c < (NK32 >> 5); ++c) {
+        float mx = np > 0 ? 0.f : NEG_BIG;       // the analytic zero-pad keys score 0
+        const int nfull = nkeys >> 5;            // chunks without a masked key
+        auto chunk = [&](const int c, const bool tail) {
             f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
             Frag<bf16_t> k00, k01, k10, k11;
             k00.v = *reinterpret_cast<const bf16x8*>(kf0 + c * 4096);
@@ -210,16 +204,25 @@ __global__ __launch_bounds__(1024, 7) void attn_rot_kernel(AttnRotArgs a) {     
             mma_step(s1, k10, qf[u][0]);
             mma_step(s0, k01, qf[u][1]);
             mma_step(s1, k11, qf[u][1]);
-            if (c * 32 + 32 > nkeys) {
+            if (tail) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     s0[r] = c * 32 + g * 4 + r < nkeys ? s0[r] : NEG_BIG;
                     s1[r] = c * 32 + 16 + g * 4 + r < nkeys ? s1[r] : NEG_BIG;
                 }
             }
+            const float cmax = g4_max(fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]))));
+            if (__builtin_amdgcn_ballot_w64(cmax > mx + RESCALE_THR) != 0ull) {          // wave-uniform: some query's maximum moved (always in the first chunk)
+                const float mnew = fmaxf(mx, cmax);                                     // per query; a query whose maximum did not move rescales by exactly 1
+                const float sc = __builtin_amdgcn_exp2f(mx - mnew);
+                sum *= sc;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o[d] *= sc;
+                mx = mnew;
+            }
             float pv[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { pv[r] = __expf(s0[r] - mx); pv[4 + r] = __expf(s1[r] - mx); }
+            for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(s0[r] - mx); pv[4 + r] = __builtin_amdgcn_exp2f(s1[r] - mx); }
             const Frag<bf16_t> pf = make_frag(pv, bf16_t());
             sum += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
 #pragma unroll
@@ -231,10 +234,12 @@ __global__ __launch_bounds__(1024, 7) void attn_rot_kernel(AttnRotArgs a) {     
                 vf.v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 mma_step(o[d], vf, pf);          // rows = head dims d*16 + .., columns = queries
             }
-        }
+        };
+        for (int c = 0; c < nfull; ++c) chunk(c, false);
+        if ((nfull << 5) < NK32) chunk(nfull, true);                                    // the one chunk that reaches past the key list
         sum = g4_sum(sum);
         float padw = 0.f;
-        if (np > 0) { padw = (float)np * __expf(-mx); sum += padw; }
+        if (np > 0) { padw = (float)np * __builtin_amdgcn_exp2f(-mx); sum += padw; }
         const float inv = 1.f / sum;
         const int qi = mt * 16 + r16;
         if (qi < n) {

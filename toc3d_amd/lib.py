@@ -18,6 +18,9 @@ ABI_VERSION = 7                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests
 F32, BF16, F32X3, F32X6, F32X3W, F32X3P, F32X3WO, F32X3WA = 0, 1, 2, 3, 4, 5, 6, 7          # F32X3: linear layers only -- f32 buffers, products as three bf16 MFMAs (include/toc3d.h)
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF = 10, 11, 12, 13
+# q scale of the pre-rotated attention path (toc3d_linear_qkv_rope -> toc3d_window_attention_rot, head_dim 64): head_dim^-0.5 (eva_vit.py:104-109) times log2(e) --
+# that kernel's softmax is exp2-based (include/toc3d.h), so the conversion factor rides on the multiply the epilogue does anyway
+ATTN_ROT_Q_SCALE = 64 ** -0.5 * 1.4426950408889634
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
 # GEMM tile variants (mod 100; + 100 / 200 / 300 select the XCD order at run time) the product library carries: every variant the autotuner may pick or a
 # shipped table names.  EXPERIMENTAL=1 builds add the rest (csrc/gemm_kernels.h launch_epi).

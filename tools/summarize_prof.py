@@ -52,15 +52,32 @@ def pmc(dirname, prefix, counter):
     return n, s / max(n, 1)
 
 
+def pmc_per_shape(dirname, prefix, counter):
+    """(kernel instantiation, grid size) -> [launches, sum]: one group per GEMM shape of the frame (a tile variant serves a few shapes, told apart by the grid)."""
+    from tools.summarize_pmc import short
+    per = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(os.path.join(out, dirname, f"{prefix}_counter_collection.csv"))):
+        if ("gemm_kernel" in r["Kernel_Name"] or "gemm_phased_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+            k = per[(short(r["Kernel_Name"]), r.get("Grid_Size", r.get("Grid_Size_X", "")))]
+            k[0] += 1
+            k[1] += float(r["Counter_Value"])
+    return per
+
+
 if not os.path.exists(os.path.join(out, "fs", "fs_counter_collection.csv")):
     sys.exit(0)                                           # kernel trace only: no PMC passes in this directory
 nf, fetch = pmc("fs", "fs", "FETCH_SIZE")
 nw, write = pmc("wsz", "wsz", "WRITE_SIZE")
+fs_shape, ws_shape = pmc_per_shape("fs", "fs", "FETCH_SIZE"), pmc_per_shape("wsz", "wsz", "WRITE_SIZE")
 js = {"kernel": "gemm_kernel<*> (all toc3d_linear launches of the step)", "launches_in_trace": nf,
       "FETCH_SIZE_KB_avg_per_launch": fetch, "WRITE_SIZE_KB_avg_per_launch": write,
       "correction": "gfx950 rocprofv3: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> read bytes = 2 x FETCH_SIZE "
                     "(MI355X_MICROARCH.md, HBM); WRITE_SIZE uncalibrated, used as is",
       "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
+      # per GEMM shape (VERDICT r04 item 1): which launches move how much -- epi5 / epi6 with N = 1024 outputs are attn.proj and mlp.w3 (f32 residual read-modify-write
+      # + the bf16 copy of the rows in their epilogues); grid = workgroups of 256 / 512 threads x tiles
+      "per_shape": [{"kernel": k[0], "grid": k[1], "launches": v[0], "read_MB": 2 * v[1] / v[0] / 1024, "write_MB": (ws_shape[k][1] / ws_shape[k][0] / 1024) if k in ws_shape else None}
+                    for k, v in sorted(fs_shape.items(), key=lambda kv: -kv[1][1])],
       "schedule": __import__("toc3d_amd.backbone", fromlist=["schedule_defaults"]).schedule_defaults("bf16"),   # the launch schedule the passes ran (bench.py quotes the file only while it matches)
       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (then WRITE_SIZE in a separate pass) -- " + cmd}
 json.dump(js, open(os.path.join(root, "profiles", f"{tag}_gemm_hbm_traffic.json"), "w"), indent=1)
