@@ -134,11 +134,7 @@ TOC3D_DEV Frag<float> frag_from_halves(const float* p0, const float* p1) {
 }
 TOC3D_DEV bf16_t frag_elem(const Frag<bf16_t>& f, int j) { return f.v[j]; }
 TOC3D_DEV float frag_elem(const Frag<float>& f, int j) { return j < 4 ? f.lo[j] : f.hi[j - 4]; }
-TOC3D_DEV float g4_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
-}
+// (g4_max: common.h)
 
 // ---- bf16 x 3 products inside the f32 kernels (TOC3D_DTYPE_F32X3 / F32X3P: the attention of precision "fp32x3") -------------------------------------
 // The exact-f32 form multiplies on v_mfma_f32_16x16x4_f32: 8 instructions (256 cycles) per 16x16x32 step, and these kernels are bound by them (the

@@ -80,18 +80,7 @@ TOC3D_DEV void prefetch_weights(const AttnRotArgs& a, char* dump, int64_t wave_i
     }
 }
 
-// max over the four lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48) WITHOUT the LDS: __shfl_xor lowers to ds_bpermute (an LDS round trip, ~100+ cycles of latency
-// each), and since round 5 this sits on every 32-key chunk's dependent chain.  v_permlane32_swap exchanges the upper 32 lanes of its first operand with the lower 32
-// of the second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second: with both operands = v the two results hold v[l] and
-// v[l ^ 32] (resp. v[l ^ 16]) between them in every lane.
-TOC3D_DEV float g4_max(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    const float m1 = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
-    const unsigned w = __builtin_bit_cast(unsigned, m1);
-    const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
-    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
-}
+// (g4_max: the maximum over the four lane groups by v_permlane16_swap / v_permlane32_swap -- common.h; it sits on every 32-key chunk's dependent chain)
 
 TOC3D_DEV int v_swz(int r) { return ((r >> 1) & 3) << 1; }
 

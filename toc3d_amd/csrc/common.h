@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -81,34 +82,70 @@ TOC3D_DEV void mma_step(f32x4& acc, const Frag<float>& a, const Frag<float>& b) 
 }
 
 // ---- wave / block reductions ----------------------------------------------------------------------
-TOC3D_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Cross-lane exchanges WITHOUT the LDS (round 5).  __shfl_xor lowers to ds_bpermute_b32 on gfx950: an LDS round trip (~100+ cycles of latency) per step, and the
+// butterflies below sit on dependent chains -- the row kernels' LayerNorm (two 6-step reductions per row), every 32-key chunk of the attention, the statistics epilogues
+// of the folded LayerNorms (32-64 exchanges per wavefront), the row table in front of the consuming GEMMs' K loops.  DPP moves (inside a 16-lane row) and the gfx950
+// v_permlane16_swap / v_permlane32_swap (across rows) are plain VALU instructions: a few cycles each.
+//   xor 1, xor 2: quad_perm;  "xor 4" / "xor 8" steps: row_half_mirror (i <-> 7 - i) / row_mirror (i <-> 15 - i) -- other pairings than xor, equally valid once the
+//   lanes below them already agree;  xor 16: v_permlane16_swap(v, v) leaves v[l] and v[l ^ 16] in its two results;  xor 32: v_permlane32_swap likewise.
+template <int CTRL> TOC3D_DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-TOC3D_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+struct LanePair { float a, b; };
+TOC3D_DEV LanePair swap16(float v) {                     // {v[l], v[l ^ 16]} in some order, the same order in both lanes of a pair's... (commutative uses only)
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return LanePair{__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1])};
 }
-// reduce across the 16 lanes that share lane>>4 (one MFMA C-row group)
-TOC3D_DEV float row16_max(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+TOC3D_DEV LanePair swap32(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return LanePair{__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1])};
 }
+// reduce across the 16 lanes that share lane>>4 (one MFMA C-row group): every lane of the row ends with the row's value
 TOC3D_DEV float row16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    v += dpp_mov<DPP_QUAD_XOR2>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
+    return v;
+}
+TOC3D_DEV float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return v;
+}
+// the 4 lane groups g = lane >> 4 that share lane & 15 (one row of a transposed MFMA C tile): (v[l] + v[l ^ 16]) + the same of l ^ 32 -- the association the
+// shuffle form had, so the statistics of the folded LayerNorms keep their bits
+TOC3D_DEV float g4_sum(float v) {
+    const LanePair p = swap16(v);
+    const LanePair q = swap32(p.a + p.b);
+    return q.a + q.b;
+}
+TOC3D_DEV float g4_max(float v) {
+    const LanePair p = swap16(v);
+    const LanePair q = swap32(fmaxf(p.a, p.b));
+    return fmaxf(q.a, q.b);
+}
+TOC3D_DEV float wave_sum(float v) { return g4_sum(row16_sum(v)); }
+TOC3D_DEV float wave_max(float v) { return g4_max(row16_max(v)); }
+// sum over the 4 lanes of a quad, f64 (the row table of the folded LayerNorms: four threads per row)
+TOC3D_DEV double quad_sum(double v) {
+    auto mov = [](double x, auto CT) {
+        constexpr int C = decltype(CT)::value;
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, C, 0xf, 0xf, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), C, 0xf, 0xf, true);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    v += mov(v, std::integral_constant<int, DPP_QUAD_XOR1>());
+    v += mov(v, std::integral_constant<int, DPP_QUAD_XOR2>());
     return v;
 }
 
-// the 4 lane groups g = lane >> 4 that share lane & 15 (one row of a transposed MFMA C tile)
-TOC3D_DEV float g4_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
 // 4 consecutive elements as one 8-byte (bf16) / 16-byte (f32) store
 TOC3D_DEV void store4(bf16_t* p, const bf16_t (&v)[4]) {
     typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));

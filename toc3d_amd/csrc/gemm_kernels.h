@@ -652,8 +652,8 @@ TOC3D_DEV void ln_rows_prepare_fn(const GemmArgs& a, const int m0, f32x2* lnrow,
                 s1 += (double)v[0];
                 s2 += (double)v[1];
             }
-            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
-            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+            s1 = quad_sum(s1);                           // (p0 + p1) + (p2 + p3) in every lane of the quad: DPP moves, no LDS round trip in front of the K loop
+            s2 = quad_sum(s2);
             const double mean = s1 * (double)a.ln_inv_n;
             double var = s2 * (double)a.ln_inv_n - mean * mean;      // biased variance (F.layer_norm)
             var = var > 0.0 ? var : 0.0;

@@ -403,9 +403,10 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
             f32x4 row[4][MAXV];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                src[u] = __shfl(my_src, (j0 + u) & 63, 64);
-                pk[u] = PENDING ? __shfl(my_pk, (j0 + u) & 63, 64) : 0;
-                wg[u] = __shfl(my_w, (j0 + u) & 63, 64);
+                // (v_readlane: the lane index is wave-uniform; __shfl would be a ds_bpermute round trip between the index load and the row loads it feeds)
+                src[u] = __builtin_amdgcn_readlane(my_src, (j0 + u) & 63);
+                pk[u] = PENDING ? __builtin_amdgcn_readlane(my_pk, (j0 + u) & 63) : 0;
+                wg[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), (j0 + u) & 63));
                 if (j0 + u >= mine) src[u] = -1;         // padded slots (src < 0) contribute x = 0; their weight is in the denominator
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(1024 / GM_SPLIT) void gather_merge_ln_split_kernel(
             f32x4 row[U][MAXV];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                src[u] = __shfl(my_src, (j0 + u) & 63, 64);
-                wg[u] = __shfl(my_w, (j0 + u) & 63, 64);
+                src[u] = __builtin_amdgcn_readlane(my_src, (j0 + u) & 63);
+                wg[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), (j0 + u) & 63));
                 if (j0 + u >= mine) { src[u] = -1; wg[u] = 0.f; }
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
