@@ -881,7 +881,7 @@ def test_ffn_ln_fold_on_the_bf16x3_path():
     lib.call("toc3d_pack_weight_lnfold", dt, W3.contiguous(), gamma, beta, b3, C, Hd, w3f, w3f.shape[0], Hp, c1, c2, S())
     cap = 6
     first = None
-    for v in (1, 8, 10, 16, 17, 19, 22, 26, 28, 49, 116, 117, 126, 149):
+    for v in (1, 8, 10, 16, 17, 19, 22, 26, 28, 29, 47, 49, 52, 116, 117, 126, 129, 149):
         stats = torch.zeros(4 + M * cap * 2, device=DEV)
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         try:
@@ -923,7 +923,7 @@ def test_norm2_fold_on_the_bf16x3_path():
     lib.call("toc3d_pack_swiglu_lnfold", dt, w1, w2, bb1, bb2, g2, b2, Hd, C, w12f, c1, c2, Hp, C, S())
     cap2, cap = C // 64, 6
     first = None
-    for v in (1, 8, 10, 16, 17, 19, 22, 26, 28, 49, 116, 117, 126, 149):
+    for v in (1, 8, 10, 16, 17, 19, 22, 26, 28, 29, 47, 49, 52, 116, 117, 126, 129, 149):
         x = x0.clone()
         a_raw = torch.full((M, C), 9.0, dtype=tdt, device=DEV)
         st2 = torch.zeros(4 + M * cap2 * 2, device=DEV)
@@ -1114,7 +1114,7 @@ def test_linear_bf16x3_products_on_f32_operands(M, N, K):
         assert torch.equal(o6, outs[lib.F32X6]), f"x6 variant {v} differs"
     res = rnd(M, N, seed=4).to(DEV)
     base = None
-    for v in (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 116, 117, 122, 126):
+    for v in (1, 8, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 52, 53, 110, 116, 117, 122, 126, 129, 145, 152):
         out = torch.empty(M, N, device=DEV)
         lib.call("toc3d_linear_ex", lib.F32X3, lib.EPI_BIAS, v, a_d, Kp, w_d, Kp, b.to(DEV), out, N, None, 0, 0, None, None, M, N, Kp, 0, S())
         assert torch.equal(out, outs[lib.F32X3]), f"variant {v} differs"

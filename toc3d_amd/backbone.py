@@ -172,7 +172,7 @@ _flush = None                   # 256 MB scratch shared by all models: evicts L2
 _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 110, 114, 116, 117, 126, 145, 147, 149, 151, 152,
                         154, 155, 156, 158, 159, 160, 161, 163),
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126),
-             lib.F32X3: (1, 8, 10, 14, 16, 17, 19, 22, 26, 28, 49, 110, 114, 116, 117, 122, 126, 149)}
+             lib.F32X3: (1, 8, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 52, 53, 110, 114, 116, 117, 122, 126, 129, 145, 147, 149, 152)}
 _VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3W] = _VARIANTS[lib.F32X3P] = _VARIANTS[lib.F32X3WO] = _VARIANTS[lib.F32X3WA] = _VARIANTS[lib.F32X3]
 
 

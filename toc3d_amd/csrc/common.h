@@ -85,15 +85,23 @@ TOC3D_DEV void mma_step(f32x4& acc, const Frag<float>& a, const Frag<float>& b) 
 // Cross-lane exchanges WITHOUT the LDS (round 5).  __shfl_xor lowers to ds_bpermute_b32 on gfx950: an LDS round trip (~100+ cycles of latency) per step, and the
 // butterflies below sit on dependent chains -- the row kernels' LayerNorm (two 6-step reductions per row), every 32-key chunk of the attention, the statistics epilogues
 // of the folded LayerNorms (32-64 exchanges per wavefront), the row table in front of the consuming GEMMs' K loops.  DPP moves (inside a 16-lane row) and the gfx950
-// v_permlane16_swap / v_permlane32_swap (across rows) are plain VALU instructions: a few cycles each.
-//   xor 1, xor 2: quad_perm;  "xor 4" / "xor 8" steps: row_half_mirror (i <-> 7 - i) / row_mirror (i <-> 15 - i) -- other pairings than xor, equally valid once the
-//   lanes below them already agree;  xor 16: v_permlane16_swap(v, v) leaves v[l] and v[l ^ 16] in its two results;  xor 32: v_permlane32_swap likewise.
-template <int CTRL> TOC3D_DEV float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+// v_permlane16_swap / v_permlane32_swap (across rows) are plain VALU instructions: a few cycles each.  Every step pairs EXACTLY the lanes the shuffle form paired
+// (l ^ 32, l ^ 16, l ^ 8, l ^ 4, l ^ 2, l ^ 1, in that order), so every sum keeps its association and its bits: the strict-parity path's near-tie top-k decisions at the
+// 1600-wide inputs (tests/test_gpu_parity_bf16.py::test_vitl_1600_fp32_matches_reference) depend on them.
+//   xor 1, xor 2: quad_perm;  xor 4: row_shl:4 into banks 0 / 2 and row_shr:4 into banks 1 / 3;  xor 8: row_ror:8;
+//   xor 16: v_permlane16_swap(v, v) leaves v[l] and v[l ^ 16] in its two results;  xor 32: v_permlane32_swap likewise.
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHR4 = 0x114, DPP_ROW_ROR8 = 0x128;
+template <int CTRL> TOC3D_DEV int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+TOC3D_DEV int lane_xor4_i(int v) {
+    int t = __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHL4, 0xf, 0x5, false);     // lanes 0-3, 8-11 of every row take lane + 4
+    return __builtin_amdgcn_update_dpp(t, v, DPP_ROW_SHR4, 0xf, 0xa, false);      // lanes 4-7, 12-15 take lane - 4
 }
-constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+TOC3D_DEV float lane_xor1(float v) { return __builtin_bit_cast(float, dpp_mov_i<DPP_QUAD_XOR1>(__builtin_bit_cast(int, v))); }
+TOC3D_DEV float lane_xor2(float v) { return __builtin_bit_cast(float, dpp_mov_i<DPP_QUAD_XOR2>(__builtin_bit_cast(int, v))); }
+TOC3D_DEV float lane_xor4(float v) { return __builtin_bit_cast(float, lane_xor4_i(__builtin_bit_cast(int, v))); }
+TOC3D_DEV float lane_xor8(float v) { return __builtin_bit_cast(float, dpp_mov_i<DPP_ROW_ROR8>(__builtin_bit_cast(int, v))); }
 struct LanePair { float a, b; };
-TOC3D_DEV LanePair swap16(float v) {                     // {v[l], v[l ^ 16]} in some order, the same order in both lanes of a pair's... (commutative uses only)
+TOC3D_DEV LanePair swap16(float v) {                     // {v[l], v[l ^ 16]} in one order or the other (for commutative uses)
     const unsigned u = __builtin_bit_cast(unsigned, v);
     const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
     return LanePair{__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1])};
@@ -105,21 +113,14 @@ TOC3D_DEV LanePair swap32(float v) {
 }
 // reduce across the 16 lanes that share lane>>4 (one MFMA C-row group): every lane of the row ends with the row's value
 TOC3D_DEV float row16_sum(float v) {
-    v += dpp_mov<DPP_QUAD_XOR1>(v);
-    v += dpp_mov<DPP_QUAD_XOR2>(v);
-    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
-    v += dpp_mov<DPP_ROW_MIRROR>(v);
+    v += lane_xor8(v); v += lane_xor4(v); v += lane_xor2(v); v += lane_xor1(v);
     return v;
 }
 TOC3D_DEV float row16_max(float v) {
-    v = fmaxf(v, dpp_mov<DPP_QUAD_XOR1>(v));
-    v = fmaxf(v, dpp_mov<DPP_QUAD_XOR2>(v));
-    v = fmaxf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
-    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    v = fmaxf(v, lane_xor8(v)); v = fmaxf(v, lane_xor4(v)); v = fmaxf(v, lane_xor2(v)); v = fmaxf(v, lane_xor1(v));
     return v;
 }
-// the 4 lane groups g = lane >> 4 that share lane & 15 (one row of a transposed MFMA C tile): (v[l] + v[l ^ 16]) + the same of l ^ 32 -- the association the
-// shuffle form had, so the statistics of the folded LayerNorms keep their bits
+// the 4 lane groups g = lane >> 4 that share lane & 15 (one row of a transposed MFMA C tile)
 TOC3D_DEV float g4_sum(float v) {
     const LanePair p = swap16(v);
     const LanePair q = swap32(p.a + p.b);
@@ -130,15 +131,23 @@ TOC3D_DEV float g4_max(float v) {
     const LanePair q = swap32(fmaxf(p.a, p.b));
     return fmaxf(q.a, q.b);
 }
-TOC3D_DEV float wave_sum(float v) { return g4_sum(row16_sum(v)); }
-TOC3D_DEV float wave_max(float v) { return g4_max(row16_max(v)); }
-// sum over the 4 lanes of a quad, f64 (the row table of the folded LayerNorms: four threads per row)
+TOC3D_DEV float wave_sum(float v) {                      // l ^ 32, l ^ 16, then the row: the shuffle form's order
+    const LanePair p = swap32(v);
+    const LanePair q = swap16(p.a + p.b);
+    return row16_sum(q.a + q.b);
+}
+TOC3D_DEV float wave_max(float v) {
+    const LanePair p = swap32(v);
+    const LanePair q = swap16(fmaxf(p.a, p.b));
+    return row16_max(fmaxf(q.a, q.b));
+}
+// sum over the 4 lanes of a quad, f64 (the row table of the folded LayerNorms: four threads per row): + l ^ 1, then + l ^ 2, like the shuffle form
 TOC3D_DEV double quad_sum(double v) {
     auto mov = [](double x, auto CT) {
         constexpr int C = decltype(CT)::value;
         const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, C, 0xf, 0xf, true);
-        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), C, 0xf, 0xf, true);
+        const unsigned lo = (unsigned)dpp_mov_i<C>((int)(unsigned)u);
+        const unsigned hi = (unsigned)dpp_mov_i<C>((int)(unsigned)(u >> 32));
         return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     };
     v += mov(v, std::integral_constant<int, DPP_QUAD_XOR1>());

@@ -1598,6 +1598,15 @@ int launch_epi_x(int variant, GemmArgs a, hipStream_t s) {
     switch (variant) {
         case 1: launch_cfg<float, EPI, 128, 128, 2, 128, 2, 2, 1, X>(a, s); break;
         case 8: launch_cfg<float, EPI, 128, 128, 1, 128, 2, 2, 1, X>(a, s); break;
+        // round 5 (fp32x3 is the constructor default now): the tiles the bf16 tables lean on, for the x3 tables' in-place tuning -- the three-product K step is
+        // longer, so tile-count quantisation weighs more
+        case 9: launch_cfg<float, EPI, 128, 64, 2, 128, 2, 2, 1, X>(a, s); break;
+        case 29: if constexpr (X == 3) launch_cfg<float, EPI, 128, 128, 4, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 33: if constexpr (X == 3) launch_cfg<float, EPI, 128, 64, 4, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 45: if constexpr (X == 3) launch_cfg<float, EPI, 128, 192, 2, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 47: if constexpr (X == 3) launch_cfg<float, EPI, 128, 192, 2, 128, 4, 2, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 52: if constexpr (X == 3) launch_cfg<float, EPI, 192, 192, 1, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 53: if constexpr (X == 3) launch_cfg<float, EPI, 192, 192, 2, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
         case 10: launch_cfg<float, EPI, 64, 128, 2, 128, 2, 2, 1, X>(a, s); break;
         case 14: launch_cfg<float, EPI, 64, 64, 2, 128, 2, 2, 1, X>(a, s); break;
         case 16: launch_cfg<float, EPI, 128, 128, 1, 128, 2, 4, 1, X>(a, s); break;
