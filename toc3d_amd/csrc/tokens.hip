@@ -694,14 +694,9 @@ __global__ __launch_bounds__(256) void ln_rebase_kernel(float* __restrict__ slow
 // plain device-to-device copy as a kernel, so that it can live inside a recorded launch plan (16-byte body, byte tail)
 __global__ __launch_bounds__(256) void copy_bytes_kernel(char* __restrict__ dst, const char* __restrict__ src, int64_t n16, int64_t nbytes) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const f32x4* __restrict__ s4 = reinterpret_cast<const f32x4*>(src);
-    f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dst);
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {              // four independent 16-byte loads in flight per lane before the first store (round 5: 5.0 -> see profiles/r05)
-        const f32x4 a = s4[i], b = s4[i + stride], c = s4[i + 2 * stride], e = s4[i + 3 * stride];
-        d4[i] = a; d4[i + stride] = b; d4[i + 2 * stride] = c; d4[i + 3 * stride] = e;
-    }
-    for (; i < n16; i += stride) d4[i] = s4[i];
+    // (round 5: four loads in flight per lane before the first store read 4.3 TB/s where this plain loop reads 5.0-5.2: the grid already keeps 8 MB in flight)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
     for (int64_t j = n16 * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nbytes; j += stride) dst[j] = src[j];
 }
 
