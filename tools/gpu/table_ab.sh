@@ -2,7 +2,7 @@
 export PYTHONUNBUFFERED=1
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-breakdown --no-batched --no-parity-path --no-other-configs --no-ab --no-calibration"
+B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-breakdown --no-batched --no-parity-path --no-other-configs --no-ab --no-calibration $BENCH_ARGS"
 for i in $(seq 1 ${N:-5}); do
   for T in base cand; do
     cp tools/gpu/${T}_table.json /tmp/t_$T.json
