@@ -1402,7 +1402,7 @@ void launch_cfg_sk(const GemmArgs& a, hipStream_t s) {
 }
 // tile variants that have a split-K form (variant mod 1000 of toc3d_linear_fused_ws; variant / 1000 = the split): BM * BN, or 0
 constexpr int64_t sk_tile_elems(int v) {
-    return (v == 16 || v == 17 || v == 28 || v == 29 || v == 1 || v == 51 || v == 22) ? 128 * 128 : (v == 55 || v == 56) ? 96 * 128 : v == 19 ? 256 * 128 : (v == 10 || v == 26) ? 64 * 128 : v == 9 ? 128 * 64 : v == 14 ? 64 * 64 : 0;
+    return (v == 16 || v == 17 || v == 28 || v == 29 || v == 1 || v == 22) ? 128 * 128 : (v == 55 || v == 56) ? 96 * 128 : v == 19 ? 256 * 128 : (v == 10 || v == 26) ? 64 * 128 : v == 9 ? 128 * 64 : v == 14 ? 64 * 64 : 0;
 }
 template <typename T, int EPI, int X3 = 0>
 int launch_epi_sk(int variant, const GemmArgs& a, hipStream_t s) {
@@ -1419,7 +1419,6 @@ int launch_epi_sk(int variant, const GemmArgs& a, hipStream_t s) {
         case 26: launch_cfg_sk<T, EPI, 64, 128, 1, 256, 2, 4, 1, X3>(a, s); break;
         case 28: launch_cfg_sk<T, EPI, 128, 128, 3, 128, 2, 4, 1, X3>(a, s); break;
         case 29: if constexpr (X3 == 0) launch_cfg_sk<T, EPI, 128, 128, 4, 128, 2, 4, 1, X3>(a, s); else return TOC3D_ERR_ARG; break;
-        case 51: if constexpr (B) launch_cfg_sk<T, EPI, 128, 128, 1, 128, 2, 4, 8, X3>(a, s); else return TOC3D_ERR_ARG; break;
         case 55: if constexpr (X3 == 0) launch_cfg_sk<T, EPI, 96, 128, 2, 128, 2, 4, 1, X3>(a, s); else return TOC3D_ERR_ARG; break;
         case 56: if constexpr (X3 == 0) launch_cfg_sk<T, EPI, 96, 128, 4, 128, 2, 4, 1, X3>(a, s); else return TOC3D_ERR_ARG; break;
         default: return TOC3D_ERR_ARG;
