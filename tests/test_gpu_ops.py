@@ -589,6 +589,39 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
         assert torch.equal(hid, ref_s), f"swiglu epilogue: variant {v} differs"
 
 
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 1024, 2752])
+def test_phased_tiles_every_ktile_count_and_bit_stable_under_load(K):
+    """The phased big tiles (variants 60-63, 160) run a two-K-tile LDS ring whose B fragments are read one phase ahead into alternating register sets
+    (gemm_kernels.h, `ktile`): 1, 2, 3, 4 K-tiles exercise the prologue / tail guards, 16 and 43 (odd) the steady state.  Bit-equal to the 128x128 single-buffer
+    variant, on every one of 60 launches with the copy kernel and another GEMM keeping the CUs' LDS and memory paths busy on a second stream."""
+    dt, tdt = lib.BF16, torch.bfloat16
+    M, N = 1111, 640
+    A, W, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23)
+    a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
+    ref = torch.zeros(M, N, dtype=tdt, device=DEV)
+    lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, 16, a_d, K, w_d, K, b.to(DEV), ref, N, None, 0, 0, None, None, M, N, K, 0, S())
+    assert relerr(ref.float(), A.to(tdt).double() @ W.to(tdt).double().T + b.double()) < 6e-3
+    big_a, big_w = as_act(rnd(4096, 1024, seed=24), tdt), pack(rnd(2048, 1024, seed=25, scale=1 / 32), dt, tdt)
+    big_o, big_b = torch.zeros(4096, 2048, dtype=tdt, device=DEV), torch.zeros(2048, device=DEV)
+    src, dst = torch.zeros(1 << 24, dtype=torch.uint8, device=DEV), torch.zeros(1 << 24, dtype=torch.uint8, device=DEV)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for v in [v for v in (60, 160, 61, 62, 63) if lib.has_variant(v)]:
+        outs = []
+        for i in range(60):
+            if i % 6 == 0:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, 17, big_a, 1024, big_w, 1024, big_b, big_o, 2048, None, 0, 0, None, None, 4096, 2048, 1024, 0, S())
+                        lib.call("toc3d_copy_bytes", src, dst, 1 << 24, S())
+            out = torch.full((M, N), 7.0, dtype=tdt, device=DEV)
+            lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, None, M, N, K, 0, S())
+            outs.append(out)
+        torch.cuda.synchronize()
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+        assert not bad, f"variant {v}, K = {K}: launches {bad[:8]} differ from the 128x128 tile"
+
+
 @pytest.mark.parametrize("name,dt,tdt", DTYPES)
 def test_linear_is_bit_stable_under_load(name, dt, tdt):
     """The GEMM keeps packed-FP32 instructions in its epilogues (csrc/Makefile); the erratum seen in the attention kernel

@@ -1188,18 +1188,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
 //
 //   the wave's block = 2 x 2 sub-blocks (a0 | a1 rows) x (b0 | b1 columns); the LDS ring holds two K-tiles, each as four
 //   half-tiles  A0 A1 B0 B1  (A_h = the a_h rows of every wave row, B_h likewise);
-//   phase 1: read B0, A0 | stage A1[t+1] | MFMA a0.b0          phase 3: read A1 | stage A0[t+2] | MFMA a1.b1
-//   phase 2: read B1     | stage B0[t+1] | MFMA a0.b1          phase 4: read B0 | stage B1[t+2], wait | MFMA a1.b0
+//   phase 1: read A0[t]    | stage A1[t+1] | MFMA a0.b0          phase 3: read A1[t]    | stage A0[t+2]       | MFMA a1.b1
+//   phase 2: read B1[t]    | stage B0[t+2] | MFMA a0.b1          phase 4: read B0[t+1]  | stage B1[t+2], wait | MFMA a1.b0
+//   (two B fragment sets that swap roles every K-tile: no half-tile is read twice, round 5; hazards at `ktile` in the kernel)
 //
 //   each phase = [LDS reads + one half-tile of global_load_lds] s_barrier [MFMAs] s_barrier, and the second half of the
 //   wavefronts (waves 4-7, which share the SIMDs of waves 0-3) runs ONE barrier behind the first: on every SIMD one wave is in its
 //   MFMA segment while its partner issues loads, so the matrix pipe and the memory path stay busy from a single workgroup.
-//
-// Hazards (both wave groups, the lagging one included):
-//   RAW  a half-tile is read one phase or more after the counted s_waitcnt vmcnt that retires it (phase 4, once per K-tile: only
-//        the two newest half-tiles may still be in flight) and a barrier every wave has passed;
-//   WAR  a slot is restaged two phases or more after its last read (A0: read ph1 -> restaged ph3; B1: ph2 -> ph4; A1: ph3 -> next
-//        ph1; B0: ph4 -> next ph2), i.e. behind a barrier that follows the readers' own lgkmcnt(0).
+//   LDS budget of a 256x256 K-tile at 128 B / clock: 8 waves x 24 KB of fragment reads + 64 KB of DMA writes = 2048 clocks = the MFMA time of the
+//   K-tile (8.4 MFLOP at 4096 FLOP / clock / CU): the LDS port is co-critical, which is what the re-read of B0 (28 KB per wave) was costing.
 // ---------------------------------------------------------------------------------------------------
 template <int ROWS, int TB, int NTHR>
 TOC3D_DEV void stage_half(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0, int h, char* lds_half, int wave, int lane) {
@@ -1286,7 +1283,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
     for (int i = 0; i < 2 * MT2; ++i)
 #pragma unroll
         for (int j = 0; j < 2 * NT2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    Frag<bf16_t> fa[MT2][2], fb[NT2][2];                  // [tile][32-wide K step]
+    Frag<bf16_t> fa[MT2][2], fb0[NT2][2], fb1[NT2][2];    // [tile][32-wide K step]; the two B sets swap roles every K-tile (see ktile)
 
     auto slot = [&](int t, int kind, int h) -> char* { return smem + (t & 1) * KT + kind * 2 * AH + h * (kind ? BH : AH); };
     auto stage_a = [&](int t, int h) { stage_half<BM / 2, TM, NTHR>(A, a.lda, m0, a_max, t * 64, h, slot(t, 0, h), wave, lane); };
@@ -1298,14 +1295,14 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_frag<128>(base, wm * HM + i * 16 + r16, ks, g, bf16_t());
     };
-    auto read_b = [&](int t, int h) {
+    auto read_b = [&](int t, int h, Frag<bf16_t> (&fb)[NT2][2]) {
         const char* base = slot(t, 1, h);
 #pragma unroll
         for (int j = 0; j < NT2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fb[j][ks] = lds_frag<128>(base, wn * HN + j * 16 + r16, ks, g, bf16_t());
     };
-    auto mfma = [&](auto HA, auto HB) {
+    auto mfma = [&](auto HA, auto HB, const Frag<bf16_t> (&fb)[NT2][2]) {
         constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1319,41 +1316,57 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // ---- prologue: K-tile 0 complete, A0 / B1 of K-tile 1 on their way (what phases 3, 4 of a tile "-1" would have staged) ----
-    stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1);
-    if (nk > 1) { stage_a(1, 0); stage_b(1, 1); wait_vmcnt<LA + LB>(); }
-    else wait_vmcnt<0>();
-    tile_barrier();
-    if (late) tile_barrier();
-
-    for (int t = 0; t < nk; ++t) {
+    // One K-tile.  fbp holds B0[t] on entry (read during phase 4 of K-tile t - 1, or by the prologue); fbq takes B1[t] in phase 2 and, once phase 3's
+    // MFMAs are done with it, B0[t + 1] in phase 4 -- so no half-tile is read twice (round 4 re-read B0 in phase 4) and the LDS reads per phase are
+    // 2 MT2 | 2 NT2 | 2 MT2 | 2 NT2 fragments instead of 2 (MT2 + NT2) | 2 NT2 | 2 MT2 | 2 NT2: the first phase no longer carries half of the K-tile's reads.
+    //   phase 1: read A0[t]      | stage A1[t+1] | MFMA a0.b0          phase 3: read A1[t]      | stage A0[t+2]       | MFMA a1.b1
+    //   phase 2: read B1[t]      | stage B0[t+2] | MFMA a0.b1          phase 4: read B0[t+1]    | stage B1[t+2], wait | MFMA a1.b0, lgkmcnt(0)
+    // RAW: the counted wait of phase 4 leaves only A0[t+2] / B1[t+2] in flight: A0, B1, A1 of K-tile t + 1 and B0[t+2] (issued in that order before them) have
+    //      landed one barrier before their first read.  B0[t+1] itself was retired by the wait of K-tile t - 1 (or the prologue's).
+    // WAR: A0 / B1 / A1 slots as before (restaged two phases or more after their read).  B0[t+1]'s slot is restaged in phase 2 of K-tile t + 1 with B0[t+3];
+    //      its read is issued in phase 4 of K-tile t and consumed two barriers later, so the explicit lgkmcnt(0) that closes phase 4's MFMA segment is what
+    //      puts the read's completion (both wave groups) in front of the barriers the restaging wave passes first.
+    auto ktile = [&](int t, Frag<bf16_t> (&fbp)[NT2][2], Frag<bf16_t> (&fbq)[NT2][2]) {
         const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
         // phase 1
-        read_b(t, 0); read_a(t, 0);
+        read_a(t, 0);
         if (n1) stage_a(t + 1, 1);
         tile_barrier();
-        mfma(I0(), I0());
+        mfma(I0(), I0(), fbp);
         tile_barrier();
         // phase 2
-        read_b(t, 1);
-        if (n1) stage_b(t + 1, 0);
+        read_b(t, 1, fbq);
+        if (n2) stage_b(t + 2, 0);
         tile_barrier();
-        mfma(I0(), I1());
+        mfma(I0(), I1(), fbq);
         tile_barrier();
         // phase 3
         read_a(t, 1);
         if (n2) stage_a(t + 2, 0);
         tile_barrier();
-        mfma(I1(), I1());
+        mfma(I1(), I1(), fbq);
         tile_barrier();
-        // phase 4: everything of K-tile t+1 that phase 1 reads must have landed (A0, B0; B1 / A1 are older): only A0 / B1 of K-tile t+2,
-        // staged in phase 3 and here, may stay in flight
-        read_b(t, 0);
+        // phase 4
+        if (n1) read_b(t + 1, 0, fbq);
         if (n2) { stage_b(t + 2, 1); wait_vmcnt<LA + LB>(); }
         else wait_vmcnt<0>();
         tile_barrier();
-        mfma(I1(), I0());
+        mfma(I1(), I0(), fbp);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         tile_barrier();
+    };
+
+    // ---- prologue: K-tile 0 and B0 of K-tile 1 complete, A0 / B1 of K-tile 1 on their way (what phases 2-4 of a tile "-1" would have staged) ----
+    stage_a(0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 1);
+    if (nk > 1) { stage_b(1, 0); stage_a(1, 0); stage_b(1, 1); wait_vmcnt<LA + LB>(); }
+    else wait_vmcnt<0>();
+    tile_barrier();
+    if (late) tile_barrier();
+    read_b(0, 0, fb0);
+
+    for (int t = 0; t < nk; t += 2) {
+        ktile(t, fb0, fb1);
+        if (t + 1 < nk) ktile(t + 1, fb1, fb0);
     }
     if (!late) tile_barrier();                            // every wave executes the same number of barriers (and is done with the ring: the statistics overlay it)
     TOC3D_TRACE(1);
