@@ -58,7 +58,7 @@ def test_qkv_projection_with_rope_in_the_epilogue(C, M, L):
     plain = torch.empty(M, 3 * C, dtype=TBF, device=DEV)
     lib.call("toc3d_linear", BF, lib.EPI_BIAS, a_d, C, w_d, C, b.to(DEV), plain, 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0, S())
     assert torch.equal(out[:, 2 * C:], plain[:, 2 * C:]), "the v columns are the plain projection"
-    for v in (1, 8, 14, 16, 17, 19, 29, 45, 49, 52, 53, 54, 55, 56, 57, 58, 60, 61, 62, 63, 116, 117, 149, 152, 154, 160, 161):
+    for v in (1, 8, 14, 16, 17, 19, 29, 45, 49, 52, 53, 54, 55, 56, 57, 58, 60, 61, 62, 63, 64, 65, 66, 116, 117, 149, 152, 154, 160, 161):
         assert torch.equal(qkv_rope(a_d, w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L, v), out), f"variant {v} differs"
 
 

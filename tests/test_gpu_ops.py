@@ -556,7 +556,7 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
     a_d, w_d = as_act(A, tdt), pack(W, dt, tdt)
     ref = None
     every = list(range(1, 11)) + list(range(13, 30)) + [32, 33, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 154, 157, 110, 116, 126, 145, 147, 149, 151, 152, 214, 216, 217, 219, 226, 249, 314, 316, 317, 319, 326, 349]
-    for v in [v for v in every + ([11, 12, 30, 31, 60, 61, 62, 63, 160, 163] if dt == lib.BF16 else []) if lib.has_variant(v)]:      # (the product library carries lib.PRODUCT_VARIANTS, EXPERIMENTAL=1 builds all)
+    for v in [v for v in every + ([11, 12, 30, 31, 60, 61, 62, 63, 64, 65, 66, 160, 163, 164] if dt == lib.BF16 else []) if lib.has_variant(v)]:      # (the product library carries lib.PRODUCT_VARIANTS, EXPERIMENTAL=1 builds all)
         out = torch.zeros(M, N, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_ex", dt, lib.EPI_BIAS, v, a_d, K, w_d, K, b.to(DEV), out, N, None, 0, 0, None, None, M, N, K, 0, S())
         if ref is None:
@@ -574,7 +574,7 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
     lib.call("toc3d_pack_swiglu", dt, rnd(Hd, K, seed=5, scale=K ** -0.5).to(DEV), rnd(Hd, K, seed=6, scale=K ** -0.5).to(DEV), rnd(Hd, seed=7).to(DEV),
              rnd(Hd, seed=8).to(DEV), Hd, K, w12, b12, Hp, K, S())
     ref_r = ref_s = None
-    for v in [v for v in every + ([60, 61, 62, 63] if dt == lib.BF16 else []) if lib.has_variant(v)]:
+    for v in [v for v in every + ([60, 61, 62, 63, 64, 65, 66] if dt == lib.BF16 else []) if lib.has_variant(v)]:
         o32 = torch.zeros(M, N, device=DEV)
         lib.call("toc3d_linear_ex", dt, lib.EPI_RESIDUAL, v, a_d, K, w_d, K, b.to(DEV), o32, N, res, N, 0, None, None, M, N, K, 0, S())
         ref_r = o32.clone() if ref_r is None else ref_r
@@ -592,7 +592,8 @@ def test_linear_variants_are_bit_identical(name, dt, tdt):
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 1024, 2752])
 def test_phased_tiles_every_ktile_count_and_bit_stable_under_load(K):
     """The phased big tiles (variants 60-63, 160) run a two-K-tile LDS ring whose B fragments are read one phase ahead into alternating register sets
-    (gemm_kernels.h, `ktile`): 1, 2, 3, 4 K-tiles exercise the prologue / tail guards, 16 and 43 (odd) the steady state.  Bit-equal to the 128x128 single-buffer
+    (gemm_kernels.h, `ktile`), the register-pipelined rings (64-66) read every K step's fragments half a K-tile ahead (gemm_tile, PIPE):
+    1, 2, 3, 4 K-tiles exercise the prologue / tail guards, 16 and 43 (odd) the steady state.  Bit-equal to the 128x128 single-buffer
     variant, on every one of 60 launches with the copy kernel and another GEMM keeping the CUs' LDS and memory paths busy on a second stream."""
     dt, tdt = lib.BF16, torch.bfloat16
     M, N = 1111, 640
@@ -606,7 +607,7 @@ def test_phased_tiles_every_ktile_count_and_bit_stable_under_load(K):
     src, dst = torch.zeros(1 << 24, dtype=torch.uint8, device=DEV), torch.zeros(1 << 24, dtype=torch.uint8, device=DEV)
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
-    for v in [v for v in (60, 160, 61, 62, 63) if lib.has_variant(v)]:
+    for v in [v for v in (60, 160, 61, 62, 63, 64, 65, 66) if lib.has_variant(v)]:
         outs = []
         for i in range(60):
             if i % 6 == 0:
@@ -849,7 +850,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
     assert relerr(c1, (gamma * W3).to(tdt).double().sum(1)) < 1e-5 and relerr(c2, (W3.double() * beta.double()).sum(1) + b3.double()) < 1e-5
     cap = 6
     ref_stats = ref_out = ref_rep = None
-    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 116, 117, 119, 126, 149, 151, 154, 160, 163, 216, 219, 249, 316, 317, 349):      # incl. every variant a shipped table names for this epilogue
+    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 64, 65, 66, 116, 117, 119, 126, 149, 151, 154, 160, 163, 216, 219, 249, 316, 317, 349):      # incl. every variant a shipped table names for this epilogue
         stats = torch.zeros(4 + M * cap * 2, device=DEV)
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS, v, a_d, K, w12, K, b12, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, K, Hd,
@@ -862,7 +863,7 @@ def test_ffn_ln_folded_across_the_gemm_boundary():
             ref_stats = st.clone()
             assert relerr(st[..., 0].sum(1), hid0.double().sum(1)) < 1e-5 and relerr(st[..., 1].sum(1), (hid0.double() ** 2).sum(1)) < 1e-5
         assert torch.equal(st, ref_stats), f"variant {v}: row statistics depend on the tile variant"
-    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 60, 61, 62, 63, 110, 114, 116, 117, 126, 145, 149, 151, 152, 156, 160, 161, 214, 217, 226, 314, 317, 326):
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 60, 61, 62, 63, 64, 65, 66, 110, 114, 116, 117, 126, 145, 149, 151, 152, 156, 160, 161, 214, 217, 226, 314, 317, 326):
         out = res.clone()
         rep = torch.zeros(nrep, C, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_RESIDUAL_LN, v, hid0, Hp, w3f, Hp, c2, out, C, out, C, 0, rep, rep_index, M, C, Hp, 0,
@@ -1020,7 +1021,7 @@ def test_norm2_folded_across_the_projection_boundary():
     lib.call("toc3d_pack_swiglu_lnfold", dt, w1, w2, bb1, bb2, g2, b2, Hd, C, w12f, c1, c2, Hp, C, S())
     cap2, cap = C // 64, 6
     ref_a = ref_st = ref_h = None
-    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 114, 116, 117, 126, 145, 156, 160, 162):
+    for v in (1, 8, 9, 10, 13, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 64, 65, 66, 114, 116, 117, 126, 145, 156, 160, 162):
         x = x0.clone()
         a_raw = torch.full((M, C), 9.0, dtype=tdt, device=DEV)
         st2 = torch.zeros(4 + M * cap2 * 2, device=DEV)
@@ -1035,7 +1036,7 @@ def test_norm2_folded_across_the_projection_boundary():
             ref_a, ref_st = a_raw.clone(), s2.clone()
             assert relerr(s2[..., 0].sum(1), a_raw.double().sum(1)) < 1e-5 and relerr(s2[..., 1].sum(1), (a_raw.double() ** 2).sum(1)) < 1e-5
         assert torch.equal(s2, ref_st), f"variant {v}: row statistics depend on the tile variant"
-    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 116, 117, 126, 149, 154, 160, 163):
+    for v in (1, 8, 10, 15, 16, 17, 19, 22, 24, 26, 28, 29, 49, 51, 54, 55, 56, 57, 58, 60, 61, 62, 63, 64, 65, 66, 116, 117, 126, 149, 154, 160, 163):
         hid = torch.full((M, Hp), 9.0, dtype=tdt, device=DEV)
         st = torch.zeros(4 + M * cap * 2, device=DEV)
         lib.call("toc3d_linear_fused", dt, lib.EPI_SWIGLU_STATS_LN, v, ref_a, C, w12f, C, c2, hid, Hp, None, 0, 0, None, None, M, 2 * Hp, C, Hd,

@@ -787,7 +787,9 @@ TOC3D_DEV bool sk_exchange(const GemmArgs& a, f32x4 (&acc)[MT][NT], char* smem, 
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int X3 = 0, int OCC = 1, int SK = 0>
 TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* smem, const int sk_tile = 0, const int sk_slice = 0) {
     static_assert(SK == 0 || (EPI != TOC3D_EPI_CONV3X3 && !epi_is_rope(EPI) && !epi_ln_self(EPI) && X3 != 32), "split-K serves the plain linear epilogues on the 16x16x32 K loop");
-    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4) || (X3 == 32 && sizeof(T) == 2), "the bf16 x 3 / x 6 product forms run on f32 operands, the 32x32x16 MFMA form on bf16");
+    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4) || ((X3 == 32 || X3 == 1) && sizeof(T) == 2),
+                  "the bf16 x 3 / x 6 product forms run on f32 operands, the 32x32x16 MFMA form and the register-pipelined loop on bf16");
+    constexpr bool PIPE = X3 == 1;                      // fragments of the NEXT 32-deep K step are read while the MFMAs of the current one run (see the loop)
     constexpr bool MF32 = X3 == 32;                     // v_mfma_f32_32x32x16_bf16 in the K loop (see lds_frag32); accumulators handed to the epilogue as 16x16 tiles
     constexpr int SW = MF32 ? 1 : 0;
     constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
@@ -1068,7 +1070,72 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
             rope_rcs[i] = a.rope_rc[row < a.M ? row : a.M - 1];
         }
     }
-    if (STAGES == 1) {
+    if constexpr (PIPE) {
+        // Register-pipelined ring (round 5) for the launches that run ONE workgroup per CU (N = 1024 at M < 6000: 176-392 tiles).  The loop below this one reads a K step's
+        // fragments and then multiplies them, every wave in step between two barriers: with no second workgroup on the CU the matrix pipe idles through every LDS round trip
+        // (deep rings at one workgroup per CU ran at half the rate of single buffers at four).  Here a wave holds TWO fragment sets: the reads of K step
+        // (kt, 1) are issued in front of the MFMAs of (kt, 0), those of (kt + 1, 0) in front of the MFMAs of (kt, 1) -- the barrier that publishes tile kt + 1 therefore sits in
+        // the MIDDLE of K-tile kt, half a tile earlier than in the plain ring (one tile less may stay in flight: STAGES >= 3, meant for 4).
+        //   RAW: tile kt + 1 is read behind the counted wait + barrier of K-tile kt.
+        //   WAR: behind that barrier the slot of tile kt - 1 is refilled; its last fragments (kt - 1, 1) were consumed by MFMAs every wave issued before arriving.
+        static_assert(STAGES >= 3 && KS == 2 && !LNSELF && EPI != TOC3D_EPI_CONV3X3, "register-pipelined loop: rings of >= 3 K-tiles of 64 bf16, linear epilogues");
+        Frag<T> fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        auto read_set = [&](int t, auto S, Frag<T> (&fa)[MT], Frag<T> (&fb)[NT]) {
+            constexpr int sidx = decltype(S)::value;
+            const char* sA = smem + (t % STAGES) * STAGE_BYTES;
+            const char* sB = sA + A_BYTES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, sidx, g, T());
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, sidx, g, T());
+        };
+        auto mfma_set = [&](auto FIRST, const Frag<T> (&fa)[MT], const Frag<T> (&fb)[NT]) {      // FIRST = 1: MFMA (0, 0) only; 0: the others; 2: all
+            constexpr int first = decltype(FIRST)::value;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (first == 2 || (first == 1) == (i == 0 && j == 0)) mma_step(acc[i][j], fb[j], fa[i]);   // swapped: C^T tile layout, see the epilogue
+        };
+        using F0 = std::integral_constant<int, 0>;
+        using F1 = std::integral_constant<int, 1>;
+        using F2 = std::integral_constant<int, 2>;
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t)
+            if (t < nk) request(t);
+        if constexpr (epi_ln_stats_in(EPI) && !PREP_EARLY) ln_rows_prepare();
+        if (nk - 1 >= STAGES - 2) wait_vmcnt<(STAGES - 2) * LOADS>();                  // tile 0 landed; tiles 1 .. STAGES - 2 may stay in flight
+        else wait_vmcnt<0>();
+        tile_barrier();
+        read_set(0, S0(), fa0, fb0);
+        for (int kt = 0; kt < nk; ++kt) {
+            // fa0 / fb0 were requested in the previous iteration: hipcc's wait in front of their first use is lgkmcnt(0) (it does not order LDS reads across the loop's back
+            // edge), so that first MFMA goes IN FRONT of this iteration's reads -- behind them the wait would cover the new reads too and expose them
+            mfma_set(F1(), fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(kt, S1(), fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_set(F0(), fa0, fb0);
+            if (kt + 1 < nk) {
+                if (nk - 2 - kt >= STAGES - 3) wait_vmcnt<(STAGES - 3) * LOADS>();      // tile kt + 1 landed; tiles kt + 2 .. kt + STAGES - 2 may stay in flight
+                else wait_vmcnt<0>();                                                   // pipeline tail
+            }
+            tile_barrier();
+            if (kt + STAGES - 1 < nk) request(kt + STAGES - 1);                         // into the slot of tile kt - 1
+            if constexpr (epi_is_rope(EPI)) { if (kt == nk - 1) rope_stage(smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES); }
+            // (the same order again: across the branches above hipcc's wait for fa1 / fb1 is lgkmcnt(0) too.  The read is unconditional -- the last iteration reads a stale
+            // slot, unused -- because behind a branch the reads would sit in a block of their own and the scheduler fences below would not hold them)
+            mfma_set(F1(), fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(kt + 1, S0(), fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_set(F0(), fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (epi_is_rope(EPI)) { wait_vmcnt<0>(); tile_barrier(); }
+    } else if (STAGES == 1) {
         // single LDS buffer, two barriers per K-tile; latency is hidden by co-resident workgroups (small LDS footprint)
         for (int kt = 0; kt < nk; ++kt) {
             request(kt);
@@ -1592,6 +1659,15 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
         case 62: if (sizeof(T) == 2) launch_phased<EPI, 128, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
         case 63: if (sizeof(T) == 2) launch_phased<EPI, 128, 128, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x32 per wave, 64 KiB: two per CU
+        // register-pipelined rings (bf16 only; gemm_tile, PIPE): the next K step's fragments are read while the current one's MFMAs run -- for one workgroup per CU
+#define TOC3D_PIPE(BM_, BN_, ST_, WM_, WN_)                                                                                                              \
+        if constexpr (sizeof(T) == 2 && !epi_ln_self(EPI) && EPI != TOC3D_EPI_CONV3X3) launch_cfg<bf16_t, EPI, BM_, BN_, ST_, 128, WM_, WN_, 1, 1>(a, s); \
+        else return TOC3D_ERR_ARG;                                                                                                                       \
+        break
+        case 64: TOC3D_PIPE(128, 128, 4, 2, 4);              // variant 29's tile and ring: 8 waves, 64x32 per wave, 128 KiB
+        case 65: TOC3D_PIPE(128, 128, 3, 2, 4);              // variant 28's: 96 KiB
+        case 66: TOC3D_PIPE(128, 128, 4, 2, 2);              // 4 waves, 64x64 per wave, 128 KiB
+#undef TOC3D_PIPE
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;

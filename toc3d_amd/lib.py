@@ -24,7 +24,7 @@ ATTN_ROT_Q_SCALE = 64 ** -0.5 * 1.4426950408889634
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
 # GEMM tile variants (mod 100; + 100 / 200 / 300 select the XCD order at run time) the product library carries: every variant the autotuner may pick or a
 # shipped table names.  EXPERIMENTAL=1 builds add the rest (csrc/gemm_kernels.h launch_epi).
-PRODUCT_VARIANTS = (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63)
+PRODUCT_VARIANTS = (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66)
 
 
 def has_variant(v: int) -> bool:

@@ -59,6 +59,8 @@ def measure():
 
 
 CANDS = (16, 116, 51, 151, 17, 117, 45, 145, 49, 149, 52, 152, 19, 114, 126, 14, 26, 28, 29, 9, 10, 54, 154, 55, 155, 56, 156, 57, 58, 158)
+if os.environ.get("TOC3D_TUNE_CANDS"):                  # e.g. TOC3D_TUNE_CANDS=64,164: a pass over a few new variants only
+    CANDS = tuple(int(v) for v in os.environ["TOC3D_TUNE_CANDS"].split(","))
 for _ in range(3):
     step()
 torch.cuda.synchronize()
