@@ -121,7 +121,8 @@ int toc3d_linear(int dtype, int epilogue, const void* A, int64_t lda, const void
  * 38/39 = 128x128 on 8 wavefronts with 32-wide K tiles 2-/3-deep, 40-42 = 128x256 / 256x128 single buffer and K32 rings;
  * 43-48 = 128x192 and 128x96 tiles (43/44 single buffer, 45/46 double buffer, 47 = 128x192 with 32x96 per wavefront so that
  * it serves SWIGLU, 48 = 3-deep); 49/50 = 192x128 double / single buffer; 51 = variant 16 compiled for 64 registers (four workgroups per CU); 52/53 = 192x192 single / double buffer;
- * 60-63 = phased 256x256 / 256x128 / 128x256 / 128x128 tiles (bf16, one or two workgroups per CU, four phases per K-tile).  A variant whose per-wavefront column slab is not a
+ * 60-63 = phased 256x256 / 256x128 / 128x256 / 128x128 tiles (bf16, one or two workgroups per CU, four phases per K-tile); 64-66 = register-pipelined 128x128 rings (bf16; 4- and 3-deep with
+ * 8 wavefronts, 4-deep with 4: the next K step's fragments are read while the current one multiplies -- for launches that run one workgroup per CU).  A variant whose per-wavefront column slab is not a
  * multiple of 32 cannot serve EPI_SWIGLU (error TOC3D_ERR_UNSUPPORTED).  variant + 100 = the same tile with the per-XCD band
  * order (each XCD keeps its A row band in L2 and walks the W panels once); variant + 200 / + 300 = a 2-D partition of the tiles over the XCDs (4 row bands x 2 column
  * halves / 2 row bands x 4 column quarters: an XCD streams half / a quarter of W instead of all of it -- the wide-N and long-K GEMMs are bound by the L2-miss traffic
