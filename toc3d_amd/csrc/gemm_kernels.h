@@ -268,6 +268,20 @@ TOC3D_DEV void epi_store4(float* p, const float (&v)[4]) {
     store4(p, v);
 #endif
 }
+#elif defined(TOC3D_NT_STORES)
+// experiment (round 5, profiles/r05_nt_stores.txt): non-temporal epilogue stores (1: act-dtype outputs, 2: f32 outputs too)
+TOC3D_DEV void epi_store4(bf16_t* p, const bf16_t (&v)[4]) {
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    const bf16x4_t x = bf16x4_t{v[0], v[1], v[2], v[3]};
+    __builtin_nontemporal_store(__builtin_bit_cast(unsigned long long, x), reinterpret_cast<unsigned long long*>(p));
+}
+TOC3D_DEV void epi_store4(float* p, const float (&v)[4]) {
+#if TOC3D_NT_STORES >= 2
+    __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(p));
+#else
+    store4(p, v);
+#endif
+}
 #else
 TOC3D_DEV void epi_store4(bf16_t* p, const bf16_t (&v)[4]) { store4(p, v); }
 TOC3D_DEV void epi_store4(float* p, const float (&v)[4]) { store4(p, v); }
@@ -295,7 +309,11 @@ TOC3D_DEV void store_pair_wide(bf16_t* dst_a, bf16_t* dst_b, Pack4 pa, Pack4 pb,
     const auto ry = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
     // even group: row tile i, columns start at its own; odd group: row tile i + 1, columns start 4 to the left (the left neighbour's)
     bf16_t* dst = (g & 1) ? dst_b - 4 : dst_a;
+#ifdef TOC3D_NT_STORES
+    if ((g & 1) ? ok_b : ok_a) __builtin_nontemporal_store(u32x4{rx[0], ry[0], rx[1], ry[1]}, reinterpret_cast<u32x4*>(dst));
+#else
     if ((g & 1) ? ok_b : ok_a) *reinterpret_cast<u32x4*>(dst) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+#endif
 }
 TOC3D_DEV void store_pair_wide(float*, float*, Pack4, Pack4, bool, bool, int) {}
 
