@@ -184,6 +184,20 @@ TOC3D_DEV void store4_planes(void* f32_addr, const float (&v)[4]) {      // 4 co
 
 // bijective XCD-aware remap of a 1-D grid (cdna_hip_programming.md T1): blocks that land on one XCD
 // (bid % 8) get a contiguous chunk of work ids so neighbouring tiles share that XCD's L2.
+// the same for the blocks [off, off + n) of a grid (other blocks of the launch do something else): block bid runs on XCD bid % 8; returns its work id in [0, n)
+TOC3D_DEV int xcd_remap_off(int bid, int off, int n) {
+    if (n < 8) return bid - off;
+    const int xcd = bid & 7;
+    int base = 0, j0x = 0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const int j0 = ((y - off) % 8 + 8) % 8;          // first block of [0, n) (as j = bid - off) on XCD y
+        const int cnt = n > j0 ? (n - j0 + 7) / 8 : 0;
+        if (y < xcd) base += cnt;
+        if (y == xcd) j0x = j0;
+    }
+    return base + (bid - off - j0x) / 8;
+}
 TOC3D_DEV int xcd_remap(int bid, int nwg) {
     const int nx = 8;
     if (nwg < nx) return bid;

@@ -10,6 +10,16 @@
 #include "capi.h"
 #include "common.h"
 
+// Row blocks -> XCDs (round 5).  Workgroup b of a launch runs on XCD b % 8; the GEMMs give every XCD a contiguous band of row tiles (xcd_remap / order 1), and what a producer
+// leaves in its XCD's L2 is worth 7-8 % of the frame (profiles/r05_nt_stores.txt).  With plain `row = 4 b + wave` a row kernel's rows are dealt round robin over the XCDs: its
+// reads of a GEMM's output and its writes of the next GEMM's A operand all cross XCDs.  Bits of TOC3D_ROW_BANDS put a kernel's row blocks in the same bands instead
+// (0: LayerNorm rows / rebase, 1: gather's kept rows, 2: scatter): +0.4 % / -0.1 % / +0.3 % frames/s, 1 | 4 shipped (profiles/r05_row_bands.txt).  Speed only.
+#ifndef TOC3D_ROW_BANDS
+#define TOC3D_ROW_BANDS 5
+#endif
+#define TOC3D_ROW_BLOCK_IF(bit, b, n) ((TOC3D_ROW_BANDS >> (bit)) & 1 ? xcd_remap((int)(b), (int)(n)) : (int)(b))
+#define TOC3D_ROW_BLOCK_OFF_IF(bit, b, off, n) ((TOC3D_ROW_BANDS >> (bit)) & 1 ? xcd_remap_off((int)(b), (int)(off), (int)(n)) : (int)(b) - (int)(off))
+
 namespace {
 
 constexpr float PAD_SCORE = -1.0e6f;        // toc3d_eva_vit.py:415
@@ -69,7 +79,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
                                                       const float* __restrict__ beta, float eps, T* __restrict__ out, int64_t ldo,
                                                       int M, int C) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
+    const int row = TOC3D_ROW_BLOCK_IF(0, blockIdx.x, gridDim.x) * 4 + wave;
     if (row >= M) return;
     const int src = row_index ? row_index[row] : row;
     const float sc = (row_scale && src >= 0) ? row_scale[src] : 1.f;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(1024) void gather_merge_ln_kernel(const float* __re
         wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
         return;
     }
-    const int64_t orow = (int64_t)(blockIdx.x - rep_blocks) * 16 + wave;
+    const int64_t orow = (int64_t)TOC3D_ROW_BLOCK_OFF_IF(1, blockIdx.x, rep_blocks, gridDim.x - rep_blocks) * 16 + wave;
     if (orow >= Ms) return;
     const int src = crow_tok[orow];
     if (src == -2) return;                               // representative row: written by its window's block above
@@ -586,7 +596,7 @@ __global__ __launch_bounds__(1024 / GM_SPLIT) void gather_merge_ln_split_kernel(
         wave_ln_write<T, MAXV>(v, nvec, lane, mean, rstd, gamma, beta, a_out + orow * lda);
         return;
     }
-    const int64_t orow = (int64_t)(blockIdx.x - rep_blocks) * WPB + wave;
+    const int64_t orow = (int64_t)TOC3D_ROW_BLOCK_OFF_IF(1, blockIdx.x, rep_blocks, gridDim.x - rep_blocks) * WPB + wave;
     if (orow >= Ms) return;
     const int src = crow_tok[orow];
     if (src == -2) return;                               // representative row: written by its window's last slice above
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(256) void scatter_update_kernel(float* __restrict__
                                                              const float* __restrict__ r2, const float* __restrict__ r3,
                                                              const float* __restrict__ r4) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t id = (int64_t)TOC3D_ROW_BLOCK_IF(2, blockIdx.x, gridDim.x) * 4 + wave;
     if (id >= (int64_t)nW * N) return;
     const int win = (int)(id / N), p = (int)(id % N);
     const int dst = tok[id];
@@ -660,7 +670,7 @@ __global__ __launch_bounds__(256) void ln_rebase_kernel(float* __restrict__ slow
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         T* __restrict__ out, int64_t ldo, int M) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
+    const int row = TOC3D_ROW_BLOCK_IF(0, blockIdx.x, gridDim.x) * 4 + wave;
     if (row >= M) return;
     const int nvec = C >> 2;
     const int win = rep_index[row];                      // wave-uniform
