@@ -152,7 +152,7 @@ template <int RB, int SW = 0> TOC3D_DEV int swz(int r) {
 }
 
 // stage one R-row x RB-byte operand tile with 16-byte global_load_lds: R*RB/16 chunks over 256 threads.
-template <typename T, int R, int RB, int NTHR, int SW = 0>
+template <typename T, int R, int RB, int NTHR, int SW = 0, int AUX = 0>
 TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max_row, int k0, char* lds_tile, int wave, int lane) {
     constexpr int CPR = RB / 16;                        // chunks per row
     // Tiles whose chunk count is not a multiple of the workgroup size (96- / 160-row tiles on 512 threads): the wavefronts past the end of the last round
@@ -169,7 +169,7 @@ TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max
         int gr = row0 + r;
         gr = gr < max_row ? gr : max_row;
         const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB, SW>(r)) << 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + base * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + base * 16), 16, 0, AUX);
     }
 }
 
@@ -916,7 +916,10 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         } else {
             stage_tile<T, BM, RB, NTHR, SW>(A, a.lda, m0, a.M - 1, k_base + t * BK, slot, wave, lane);
         }
-        stage_tile<T, BN, RB, NTHR, SW>(W, a.ldw, n0, w_max, k_base + t * BK, slot + A_BYTES, wave, lane);
+#ifndef TOC3D_W_AUX
+#define TOC3D_W_AUX 0                                   // experiment (round 5, profiles/r05_nt_stores.txt): cache policy bits of the W operand's DMA loads (2 = nt: stream past the L2's LRU)
+#endif
+        stage_tile<T, BN, RB, NTHR, SW, TOC3D_W_AUX>(W, a.ldw, n0, w_max, k_base + t * BK, slot + A_BYTES, wave, lane);
     };
     auto multiply = [&](int t) {
         const char* sA = smem + (t % STAGES) * STAGE_BYTES;
