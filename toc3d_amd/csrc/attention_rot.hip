@@ -39,6 +39,13 @@ extern "C" int toc3d_attn_trace_set(void* p) { return (int)hipMemcpyToSymbol(HIP
 #define ATTN_TRACE(slot) do {} while (0)
 #endif
 
+// Cache policy of the K / V DMA loads: 2 = nt.  Every K / V byte of the q|k|v buffer is read by exactly one workgroup, once; streamed past the L2s' LRU it leaves the
+// prefetched weights and the GEMM operands alone: +0.3-0.4 % frames/s, eight alternations on two boxes, all in favour (profiles/r05_nt_stores.txt; the same hint on the row
+// kernels' read-once rows LOSES 2 %, on the GEMM's W operand 19.5 %).  Bit-identical.
+#ifndef TOC3D_ATTN_KV_AUX
+#define TOC3D_ATTN_KV_AUX 2
+#endif
+
 namespace {
 
 constexpr int HD = 64;
@@ -147,8 +154,8 @@ __global__ __launch_bounds__(1024, 7) void attn_rot_kernel(AttnRotArgs a) {     
             const bf16_t* src = krow[i] >= 0 ? a.qkv + (int64_t)krow[i] * a.ldqkv : a.pad_rot + (int64_t)(-1 - krow[i]) * a.ldqkv;
             const char* kb = reinterpret_cast<const char*>(src + a.C + head * HD);
             const char* vb = reinterpret_cast<const char*>(src + 2 * a.C + head * HD);
-            __builtin_amdgcn_global_load_lds((gptr_t)(kb + ((p ^ (r & 7)) << 4)), (lptr_t)(Ks + piece * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(vb + ((p ^ v_swz(r)) << 4)), (lptr_t)(Vs + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kb + ((p ^ (r & 7)) << 4)), (lptr_t)(Ks + piece * 1024), 16, 0, TOC3D_ATTN_KV_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + ((p ^ v_swz(r)) << 4)), (lptr_t)(Vs + piece * 1024), 16, 0, TOC3D_ATTN_KV_AUX);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
