@@ -265,7 +265,7 @@ def test_launch_schedule_switches_are_attributes_not_environment():
     d16, d32, dx3 = schedule_defaults("bf16"), schedule_defaults("fp32"), schedule_defaults("fp32x3")
     assert d16["fold_norm2"] and d16["carry_compact"] and d16["attn_rot"] and d16["prefetch_weights"] > 0
     assert not (d32["fold_ffn_ln"] or d32["fold_norm2"] or d32["carry_compact"] or d32["attn_rot"]), "the strict-parity path keeps the reference's sequence"
-    assert dx3["fold_ffn_ln"] and dx3["fold_norm2"] and dx3["carry_compact"] and not dx3["attn_rot"], "fp32x3: the folds and the carried compact set on f32 buffers"
+    assert dx3["fold_ffn_ln"] and dx3["fold_norm2"] and dx3["carry_compact"] and dx3["attn_rot"], "fp32x3: the folds, the carried compact set and (round 6) the pre-rotated attention on (hi, lo) planes"
     assert dx3["x3_planes"] and dx3["x3_attention"] and not (d16["x3_planes"] or d32["x3_planes"] or d16["x3_attention"] or d32["x3_attention"]), "(hi, lo) planes are the fp32x3 path's operand layout only"
     m = toc3d_amd.build_backbone(dict(configs.get("toc3d_tiny"), schedule=dict(fold_norm2=False, side_lanes=False)))
     assert m.fold_norm2 is False and m.side_lanes is False and m.fold_ffn_ln is True

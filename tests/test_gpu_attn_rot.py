@@ -11,6 +11,38 @@ from test_gpu_ops import DEV, S, as_act, pack, relerr, rnd
 
 pytestmark = pytest.mark.gpu
 BF, TBF = lib.BF16, torch.bfloat16
+F32T = torch.float32
+# the two precisions of the pre-rotated path: bf16 buffers, or (round 6) f32-sized buffers holding (hi, lo) bf16 planes with bf16 x 3 products (precision "fp32x3")
+PRECS = ["bf16", "x3"]
+
+
+def planes_decode(t):
+    """A (hi, lo) planes buffer (f32-typed tensor [rows, ld], ld % 32 == 0; include/toc3d.h TOC3D_DTYPE_F32X3P) -> the f32 values hi + lo."""
+    rows, ld = t.shape
+    b = t.contiguous().view(torch.bfloat16).view(rows, ld // 32, 2, 32).float()
+    return (b[:, :, 0] + b[:, :, 1]).reshape(rows, ld)
+
+
+def planes_encode(x):
+    """f32 device tensor [rows, ld] -> planes, through the library's own converter."""
+    x = x.contiguous().clone()
+    lib.call("toc3d_x3_planes", x, x.shape[1], x, x.shape[1], x.shape[0], x.shape[1], S())
+    return x
+
+
+def pack_p(w, prec):
+    return pack(w, BF, TBF) if prec == "bf16" else planes_encode(pack(w, lib.F32, F32T))
+
+
+def act_p(x, prec, planes=True):
+    if prec == "bf16":
+        return as_act(x, TBF)
+    a = as_act(x, F32T)
+    return planes_encode(a) if planes else a
+
+
+def values(t, prec):
+    return t.float() if prec == "bf16" else planes_decode(t)
 
 
 def compact_tables(cos, sin):
@@ -33,10 +65,38 @@ def rope_ref(x, cos, sin):
     return x * cos + x2 * sin
 
 
-def qkv_rope(a_d, wqkv_p, bqkv, M, C, rc, tab, L, variant=0):
-    out = torch.empty(M, 3 * C, dtype=TBF, device=DEV)
-    lib.call("toc3d_linear_qkv_rope", BF, variant, a_d, C, wqkv_p, C, bqkv, out, 3 * C, M, 3 * C, C, rc, tab, L, lib.ATTN_ROT_Q_SCALE, S())
+def qkv_rope(a_d, wqkv_p, bqkv, M, C, rc, tab, L, variant=0, prec="bf16", a_planes=True):
+    out = torch.empty(M, 3 * C, dtype=TBF if prec == "bf16" else F32T, device=DEV)
+    dt = BF if prec == "bf16" else (lib.F32X3P if a_planes else lib.F32X3WO)
+    lib.call("toc3d_linear_qkv_rope", dt, variant, a_d, C, wqkv_p, C, bqkv, out, 3 * C, M, 3 * C, C, rc, tab, L, lib.ATTN_ROT_Q_SCALE, S())
     return out
+
+
+def attn_rot(prec, qkv, C, out, rows, slots, count, count_k, npad, pad_rot, stride, nW, max_count, heads, v_bias):
+    lib.call("toc3d_window_attention_rot", BF if prec == "bf16" else lib.F32X3P, qkv, 3 * C, out, C, rows, slots, count, count_k, npad, pad_rot, stride, nW, max_count, heads,
+             v_bias, 0, None, None, 0, S())
+
+
+def test_qkv_projection_with_rope_in_the_epilogue_on_planes():
+    """bf16 x 3 form of the rotating epilogue: A (planes or plain f32) . W (planes), RoPE + q scale on the f32 accumulators, rows written as (hi, lo) planes.  Against f64
+    on the f32 operands: product error <= ~2^-16, the planes carry 16 mantissa bits."""
+    C, M, L = 1024, 777, 20
+    heads = C // 64
+    cos, sin = synth.rope_tables(L)
+    A, W, b = rnd(M, C, seed=1), rnd(3 * C, C, seed=2, scale=C ** -0.5), rnd(3 * C, seed=3)
+    g = torch.Generator().manual_seed(4)
+    slots = torch.randint(0, L * L, (M,), generator=g)
+    y = (A.double() @ W.double().T + b.double()).view(M, 3, heads, 64)
+    cs, sn = cos[slots].double()[:, None, :], sin[slots].double()[:, None, :]
+    ref = torch.stack([rope_ref(y[:, 0], cs, sn) * lib.ATTN_ROT_Q_SCALE, rope_ref(y[:, 1], cs, sn), y[:, 2]], 1).reshape(M, 3 * C)
+    tab, _ = compact_tables(cos, sin)
+    w_d = pack_p(W, "x3")
+    out = qkv_rope(act_p(A, "x3"), w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L, prec="x3")
+    assert relerr(planes_decode(out), ref) < 5e-5
+    out_plain_a = qkv_rope(act_p(A, "x3", planes=False), w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L, prec="x3", a_planes=False)
+    assert torch.equal(out_plain_a.view(torch.int32), out.view(torch.int32)), "A split in the kernel or delivered as planes: the same bits"
+    for v in (1, 8, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 52, 53, 60, 61, 62, 63, 116, 117, 149, 152, 160, 161):
+        assert torch.equal(qkv_rope(act_p(A, "x3"), w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L, v, prec="x3").view(torch.int32), out.view(torch.int32)), f"variant {v} differs"
 
 
 @pytest.mark.parametrize("C,M,L", [(128, 333, 16), (1024, 777, 20)])
@@ -62,14 +122,18 @@ def test_qkv_projection_with_rope_in_the_epilogue(C, M, L):
         assert torch.equal(qkv_rope(a_d, w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L, v), out), f"variant {v} differs"
 
 
-def _proj_weights(sd, pre, C):
+def _proj_weights(sd, pre, C, prec="bf16"):
     wqkv = torch.cat([sd[pre + "q_proj.weight"], sd[pre + "k_proj.weight"], sd[pre + "v_proj.weight"]])
     bqkv = torch.cat([sd[pre + "q_bias"], torch.zeros(C), sd[pre + "v_bias"]])
-    return pack(wqkv, BF, TBF), bqkv.to(DEV)
+    return pack_p(wqkv, prec), bqkv.to(DEV)
 
 
+TOL = {"bf16": 3e-2, "x3": 1e-4}               # against the oracle's f32 attention: bf16 operands round at 2^-9; the x3 products at ~2^-16
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("L", [16, 20])
-def test_rot_attention_dense_windows_with_analytic_pads(L):
+def test_rot_attention_dense_windows_with_analytic_pads(L, prec):
     """Block.forward attention part (eva_vit.py:249-262) on the pre-rotated path: 256 / 400-key windows, ragged edge windows."""
     cfg = configs.get("toc3d_tiny")
     sd = synth.make_state_dict(cfg)
@@ -84,25 +148,25 @@ def test_rot_attention_dense_windows_with_analytic_pads(L):
     ref = O.attention(yw.reshape(nB, L * L, C), sd2, pre, heads, cos, sin)
     ref = O.window_unpartition(ref.reshape(nB, L, L, C), L, pad_hw, (h, w)).reshape(-1, C)
     M = V * h * w
-    wq, bq = _proj_weights(sd, pre, C)
+    wq, bq = _proj_weights(sd, pre, C, prec)
     tab, _ = compact_tables(cos, sin)
     r = torch.arange(h).view(1, h, 1).expand(V, h, w)
     c = torch.arange(w).view(1, 1, w).expand(V, h, w)
     rc = (((r % L) << 16) | (c % L)).reshape(-1).to(torch.int32).to(DEV)
-    qkv = qkv_rope(as_act(y.reshape(M, C), TBF), wq, bq, M, C, rc, tab, L)
+    qkv = qkv_rope(act_p(y.reshape(M, C), prec), wq, bq, M, C, rc, tab, L, prec=prec)
     nW, N = nB, L * L
     rows = torch.empty(nW, N, dtype=torch.int32, device=DEV)
     slots, count, npad = torch.empty_like(rows), torch.empty(nW, dtype=torch.int32, device=DEV), torch.empty(nW, dtype=torch.int32, device=DEV)
     lib.call("toc3d_window_map_dense", V, h, w, L, rows, slots, count, npad, S())
-    out = torch.zeros(M, C, dtype=TBF, device=DEV)
-    lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, out, C, rows, slots, count, None, npad, None, N, nW, int(count.max()), heads,
-             sd[pre + "v_bias"].to(DEV), 0, None, None, 0, S())
-    err = relerr(out.float(), ref)
-    assert err < 3e-2, err
+    out = torch.zeros(M, C, dtype=qkv.dtype, device=DEV)
+    attn_rot(prec, qkv, C, out, rows, slots, count, None, npad, None, N, nW, int(count.max()), heads, sd[pre + "v_bias"].to(DEV))
+    err = relerr(values(out, prec), ref)
+    assert err < TOL[prec], err
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("n", [33, 77, 103, 129, 161, 201, 256, 300, 401])
-def test_rot_attention_selected_slots(n):
+def test_rot_attention_selected_slots(n, prec):
     """ToC3DEVAAttention (toc3d_eva_vit.py:484-518): compact rows, RoPE rows gathered by slot index -- every instantiation of the kernel."""
     cfg = configs.get("toc3d_tiny")
     sd = synth.make_state_dict(cfg)
@@ -116,22 +180,23 @@ def test_rot_attention_selected_slots(n):
     sd2[pre + "proj.weight"], sd2[pre + "proj.bias"] = torch.eye(C), torch.zeros(C)
     ref = O.attention(y, sd2, pre, heads, cosT[slots], sinT[slots]).reshape(-1, C)
     M = nW * n
-    wq, bq = _proj_weights(sd, pre, C)
+    wq, bq = _proj_weights(sd, pre, C, prec)
     tab, L = compact_tables(cosT, sinT)
-    qkv = qkv_rope(as_act(y.reshape(M, C), TBF), wq, bq, M, C, rc_of(slots.reshape(-1), L), tab, L)
+    qkv = qkv_rope(act_p(y.reshape(M, C), prec), wq, bq, M, C, rc_of(slots.reshape(-1), L), tab, L, prec=prec)
     # scattered compact rows: the kernel must go through the index list
     perm = torch.randperm(M, generator=g)
     qkv_s = torch.empty_like(qkv)
     qkv_s[perm.to(DEV)] = qkv
     rows = perm.to(torch.int32).reshape(nW, n).to(DEV)
     count = torch.full((nW,), n, dtype=torch.int32, device=DEV)
-    out = torch.zeros(M, C, dtype=TBF, device=DEV)
-    lib.call("toc3d_window_attention_rot", BF, qkv_s, 3 * C, out, C, rows, None, count, None, None, None, n, nW, n, heads, None, 0, None, None, 0, S())
-    err = relerr(out[perm.to(DEV)].float(), ref)
-    assert err < 3e-2, err
+    out = torch.zeros(M, C, dtype=qkv.dtype, device=DEV)
+    attn_rot(prec, qkv_s, C, out, rows, None, count, None, None, None, n, nW, n, heads, None)
+    err = relerr(values(out[perm.to(DEV)], prec), ref)
+    assert err < TOL[prec], err
 
 
-def test_rot_attention_virtual_pad_keys_equal_explicit_pad_rows():
+@pytest.mark.parametrize("prec", PRECS)
+def test_rot_attention_virtual_pad_keys_equal_explicit_pad_rows(prec):
     """toc3d_eva_vit.py:414,421,372: kept padded slots are LN(0) = beta rows.  As virtual keys (rows = -1, k taken from pad_rot[slot]) they must give
     the real rows exactly the output they get when the pads are explicit rows; ragged query counts per window."""
     cfg = configs.get("toc3d_tiny")
@@ -144,20 +209,20 @@ def test_rot_attention_virtual_pad_keys_equal_explicit_pad_rows():
     n = n_real + n_pad
     gsl = torch.Generator().manual_seed(23)
     slots = torch.stack([torch.randperm(256, generator=gsl)[:n] for _ in range(nW)]).int()
-    wq, bq = _proj_weights(sd, pre, C)
+    wq, bq = _proj_weights(sd, pre, C, prec)
     M = nW * n
-    qkv = qkv_rope(as_act(y.reshape(M, C), TBF), wq, bq, M, C, rc_of(slots.reshape(-1).long(), L), tab, L)
+    qkv = qkv_rope(act_p(y.reshape(M, C), prec), wq, bq, M, C, rc_of(slots.reshape(-1).long(), L), tab, L, prec=prec)
     rows = torch.arange(M, dtype=torch.int32).reshape(nW, n).to(DEV)
     cnt = torch.full((nW,), n, dtype=torch.int32, device=DEV)
-    full = torch.zeros(M, C, dtype=TBF, device=DEV)
-    lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, full, C, rows, slots.to(DEV), cnt, None, None, None, n, nW, n, heads, None, 0, None, None, 0, S())
-    # the pad row rotated for every window slot, by the same epilogue (what ToC3DEVAViT._pack builds)
-    pad_rot = qkv_rope(as_act(beta_row.expand(256, C).contiguous(), TBF), wq, bq, 256, C, rc_of(torch.arange(256), L), tab, L)
+    full = torch.zeros(M, C, dtype=qkv.dtype, device=DEV)
+    attn_rot(prec, qkv, C, full, rows, slots.to(DEV), cnt, None, None, None, n, nW, n, heads, None)
+    # the pad row rotated for every window slot, by the same epilogue (what ToC3DEVAViT._pack builds: on the x3 path from the PLAIN f32 LayerNorm row)
+    pad_rot = qkv_rope(act_p(beta_row.expand(256, C).contiguous(), prec, planes=False), wq, bq, 256, C, rc_of(torch.arange(256), L), tab, L, prec=prec, a_planes=False)
     rows_v = rows.clone()
     rows_v[:, n_real:] = -1
     cq = torch.full((nW,), n_real, dtype=torch.int32, device=DEV)
-    virt = torch.zeros(M, C, dtype=TBF, device=DEV)
-    lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, virt, C, rows_v, slots.to(DEV), cq, cnt, None, pad_rot, n, nW, n_real, heads, None, 0, None, None, 0, S())
+    virt = torch.zeros(M, C, dtype=qkv.dtype, device=DEV)
+    attn_rot(prec, qkv, C, virt, rows_v, slots.to(DEV), cq, cnt, None, pad_rot, n, nW, n_real, heads, None)
     fr = full.view(nW, n, C)[:, :n_real].float()
     vr = virt.view(nW, n, C)[:, :n_real].float()
     assert torch.equal(fr, vr)
@@ -188,8 +253,9 @@ def test_rot_attention_is_bit_stable_and_rides_prefetch():
     assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0
 
 
-@pytest.mark.parametrize("n,np_pad", [(129, 0), (201, 0), (256, 0), (96, 160)])
-def test_rot_attention_deferred_rescale_is_the_exact_softmax(n, np_pad):
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("n,np_pad", [(129, 0), (201, 0), (256, 0), (96, 160), (400, 0)])
+def test_rot_attention_deferred_rescale_is_the_exact_softmax(n, np_pad, prec):
     """The one-pass softmax of round 5 moves a query's reference point only when a 32-key chunk's maximum exceeds it by more than 8 (log2 units): the branch
     that rescales sum and O^T is (almost) never taken after the first chunk on benign data, so it gets its own input (cdna_hip_programming.md rule 26): spikes
     planted in LATER chunks -- one key far above everything before it, a second one above that, both only for some queries -- against an f64 softmax of the
@@ -209,7 +275,11 @@ def test_rot_attention_deferred_rescale_is_the_exact_softmax(n, np_pad):
                 if qi < n:
                     k[key] += q[qi] / 40.0
             k[key] *= amp * 40.0 / 6.0
+    if prec == "x3":
+        q, k, v = (t.to(TBF).float() for t in (q, k, v))      # the same bf16-representable operands: hi = the value, lo = 0
     qkv = torch.cat([q.reshape(M, C), k.reshape(M, C), v.reshape(M, C)], 1).to(TBF).to(DEV).contiguous()
+    if prec == "x3":
+        qkv = planes_encode(qkv.float())
     rows = torch.arange(M, dtype=torch.int32).view(nW, n)
     stride = (n + 15) // 16 * 16
     rows_p = torch.zeros(nW, stride, dtype=torch.int32)
@@ -217,9 +287,9 @@ def test_rot_attention_deferred_rescale_is_the_exact_softmax(n, np_pad):
     count = torch.full((nW,), n, dtype=torch.int32)
     npad = torch.full((nW,), np_pad, dtype=torch.int32) if np_pad else None
     vb = (torch.randn(C, generator=g) * 0.3)
-    out = torch.zeros(M, C, dtype=TBF, device=DEV)
-    lib.call("toc3d_window_attention_rot", BF, qkv, 3 * C, out, C, rows_p.to(DEV), rows_p.to(DEV), count.to(DEV), None, None if npad is None else npad.to(DEV), None,
-             stride, nW, n, heads, vb.to(DEV) if np_pad else None, 0, None, None, 0, S())
+    out = torch.zeros(M, C, dtype=qkv.dtype, device=DEV)
+    attn_rot(prec, qkv, C, out, rows_p.to(DEV), rows_p.to(DEV), count.to(DEV), None, None if npad is None else npad.to(DEV), None, stride, nW, n, heads,
+             vb.to(DEV) if np_pad else None)
     qb, kb, vbf = (t.to(TBF).double().view(nW, n, heads, 64) for t in (q, k, v))
     S_ = torch.einsum("wqhd,wkhd->whqk", qb, kb) * 0.6931471805599453          # the kernel exponentiates with exp2: exp2(s) = exp(s ln 2)
     if np_pad:                                                                    # zero-pad keys: score 0, value = v_bias (attention.hip header)
@@ -229,5 +299,5 @@ def test_rot_attention_deferred_rescale_is_the_exact_softmax(n, np_pad):
     P = torch.softmax(S_, -1)
     ref = torch.einsum("whqk,wkhd->wqhd", P, vbf).reshape(M, C)
     assert float(S_[0].max() - S_[0, :, :, :32].max()) > 8 * 0.69, "the planted spikes must exceed the first chunk's maximum by more than the threshold"
-    err = relerr(out.float(), ref)
-    assert err < 2e-2, err
+    err = relerr(values(out, prec), ref)
+    assert err < (2e-2 if prec == "bf16" else 1e-4), err

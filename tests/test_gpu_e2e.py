@@ -633,7 +633,7 @@ def test_fp32x3_on_planes_is_bit_identical_to_the_in_kernel_split(name, prev):
     inp = synth.make_inputs(cfg, views_per_frame=2 if name == "toc3d_tiny" else 6)
     outs = []
     for planes in (False, True):
-        m = toc3d_amd.build_backbone(dict(cfg, precision="fp32x3", schedule=dict(x3_planes=planes, x3_attention=False)))   # (the attention's own x3 products: next test)
+        m = toc3d_amd.build_backbone(dict(cfg, precision="fp32x3", schedule=dict(x3_planes=planes, x3_attention=False, attn_rot=False)))   # (the attention's own x3 products and its pre-rotated form on planes: next test)
         m.load_state_dict(sd, strict=True)
         m = m.to(DEV).eval()
         assert m.x3_planes is planes
@@ -650,11 +650,15 @@ def test_fp32x3_attention_products_stay_parity_grade():
     sd = synth.make_state_dict(cfg)
     inp = synth.make_inputs(cfg, views_per_frame=6)
     outs = []
-    for x3a in (False, True):
-        m = toc3d_amd.build_backbone(dict(cfg, precision="fp32x3", schedule=dict(x3_attention=x3a)))
+    for x3a, rot in ((False, False), (True, False), (True, True)):
+        m = toc3d_amd.build_backbone(dict(cfg, precision="fp32x3", schedule=dict(x3_attention=x3a, attn_rot=rot)))
         m.load_state_dict(sd, strict=True)
         m = m.to(DEV).eval()
         outs.append(run_toc3d(m, inp, True).img_feats["last_feat"].clone())
     e = rel_max(outs[1], outs[0].cpu())
     print(f"[fp32x3] attention with bf16 x 3 products vs exact-f32 attention: rel max diff {e:.3e}")
+    assert e < 2e-4
+    # round 6, the shipped schedule: RoPE + q scale in the x3 q|k|v epilogue, rows as (hi, lo) planes, toc3d_window_attention_rot on planes (exp2-based online softmax)
+    e = rel_max(outs[2], outs[0].cpu())
+    print(f"[fp32x3] pre-rotated attention on planes vs exact-f32 attention: rel max diff {e:.3e}")
     assert e < 2e-4

@@ -173,7 +173,10 @@ _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28,
                         154, 155, 156, 158, 159, 160, 161, 163),
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126),
              lib.F32X3: (1, 8, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 52, 53, 110, 114, 116, 117, 122, 126, 129, 145, 147, 149, 152)}
-_VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3W] = _VARIANTS[lib.F32X3P] = _VARIANTS[lib.F32X3WO] = _VARIANTS[lib.F32X3WA] = _VARIANTS[lib.F32X3]
+# the phased big tiles on planes (round 6) need BOTH operands in planes: candidates of TOC3D_DTYPE_F32X3P only
+_VARIANTS_X3P = _VARIANTS[lib.F32X3] + (60, 61, 62, 63, 160, 161, 162, 163)
+_VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3W] = _VARIANTS[lib.F32X3WO] = _VARIANTS[lib.F32X3WA] = _VARIANTS[lib.F32X3]
+_VARIANTS[lib.F32X3P] = _VARIANTS_X3P
 
 
 def schedule_defaults(precision):
@@ -192,7 +195,8 @@ def schedule_defaults(precision):
         fold_norm2=fast,             # norm2 folded across the attention-projection -> w1|w2 boundary the same way
         gathered_residual=True,      # the gather skips the f32 copy of the kept rows; the projection GEMM reads their residual from x through crow_tok
         prefetch_weights=192 if bf16 else 0,   # workgroups of each attention launch that pull the next GEMMs' weights towards the chip (0 = off)
-        attn_rot=bf16,               # RoPE + q scale in the q|k|v GEMM epilogue, attention on the pre-rotated buffer with K / V staged by DMA
+        attn_rot=fast,               # RoPE + q scale in the q|k|v GEMM epilogue, attention on the pre-rotated buffer with K / V staged by DMA (fp32x3, round 6: on (hi, lo)
+                                     # planes -- needs x3_planes; both contractions as bf16 x 3 products, f32 softmax statistics and accumulation)
         gather_split=False,          # True / 2 / 8 / 16: every window's merge_tokens cut over 4 / 2 / 8 / 16 workgroups (toc3d_gather_merge_ln_split, same bits as the
                                      # single-workgroup form).  Round 4, built on the theory that one CU's load path bounds the merge -- measured: the launch is a chain
                                      # of dependent round trips, not bandwidth (12-17 us either way, profiles/r04_gather_split.txt), +-0.5 % in the frame: off
@@ -220,6 +224,8 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
         rope = fused
         if var is None:
             var = self._tuned.get((lib.EPI_BIAS, M, N, K), 0)
+        if dtg in (lib.F32X3WA, lib.F32X3W):                # (the rotated rows always leave as planes on the x3 path: toc3d_window_attention_rot stages them by DMA)
+            dtg = lib.F32X3P if dtg == lib.F32X3WA else lib.F32X3WO
         lib.call("toc3d_linear_qkv_rope", dtg, var, A, lda, W, ldw, bias, out, ldo, M, N, K, *rope, s)
         return
     if var is None:
@@ -656,9 +662,13 @@ class _BackboneBase(nn.Module):
         """q|k|v projection + windowed attention of block i on plan["a"] [M, C] -> plan["att"] (eva_vit.py:97-113, toc3d_eva_vit.py:495-512)."""
         bp = P["blocks"][i]
         C, dt = self.embed_dim, self._dt
-        if self.attn_rot and stride <= 416:
+        if self._rot_ok(stride):
             self._linear(lib.EPI_QKV_ROPE, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0,
-                         fused=(rope_rc, bp["rope_tab"], bp["rope_side"], lib.ATTN_ROT_Q_SCALE))
+                         fused=(rope_rc, bp["rope_tab"], bp["rope_side"], lib.ATTN_ROT_Q_SCALE), a_planes=self._x3p, o_planes=self._x3p)
+            if self._x3p:       # planes in, planes out; no weight prefetch riding on this form
+                lib.call("toc3d_window_attention_rot", lib.F32X3P, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad, stride, nwin, max_count,
+                         self.num_heads, v_bias, 0, None, None, 0, lib.stream_ptr())
+                return
             import ctypes
             nxt = P["blocks"][i + 1] if i + 1 < self.depth else None
             ts = [bp["wproj"], bp["w12"], bp["w3"]] + ([nxt["wqkv"]] if nxt is not None else [])
@@ -672,6 +682,15 @@ class _BackboneBase(nn.Module):
         self._linear(lib.EPI_BIAS, plan["a"], C, bp["wqkv"], C, bp["bqkv"], plan["qkv"], 3 * C, None, 0, 0, None, None, M, 3 * C, C, 0, a_planes=self._x3p)
         self._attention(P, i, self._dt_attn, plan["qkv"], 3 * C, plan["att"], C, arows, aslots, count_q, count_k, npad, pad,
                         stride, nwin, max_count, self.num_heads, bp["cos"], bp["sin"], bp["rope_side"], v_bias, 64 ** -0.5)
+
+    def _rot_ok(self, stride):
+        """The pre-rotated attention path serves this window size: bf16 up to 416 keys (K and V of a head whole in LDS); fp32x3 on planes any size of the model
+        (windows over 288 keys in super-tiles) -- needs the GEMM operands in planes (x3_planes)."""
+        if not self.attn_rot:
+            return False
+        if self.precision == "bf16":
+            return stride <= 416
+        return self._x3p and stride <= 1024
 
     def _proj(self, bp, plan, rows, out, rep_out, rep_index, res=None, res_index=None):
         """attn.proj + residual add (eva_vit.py:115,262 / toc3d_eva_vit.py:514,379) into ``out`` f32 [rows, C]: in place by default, or with the
@@ -920,7 +939,7 @@ class ToC3DEVAViT(_BackboneBase):
             lib.call("toc3d_layernorm_rows", self._dt, bp["ln1_w"], C, minus1, None, bp["ln1_w"], bp["ln1_b"], self.LN_EPS, a_row, C, 1, C, s)
             lib.call("toc3d_linear", self._dt_gemm, lib.EPI_BIAS, a_row, C, bp["wqkv"], C, bp["bqkv"], bp["pad_qkv"], 3 * C, None, 0, 0, None, None,
                      1, 3 * C, C, 0, s)
-            if self.attn_rot:
+            if self.attn_rot and (self.precision == "bf16" or self._x3p):
                 # ... and, for the pre-rotated attention, that row rotated for EVERY window slot by the same GEMM epilogue that rotates real rows
                 # (bit-identical to an explicit pad row at that slot): pad_rot [L*L, 3C], row = window slot
                 L = bp["rope_side"]
@@ -928,8 +947,8 @@ class ToC3DEVAViT(_BackboneBase):
                 rc = (((sl // L) << 16) | (sl % L)).to(torch.int32).contiguous()
                 a_rep = a_row.expand(L * L, C).contiguous()
                 bp["pad_rot"] = torch.empty(L * L, 3 * C, dtype=self._tdt, device=dev)
-                lib.call("toc3d_linear_qkv_rope", self._dt, 0, a_rep, C, bp["wqkv"], C, bp["bqkv"], bp["pad_rot"], 3 * C, L * L, 3 * C, C,
-                         rc, bp["rope_tab"], L, lib.ATTN_ROT_Q_SCALE, s)
+                lib.call("toc3d_linear_qkv_rope", lib.F32X3WO if self._x3p else self._dt, 0, a_rep, C, bp["wqkv"], C, bp["bqkv"], bp["pad_rot"], 3 * C, L * L, 3 * C, C,
+                         rc, bp["rope_tab"], L, lib.ATTN_ROT_Q_SCALE, s)      # (fp32x3: A = the plain f32 LayerNorm row, W in planes, the rotated rows as planes)
                 keep_alive += [a_rep, rc]
         torch.cuda.current_stream().synchronize()
         nfl = lib.load().toc3d_motion_weights_floats()
@@ -1174,7 +1193,7 @@ class ToC3DEVAViT(_BackboneBase):
         else:
             lib.call("toc3d_gather_merge_ln_ex", self._dt_rows, plan["x"], C, sel["tok"], sel["wgt"], sel["crow_tok"], sel["rep_row"], nW, N, k, rows,
                      bp["ln1_w"], bp["ln1_b"], self.LN_EPS, slow, plan["a"], C, 0 if self.gathered_residual else 1, s)
-        rot = self.attn_rot and k + 1 <= 416
+        rot = self._rot_ok(k + 1)
         self._qkv_attention(P, i, plan, rows, sel["crow_rc"], sel["arows"], sel["aslots"], sel["acount_q"], sel["acount_k"], None,
                             bp["pad_rot"] if rot else bp["pad_qkv"], k + 1, nW, sel["max_q"], None)
         ra, rb = (plan["rep3"], plan["rep4"]) if carry_in else (plan["rep1"], plan["rep2"])

@@ -165,7 +165,6 @@ __global__ __launch_bounds__(1024, 7) void attn_rot_kernel(AttnRotArgs a) {     
         prefetch_weights(a, Vs + NK32 * 128, ((int64_t)win * gridDim.x + head) * NW + wave, (int64_t)gridDim.y * gridDim.x * NW, lane);
 
     const int np = a.npad ? a.npad[win] : 0;
-    const int nt16 = NK32 >> 4;
     // K fragment of 16-key tile t, 32-dim half s2: row t*16 + r16, chunk s2*4 + g (permuted by row & 7 = r16 & 7)
     const char* kf0 = Ks + r16 * 128 + ((g ^ (r16 & 7)) << 4);
     const char* kf1 = Ks + r16 * 128 + (((4 + g) ^ (r16 & 7)) << 4);
@@ -289,6 +288,272 @@ void launch_rot(const AttnRotArgs& a, int64_t max_count, int64_t num_heads, int6
     toc3d_launch(attn_rot_kernel, dim3((unsigned)num_heads, (unsigned)nwin), dim3(256 * quads), lds, s, b);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The same attention on (hi, lo) bf16 PLANES (round 6; precision "fp32x3", TOC3D_DTYPE_F32X3P): the q|k|v buffer was written by the x3 projection's
+// rotating epilogue as planes (common.h: element c of a row in the 128-byte group c / 32, hi at byte 2 (c % 32), lo at 64 + 2 (c % 32)), i.e. a head's
+// 64 dims are 256 bytes = 16 chunks [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63].  Both contractions are bf16 x 3 products like the GEMMs of that precision
+// (a . b = lo.hi + hi.lo + hi.hi, small terms first), softmax statistics and accumulation in f32, P split in registers once per 32 keys.
+//   K image [key][256 B], chunk c of key r at position c ^ (r & 15): the ds_read_b128 lane groups (16 rows x one chunk) hit 16 distinct 16-byte slots;
+//   V image [key][256 B], chunk c of key r at position c ^ ((r & 7) << 1): the 8 keys of a ds_read_b64_tr_b16 lane group (2 x 16 lanes, 32 bytes per key) hit
+//   8 distinct 32-byte slots of the 256-byte bank row.
+// A key costs 512 bytes of LDS, so windows of more than `tile_keys` keys are walked in SUPER-TILES of tile_keys keys (MULTI): stage, barrier, every
+// query tile of the wave over the staged keys (the online softmax state of both tiles stays in registers), barrier, next -- the 400-key global windows of
+// the dense blocks in 128-key tiles at two workgroups per CU.  Windows that fit are staged whole behind one dependent index read, like the bf16 kernel.
+struct AttnRotX3Args {
+    const float* qkv; int64_t ldqkv;             // planes; leading dimension in f32 elements
+    float* out; int64_t ldo;                     // planes (the projection GEMM's A operand)
+    const int32_t* rows; const int32_t* slots; const int32_t* count; const int32_t* count_k; const int32_t* npad;
+    const float* pad_rot;
+    int64_t stride;
+    int C;
+    const float* v_bias;
+    int tile_keys;                               // keys per super-tile (multiple of 32)
+};
+
+constexpr int X3_MAXPC = 8;                      // DMA pieces (4 keys x 256 B) per wave, operand and super-tile: the host launches >= ceil(tile_keys / 32) waves
+
+TOC3D_DEV void x3_mma16(f32x4& acc, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {      // small terms first, like the GEMM
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(1024, 4) void attn_rot_x3_kernel(AttnRotX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NW = blockDim.x >> 6;
+    const int head = blockIdx.x, win = (int)blockIdx.y;
+    const int n = a.count[win];
+    if (n == 0) return;
+    const int nkeys = a.count_k ? a.count_k[win] : n;
+    const int NK32 = ((nkeys + 31) >> 5) << 5;
+    const int TK = MULTI ? a.tile_keys : NK32;   // keys staged at a time
+    char* Ks = smem;                             // [TK][256 B]
+    char* Vs = smem + (MULTI ? a.tile_keys : NK32) * 256;
+    const int32_t* rows = a.rows + (int64_t)win * a.stride;
+    const int32_t* slots = a.slots + (int64_t)win * a.stride;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nmt = (n + 15) >> 4;
+    // query tiles of this wave: two at most in the whole-window kernel (mt = wave, wave + NW); ONE in the super-tile kernel, whose grid carries a third dimension over
+    // groups of NW query tiles instead (every group stages the window's keys again, L2-hot: the online-softmax state of two tiles beside the staging registers does
+    // not fit the 128 registers of a 16-wave workgroup)
+    constexpr int NU = MULTI ? 1 : 2;
+    constexpr int NPC = MULTI ? 2 : X3_MAXPC;    // DMA pieces per wave, operand and staging round (MULTI: 16 waves x 2 pieces x 4 keys = the 128-key super-tile)
+    const int mt0 = MULTI ? (int)blockIdx.z * NW + wave : wave;
+    if (MULTI && (int)blockIdx.z * NW >= nmt) return;            // (workgroup-uniform)
+
+    // index round trip of the first (only) super-tile + the query rows
+    int krow[NPC];
+    auto key_rows = [&](const int k0, const int tk) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int piece = i * NW + wave;     // wave-uniform; one piece = 4 keys x 16 chunks = 1 KB per operand
+            krow[i] = 0;
+            if (piece * 4 < tk) {
+                int key = k0 + piece * 4 + (lane >> 4);
+                key = key < nkeys ? key : 0;     // rows past the list alias key 0: finite values, their scores are masked
+                int row = rows[key];
+                if (a.pad_rot) { const int sl = slots[key]; row = row >= 0 ? row : -1 - sl; }
+                krow[i] = row;
+            }
+        }
+    };
+    auto stage = [&](const int tk) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int piece = i * NW + wave;
+            if (piece * 4 < tk) {
+                const int r = piece * 4 + (lane >> 4), p = lane & 15;
+                const float* src = krow[i] >= 0 ? a.qkv + (int64_t)krow[i] * a.ldqkv : a.pad_rot + (int64_t)(-1 - krow[i]) * a.ldqkv;
+                const char* kb = reinterpret_cast<const char*>(src + a.C + head * HD);
+                const char* vb = reinterpret_cast<const char*>(src + 2 * a.C + head * HD);
+                __builtin_amdgcn_global_load_lds((gptr_t)(kb + ((p ^ (r & 15)) << 4)), (lptr_t)(Ks + piece * 1024), 16, 0, TOC3D_ATTN_KV_AUX);
+                __builtin_amdgcn_global_load_lds((gptr_t)(vb + ((p ^ ((r & 7) << 1)) << 4)), (lptr_t)(Vs + piece * 1024), 16, 0, TOC3D_ATTN_KV_AUX);
+            }
+        }
+    };
+    const int tk0 = NK32 < TK ? NK32 : TK;
+    key_rows(0, tk0);
+    int qrow[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int qi = (mt0 + NW * u) * 16 + r16;
+        qrow[u] = rows[qi < n ? qi : 0];         // the first `count` entries are real rows
+    }
+    // Q fragments (hi, lo) of the wave's query tiles, in flight together with the K / V DMA
+    bf16x8 qh[NU][2], ql[NU][2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            qh[u][s2] = bf16x8{}; ql[u][s2] = bf16x8{};
+            if (mt0 + NW * u < nmt) {
+                const char* qb = reinterpret_cast<const char*>(a.qkv + (int64_t)qrow[u] * a.ldqkv + head * HD) + s2 * 128 + g * 16;
+                qh[u][s2] = *reinterpret_cast<const bf16x8*>(qb);
+                ql[u][s2] = *reinterpret_cast<const bf16x8*>(qb + 64);
+            }
+        }
+    stage(tk0);
+
+    const int np = a.npad ? a.npad[win] : 0;
+    // K fragment of the 16-key tile at key row kr (multiple of 16), 32-dim half s2: row kr + r16, hi chunk s2*8 + g, lo chunk s2*8 + 4 + g, permuted by r16
+    const char* kf = Ks + r16 * 256;
+    int kofs[2][2];                              // [s2][hi | lo] byte offset inside the row
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) { kofs[s2][0] = ((s2 * 8 + g) ^ r16) << 4; kofs[s2][1] = ((s2 * 8 + 4 + g) ^ r16) << 4; }
+    // V^T fragment: this lane addresses 4 dims of key row g*4 + (r16 >> 2) (+ 16 for the second half) of each 32-key chunk
+    const int vr = g * 4 + (r16 >> 2);
+    const char* vbase = Vs + vr * 256 + (r16 & 1) * 8;
+    const int vsw = (vr & 7) << 1, vch = (r16 & 3) >> 1;
+
+    f32x4 o[NU][4];
+    float sum[NU], mx[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[u][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sum[u] = 0.f;
+        mx[u] = np > 0 ? 0.f : NEG_BIG;          // the analytic zero-pad keys score 0
+    }
+    // one 32-key chunk of the staged keys for query tile U: local chunk c (LDS rows c*32 ..), global key offset kg = k0 + c*32
+    auto chunk = [&](auto U, const int c, const int kg, const bool tail) {
+        constexpr int u = decltype(U)::value;
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 k0h = *reinterpret_cast<const bf16x8*>(kf + c * 8192 + kofs[s2][0]);
+            const bf16x8 k0l = *reinterpret_cast<const bf16x8*>(kf + c * 8192 + kofs[s2][1]);
+            const bf16x8 k1h = *reinterpret_cast<const bf16x8*>(kf + c * 8192 + 4096 + kofs[s2][0]);
+            const bf16x8 k1l = *reinterpret_cast<const bf16x8*>(kf + c * 8192 + 4096 + kofs[s2][1]);
+            x3_mma16(s0, k0h, k0l, qh[u][s2], ql[u][s2]);
+            x3_mma16(s1, k1h, k1l, qh[u][s2], ql[u][s2]);
+        }
+        if (tail) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = kg + g * 4 + r < nkeys ? s0[r] : NEG_BIG;
+                s1[r] = kg + 16 + g * 4 + r < nkeys ? s1[r] : NEG_BIG;
+            }
+        }
+        const float cmax = g4_max(fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]))));
+        if (__builtin_amdgcn_ballot_w64(cmax > mx[u] + RESCALE_THR) != 0ull) {
+            const float mnew = fmaxf(mx[u], cmax);
+            const float sc = __builtin_amdgcn_exp2f(mx[u] - mnew);
+            sum[u] *= sc;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[u][d] *= sc;
+            mx[u] = mnew;
+        }
+        float pv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(s0[r] - mx[u]); pv[4 + r] = __builtin_amdgcn_exp2f(s1[r] - mx[u]); }
+        bf16x8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bf16_t h = (bf16_t)pv[e];
+            ph[e] = h;
+            pl[e] = (bf16_t)(pv[e] - (float)h);
+        }
+        sum[u] += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            // dims d*16 + (r16 & 3)*4 ..: 32-dim group d >> 1, chunk (d & 1)*2 + vch inside it (hi), + 4 (lo)
+            const int ch = (d >> 1) * 8 + (d & 1) * 2 + vch;
+            const char* ph0 = vbase + c * 8192 + ((ch ^ vsw) << 4);
+            const char* pl0 = vbase + c * 8192 + (((ch + 4) ^ vsw) << 4);
+            const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lptr_t)ph0);
+            const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lptr_t)(ph0 + 4096));
+            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lptr_t)pl0);
+            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lptr_t)(pl0 + 4096));
+            const bf16x8 vh = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8 vl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            x3_mma16(o[u][d], vh, vl, ph, pl);   // rows = head dims d*16 + .., columns = queries
+        }
+    };
+    auto tile_keys_of = [&](auto U, const int k0, const int tk) {
+        constexpr int u = decltype(U)::value;
+        if (mt0 + NW * u >= nmt) return;
+        const int nfull = (nkeys - k0 < tk ? (nkeys - k0 > 0 ? nkeys - k0 : 0) : tk) >> 5;      // chunks of this super-tile without a masked key
+        for (int c = 0; c < nfull; ++c) chunk(U, c, k0 + c * 32, false);
+        if ((nfull << 5) < tk) chunk(U, nfull, k0 + nfull * 32, true);                          // the one chunk that reaches past the key list
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (!MULTI) {
+        tile_keys_of(U0(), 0, NK32);
+        tile_keys_of(U1(), 0, NK32);
+    } else {
+        for (int k0 = 0; k0 < NK32; k0 += TK) {
+            const int tk = NK32 - k0 < TK ? NK32 - k0 : TK;
+            if (k0 > 0) {
+                key_rows(k0, tk);
+                stage(tk);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            tile_keys_of(U0(), k0, tk);
+            if (k0 + TK < NK32) __syncthreads();                  // every wave is done reading: the images may be overwritten
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int mt = mt0 + NW * u;
+        if (mt >= nmt) break;
+        float s = g4_sum(sum[u]);
+        float padw = 0.f;
+        if (np > 0) { padw = (float)np * __builtin_amdgcn_exp2f(-mx[u]); s += padw; }
+        const float inv = 1.f / s;
+        const int qi = mt * 16 + r16;
+        if (qi < n) {
+            float* dst = a.out + (int64_t)qrow[u] * a.ldo + head * HD + g * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {        // o[d][r] = O[q = r16][dim d*16 + g*4 + r]
+                float o4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = o[u][d][r];
+                    if (np > 0) v += padw * a.v_bias[head * HD + d * 16 + g * 4 + r];
+                    o4[r] = v * inv;
+                }
+                store4_planes(dst + d * 16, o4);
+            }
+        }
+    }
+}
+
+void launch_rot_x3(AttnRotX3Args a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
+    const int64_t nk32 = (a.stride + 31) / 32 * 32;
+    const bool multi = nk32 * 512 > 144 * 1024;              // the window's K and V planes do not fit beside nothing else: walk it in super-tiles
+    a.tile_keys = multi ? 128 : (int)nk32;          // (the super-tile kernel's staging is sized for 128 keys on 16 waves)
+    const size_t lds = (size_t)a.tile_keys * 512;
+    static Toc3dLdsAttr attr_s, attr_m;
+    if (multi) attr_m.ensure(reinterpret_cast<const void*>(&attn_rot_x3_kernel<true>), 144 * 1024);
+    else attr_s.ensure(reinterpret_cast<const void*>(&attn_rot_x3_kernel<false>), 144 * 1024);
+    const int nqt = (int)((max_count + 15) / 16);
+    if (multi) {
+        // one query tile per wave, 16-wave workgroups, the grid's third dimension over groups of 16 query tiles
+        toc3d_launch(attn_rot_x3_kernel<true>, dim3((unsigned)num_heads, (unsigned)nwin, (unsigned)((nqt + 15) / 16)), dim3(1024), lds, s, a);
+        return;
+    }
+    const int64_t wgs = nwin * num_heads;
+    const int by_lds = (int)(160 * 1024 / lds);
+    int per_cu = (int)((wgs + 255) / 256);                   // workgroups per CU if the whole grid is to be resident
+    per_cu = per_cu < 1 ? 1 : (per_cu > by_lds ? by_lds : per_cu);
+    int quads = 4 / per_cu;                                   // waves per SIMD and workgroup (the kernel is held to 128 registers: 4 waves per SIMD)
+    quads = quads < 1 ? 1 : quads;
+    const int want = (nqt + 3) / 4;                           // one query tile per wave
+    quads = quads > want ? want : quads;
+    int least = ((nqt + 1) / 2 + 3) / 4;                      // two query tiles per wave at most ...
+    const int by_keys = (int)((a.tile_keys + 127) / 128);     // ... and at most X3_MAXPC = 8 DMA pieces of 4 keys per wave
+    least = least < by_keys ? by_keys : least;
+    quads = quads < least ? least : quads;
+    toc3d_launch(attn_rot_x3_kernel<false>, dim3((unsigned)num_heads, (unsigned)nwin), dim3(256 * quads), lds, s, a);
+}
+
 }  // namespace
 
 extern "C" {
@@ -298,7 +563,25 @@ int toc3d_window_attention_rot(int dtype, const void* qkv, int64_t ldqkv, void* 
                                int64_t nwin, int64_t max_count, int64_t num_heads, const float* v_bias,
                                int64_t n_prefetch, const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int64_t prefetch_workgroups,
                                toc3d_stream_t stream) {
-    TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_window_attention_rot: bf16 only (the f32 path is toc3d_window_attention)");
+    TOC3D_REQUIRE(dtype == TOC3D_BF16 || dtype == TOC3D_F32X3P, "toc3d_window_attention_rot: bf16, or (hi, lo) planes of the bf16 x 3 precision (TOC3D_DTYPE_F32X3P); exact f32 is toc3d_window_attention");
+    if (dtype == TOC3D_F32X3P) {
+        // q|k|v and out in planes (written by toc3d_linear_qkv_rope with TOC3D_DTYPE_F32X3P / F32X3WO; out = the projection GEMM's A operand); leading dimensions in f32 elements
+        TOC3D_REQUIRE(qkv && out && rows && count, "toc3d_window_attention_rot: null buffer");
+        TOC3D_REQUIRE(!npad || v_bias, "toc3d_window_attention_rot: npad given without v_bias");
+        TOC3D_REQUIRE(!count_k || (pad_rot && slots), "toc3d_window_attention_rot: count_k given without pad_rot / slots");
+        TOC3D_REQUIRE(num_heads > 0 && nwin >= 0 && max_count >= 0 && stride >= max_count, "toc3d_window_attention_rot: bad dims");
+        TOC3D_REQUIRE(stride <= 1024 && max_count <= 512, "toc3d_window_attention_rot: windows of up to 1024 keys / 512 queries");
+        const int64_t Cx = num_heads * HD;
+        TOC3D_REQUIRE(ldqkv >= 3 * Cx && ldo >= Cx && ldqkv % 32 == 0 && ldo % 32 == 0, "toc3d_window_attention_rot: rows of planes are whole 32-element groups (ldqkv, ldo multiples of 32)");
+        TOC3D_REQUIRE(((uintptr_t)qkv % 128) == 0 && ((uintptr_t)out % 128) == 0 && (!pad_rot || ((uintptr_t)pad_rot % 128) == 0), "toc3d_window_attention_rot: planes start on 128-byte boundaries");
+        TOC3D_REQUIRE(num_heads <= 65535 && nwin <= 65535, "toc3d_window_attention_rot: grid too large");
+        TOC3D_REQUIRE(n_prefetch == 0 || prefetch_workgroups == 0, "toc3d_window_attention_rot: the planes form carries no weight prefetch");
+        if (nwin == 0 || max_count == 0) return TOC3D_OK;
+        AttnRotX3Args x{(const float*)qkv, ldqkv, (float*)out, ldo, rows, slots ? slots : rows, count, count_k, npad, (const float*)pad_rot, stride, (int)Cx, v_bias, 0};
+        launch_rot_x3(x, max_count, num_heads, nwin, as_stream(stream));
+        TOC3D_LAUNCH_CHECK("toc3d_window_attention_rot");
+        return TOC3D_OK;
+    }
     TOC3D_REQUIRE(qkv && out && rows && count, "toc3d_window_attention_rot: null buffer");
     TOC3D_REQUIRE(!npad || v_bias, "toc3d_window_attention_rot: npad given without v_bias");
     TOC3D_REQUIRE(!count_k || (pad_rot && slots), "toc3d_window_attention_rot: count_k given without pad_rot / slots");

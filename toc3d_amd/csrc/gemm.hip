@@ -467,20 +467,25 @@ int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const v
 int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
                           int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
                           float q_scale, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear_qkv_rope: bf16 only (the f32 path rotates inside toc3d_window_attention)");
+    // bf16, or bf16 x 3 on (hi, lo) planes (round 6): W in planes, the rotated q|k|v rows written as planes; A in planes (F32X3P) or plain f32 (F32X3WO)
+    const bool x3 = dtype == TOC3D_F32X3P || dtype == TOC3D_F32X3WO;
+    TOC3D_REQUIRE(dtype == TOC3D_BF16 || x3, "toc3d_linear_qkv_rope: bf16, TOC3D_DTYPE_F32X3P or F32X3WO (exact f32 rotates inside toc3d_window_attention)");
     TOC3D_REQUIRE(A && W && out && rope_rc && rope_tab, "toc3d_linear_qkv_rope: null buffer");
     TOC3D_REQUIRE(M >= 0 && N > 0 && N % 192 == 0 && K > 0 && K % 64 == 0, "toc3d_linear_qkv_rope: N = 3C with C a multiple of 64, K a multiple of 64");
-    TOC3D_REQUIRE(lda >= K && ldw >= K && ldo >= N && (lda * 2) % 16 == 0 && (ldw * 2) % 16 == 0, "toc3d_linear_qkv_rope: bad leading dims");
+    const int esz = x3 ? 4 : 2;
+    TOC3D_REQUIRE(lda >= K && ldw >= K && ldo >= N && (lda * esz) % 16 == 0 && (ldw * esz) % 16 == 0, "toc3d_linear_qkv_rope: bad leading dims");
     TOC3D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)rope_tab % 16) == 0, "toc3d_linear_qkv_rope: misaligned buffer");
-    TOC3D_REQUIRE(rope_side > 0 && rope_side <= 64, "toc3d_linear_qkv_rope: rope_side out of range (the tables live in LDS: <= 64)");
+    TOC3D_REQUIRE(rope_side > 0 && rope_side <= 64, "toc3d_linear_qkv_rope: rope_side out of range (the tables live in LDS: <= 64; launch_cfg / launch_phased size their LDS attribute for 64)");
+    if (x3) TOC3D_REQUIRE(ldo % 32 == 0 && ((uintptr_t)out % 128) == 0 && (dtype != TOC3D_F32X3P || lda % 32 == 0), "toc3d_linear_qkv_rope: rows of (hi, lo) planes are whole 32-element groups on 128-byte boundaries");
     if (M == 0) return TOC3D_OK;
-    const bool vec = ldo % 4 == 0 && (uintptr_t)out % 8 == 0;
+    const bool vec = ldo % 4 == 0 && (uintptr_t)out % (4 * esz) == 0;
     static const bool wide_ok = [] { const char* e = getenv("TOC3D_WIDE_STORES"); return !(e && e[0] == '0'); }();
-    const bool vec8 = wide_ok && vec && ldo % 8 == 0 && (uintptr_t)out % 16 == 0;
+    const bool vec8 = !x3 && wide_ok && vec && ldo % 8 == 0 && (uintptr_t)out % 16 == 0;
     GemmArgs a{A, lda, W, ldw, bias, out, ldo, nullptr, 0, 0, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K, 0, 0, vec ? 1 : 0, vec8 ? 1 : 0,
-               nullptr, 0, nullptr, 0, 0, nullptr, 0.f, 0.f, nullptr, 0, 0, 0, nullptr, rope_rc, rope_tab, (int)rope_side, q_scale};
+               nullptr, 0, nullptr, 0, 0, nullptr, 0.f, 0.f, nullptr, 0, 0, 0, nullptr, rope_rc, rope_tab, (int)rope_side, q_scale,
+               dtype == TOC3D_F32X3P ? 1 : 0, x3 ? 1 : 0, x3 ? 1 : 0};
     g_bad_variant = false;
-    const int rc = launch_gemm(1, TOC3D_EPI_QKV_ROPE, variant, a, as_stream(stream));
+    const int rc = x3 ? toc3d_gemm_launch_x3(TOC3D_EPI_QKV_ROPE, variant, a, as_stream(stream)) : launch_gemm(1, TOC3D_EPI_QKV_ROPE, variant, a, as_stream(stream));
     if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear_qkv_rope: bad variant %d", variant); return rc; }
     if (g_bad_variant) { toc3d_set_error("toc3d_linear_qkv_rope: variant %d cannot serve this epilogue", variant); return TOC3D_ERR_UNSUPPORTED; }
     TOC3D_LAUNCH_CHECK("toc3d_linear_qkv_rope");

@@ -15,6 +15,8 @@ int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s)
         // ... and norm2 across the projection -> w1|w2 boundary (round 4): the projection leaves the updated rows as an f32 copy with their statistics
         case TOC3D_EPI_RESIDUAL_STATS: return launch_epi_x<TOC3D_EPI_RESIDUAL_STATS, 3>(variant, a, s);
         case TOC3D_EPI_SWIGLU_STATS_LN: return launch_epi_x<TOC3D_EPI_SWIGLU_STATS_LN, 3>(variant, a, s);
+        // ... and the rotating q|k|v epilogue (round 6): RoPE + q scale on the f32 accumulators, rows written as (hi, lo) planes for toc3d_window_attention_rot
+        case TOC3D_EPI_QKV_ROPE: return launch_epi_x<TOC3D_EPI_QKV_ROPE, 3>(variant, a, s);
         default: return TOC3D_ERR_ARG;
     }
 }

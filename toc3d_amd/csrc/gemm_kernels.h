@@ -63,7 +63,7 @@ int toc3d_gemm_launch_residual(int is_bf16, int epi, int variant, const GemmArgs
 int toc3d_gemm_launch_swiglu(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);     // EPI_SWIGLU, EPI_SWIGLU_STATS, EPI_SWIGLU_STATS_LN
 int toc3d_gemm_launch_rope(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);       // EPI_QKV_ROPE (bf16)
 int toc3d_gemm_launch_lnself(int epi, int variant, const GemmArgs& a, hipStream_t s);                   // bf16: EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF
-int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 3 products on f32 operands: epilogues 0-3, 8
+int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 3 products on f32 operands: epilogues 0-9
 int toc3d_gemm_launch_x6(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 6 (three-way split): f32-grade products
 int toc3d_gemm_launch_splitk(int dtype, int epi, int variant, const GemmArgs& a, hipStream_t s);       // residual epilogues with a.split > 1 (gemm_epi_splitk.hip); dtype: TOC3D_BF16 / TOC3D_F32 / TOC3D_F32X3
 int64_t toc3d_gemm_splitk_tile_elems(int variant);                                                      // BM * BN of a split-K tile variant (0: the variant has no split-K form)
@@ -497,6 +497,10 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
             const int col = col0 + j * 16 + g * 4;
             T o4[4];
             act4(i, j, o4);
+            if constexpr (sizeof(T) == 4 && epi_is_rope(EPI)) {
+                // bf16 x 3 on planes: the rotated q | k | v rows leave as (hi, lo) planes -- what toc3d_window_attention_rot stages by DMA (N = 3C, C % 64 == 0: whole groups of 4)
+                if (a.out_planes) { store_planes4(reinterpret_cast<float*>(orow), col, o4); continue; }
+            }
             if (a.vec && nok[j] == 4) epi_store4(orow + col, o4);
             else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
         }
@@ -1287,7 +1291,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
 //   K-tile (8.4 MFLOP at 4096 FLOP / clock / CU): the LDS port is co-critical, which is what the re-read of B0 (28 KB per wave) was costing.
 // ---------------------------------------------------------------------------------------------------
 template <int ROWS, int TB, int NTHR>
-TOC3D_DEV void stage_half(const bf16_t* __restrict__ g, int64_t ld, int row0, int max_row, int k0, int h, char* lds_half, int wave, int lane) {
+TOC3D_DEV void stage_half(const char* __restrict__ g, int64_t ld_bytes, int row0, int max_row, int64_t k0_bytes, int h, char* lds_half, int wave, int lane) {
     // half-tile h of an operand whose wave blocks are TB rows tall: LDS row lr = (wave-row w) * TB/2 + j  <->  tile row w * TB + h * TB/2 + j
     constexpr int L = ROWS * 8 / NTHR;
     static_assert(L * NTHR == ROWS * 8, "half-tile must be a whole number of 16-byte loads per thread");
@@ -1298,13 +1302,18 @@ TOC3D_DEV void stage_half(const bf16_t* __restrict__ g, int64_t ld, int row0, in
         const int w = lr / (TB / 2), j = lr % (TB / 2);
         int gr = row0 + w * TB + h * (TB / 2) + j;
         gr = gr < max_row ? gr : max_row;
-        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ (lr & 7)) << 4);
+        const char* src = g + (int64_t)gr * ld_bytes + k0_bytes + ((p ^ (lr & 7)) << 4);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_half + (i * NTHR + wave * 64) * 16), 16, 0, 0);
     }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN>
+// X3 (round 6): the bf16 x 3 form on (hi, lo) PLANES (TOC3D_DTYPE_F32X3P: both operands in planes).  A 128-byte row piece of a planes operand is [32 x hi | 32 x lo] of
+// 32 consecutive k -- byte for byte the image the bf16 kernel stages for 64 consecutive k -- so staging, LDS layout and fragment reads are unchanged: a K-tile covers 32 k
+// (nk = K / 32), the fragment of "K step 0" is hi and that of "K step 1" lo, and a (row tile, column tile) pair takes THREE MFMAs per K-tile (lo.hi, hi.lo, hi.hi: the order
+// of gemm_tile's X3 loop, so every x3 variant returns the same bits) instead of two: 1.5x the matrix-core work per LDS byte of the bf16 form, whose LDS port is co-critical.
+template <int EPI, int BM, int BN, int WM, int WN, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
+    using T = std::conditional_t<X3, float, bf16_t>;      // element type of the epilogue's buffers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(WM * WN == 8, "eight wavefronts");
     constexpr int NTHR = 512;
@@ -1335,9 +1344,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
         m0 = (r0 + l % band) * BM;
         n0 = (l / band) * BN;
     }
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
-    const bf16_t* W = reinterpret_cast<const bf16_t*>(a.W);
-    const int nk = a.K / 64;
+    const char* A = reinterpret_cast<const char*>(a.A);
+    const char* W = reinterpret_cast<const char*>(a.W);
+    const int64_t lda_b = a.lda * (int64_t)sizeof(T), ldw_b = a.ldw * (int64_t)sizeof(T);
+    const int nk = a.K / (X3 ? 32 : 64);                  // 128 bytes of every row per K-tile
     const int a_max = a.M - 1, w_max = ((a.N + 127) / 128) * 128 - 1;
     // behind the two-K-tile ring: the (mean, rstd) row table of the LayerNorm-consuming epilogues, then the RoPE tables of the rotating q|k|v epilogue
     f32x2* lnrow = reinterpret_cast<f32x2*>(smem + 2 * KT);
@@ -1374,8 +1384,8 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
     Frag<bf16_t> fa[MT2][2], fb0[NT2][2], fb1[NT2][2];    // [tile][32-wide K step]; the two B sets swap roles every K-tile (see ktile)
 
     auto slot = [&](int t, int kind, int h) -> char* { return smem + (t & 1) * KT + kind * 2 * AH + h * (kind ? BH : AH); };
-    auto stage_a = [&](int t, int h) { stage_half<BM / 2, TM, NTHR>(A, a.lda, m0, a_max, t * 64, h, slot(t, 0, h), wave, lane); };
-    auto stage_b = [&](int t, int h) { stage_half<BN / 2, TN, NTHR>(W, a.ldw, n0, w_max, t * 64, h, slot(t, 1, h), wave, lane); };
+    auto stage_a = [&](int t, int h) { stage_half<BM / 2, TM, NTHR>(A, lda_b, m0, a_max, (int64_t)t * 128, h, slot(t, 0, h), wave, lane); };
+    auto stage_b = [&](int t, int h) { stage_half<BN / 2, TN, NTHR>(W, ldw_b, n0, w_max, (int64_t)t * 128, h, slot(t, 1, h), wave, lane); };
     auto read_a = [&](int t, int h) {
         const char* base = slot(t, 0, h);
 #pragma unroll
@@ -1393,12 +1403,24 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
     auto mfma = [&](auto HA, auto HB, const Frag<bf16_t> (&fb)[NT2][2]) {
         constexpr int ha = decltype(HA)::value, hb = decltype(HB)::value;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < MT2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT2; ++j) {      // [0] = hi, [1] = lo; small terms first, the order of gemm_tile's X3 loop
+                    f32x4& c = acc[ha * MT2 + i][hb * NT2 + j];
+                    mma_step(c, fb[j][1], fa[i][0]);
+                    mma_step(c, fb[j][0], fa[i][1]);
+                    mma_step(c, fb[j][0], fa[i][0]);
+                }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < MT2; ++i)
 #pragma unroll
                 for (int j = 0; j < NT2; ++j) mma_step(acc[ha * MT2 + i][hb * NT2 + j], fb[j][ks], fa[i][ks]);   // swapped: see gemm_epilogue
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -1459,7 +1481,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmArgs a) {
     if (!late) tile_barrier();                            // every wave executes the same number of barriers (and is done with the ring: the statistics overlay it)
     TOC3D_TRACE(1);
 
-    tile_finish<bf16_t, EPI, BM, BN, WM, WN, false>(a, acc, m0, n0, smem, lnrow, rope_rcs, rope_tab);
+    tile_finish<T, EPI, BM, BN, WM, WN, false>(a, acc, m0, n0, smem, lnrow, rope_rcs, rope_tab);
     TOC3D_TRACE_END();
 }
 
@@ -1470,7 +1492,7 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr bool unsupported = (epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) ||
                                  (EPI >= TOC3D_EPI_SWIGLU_STATS && EPI != TOC3D_EPI_CONV3X3 && sizeof(T) != 2 &&
                                   !(X3 == 3 && (EPI == TOC3D_EPI_SWIGLU_STATS || EPI == TOC3D_EPI_RESIDUAL_LN || EPI == TOC3D_EPI_RESIDUAL_STATS ||
-                                                EPI == TOC3D_EPI_SWIGLU_STATS_LN)));   // ... and the bf16 x 3 forms of the ffn_ln and norm2 folds (f32 copies, f32 statistics)
+                                                EPI == TOC3D_EPI_SWIGLU_STATS_LN || EPI == TOC3D_EPI_QKV_ROPE)));   // ... and the bf16 x 3 forms of the ffn_ln and norm2 folds (f32 copies, f32 statistics)
     constexpr bool partial_round = (BM * (RB / 16)) % (64 * WM * WN) != 0 || (BN * (RB / 16)) % (64 * WM * WN) != 0;      // 96- / 160-row tiles
     if constexpr (unsupported || (partial_round && (X3 != 0 || EPI == TOC3D_EPI_CONV3X3))) {
         g_bad_variant = true;
@@ -1527,7 +1549,7 @@ int launch_epi_sk(int variant, const GemmArgs& a, hipStream_t s) {
     return TOC3D_OK;
 }
 
-template <int EPI, int BM, int BN, int WM, int WN>
+template <int EPI, int BM, int BN, int WM, int WN, bool X3 = false>
 void launch_phased(const GemmArgs& a, hipStream_t s) {
     // round 5: every linear epilogue (the folded LayerNorms' statistics in and out, the rotating q|k|v epilogue); not the conv gather (its own operand loader)
     // nor the experimental self-normalising forms (statistics inside the K loop)
@@ -1538,11 +1560,12 @@ void launch_phased(const GemmArgs& a, hipStream_t s) {
         constexpr int lds_fixed = 2 * (BM + BN) * 128 + (epi_ln_in(EPI) ? BM * 8 : 0);              // two K-tiles of 64 bf16 (+ the row table)
         const int lds = lds_fixed + (epi_is_rope(EPI) ? (a.rope_L * 256 + 1023) / 1024 * 1024 : 0);   // + the RoPE tables (cos | sin), whole DMA instructions
         if (lds > 160 * 1024) { g_bad_variant = true; return; }
+        if (X3 && !(a.a_planes && a.w_planes)) { g_bad_variant = true; return; }      // the x3 form stages planes as they lie: both operands must be planes (TOC3D_DTYPE_F32X3P)
         static Toc3dLdsAttr attr;
-        attr.ensure(reinterpret_cast<const void*>(&gemm_phased_kernel<EPI, BM, BN, WM, WN>), lds_fixed + (epi_is_rope(EPI) ? 64 * 256 : 0));
+        attr.ensure(reinterpret_cast<const void*>(&gemm_phased_kernel<EPI, BM, BN, WM, WN, X3>), lds_fixed + (epi_is_rope(EPI) ? 64 * 256 : 0));   // (64 * 256: the largest rope_side toc3d_linear_qkv_rope accepts)
         const int tm = (a.M + BM - 1) / BM, tn = (a.N + BN - 1) / BN;
         const int tiles = a.order == 0 ? tm * tn : 8 * ((tm + 7) / 8) * tn;
-        toc3d_launch((gemm_phased_kernel<EPI, BM, BN, WM, WN>), dim3(tiles), dim3(512), lds, s, a);
+        toc3d_launch((gemm_phased_kernel<EPI, BM, BN, WM, WN, X3>), dim3(tiles), dim3(512), lds, s, a);
     }
 }
 
@@ -1704,6 +1727,9 @@ int launch_epi_x(int variant, GemmArgs a, hipStream_t s) {
         const int t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
         variant = t128 < 700 ? 17 : 16;
     }
+    // the rotating q|k|v epilogue (round 6) is held to 128 registers on the 8-wave tiles that share a CU between two workgroups (the bf16 form of variants 52 / 53 does the
+    // same): unconstrained, variant 49 took 148 -- ONE workgroup per CU, 137 instead of ~75 us for q|k|v at M = 6000
+    constexpr int RO = epi_is_rope(EPI) ? 4 : 1;
     switch (variant) {
         case 1: launch_cfg<float, EPI, 128, 128, 2, 128, 2, 2, 1, X>(a, s); break;
         case 8: launch_cfg<float, EPI, 128, 128, 1, 128, 2, 2, 1, X>(a, s); break;
@@ -1712,19 +1738,24 @@ int launch_epi_x(int variant, GemmArgs a, hipStream_t s) {
         case 9: launch_cfg<float, EPI, 128, 64, 2, 128, 2, 2, 1, X>(a, s); break;
         case 29: if constexpr (X == 3) launch_cfg<float, EPI, 128, 128, 4, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
         case 33: if constexpr (X == 3) launch_cfg<float, EPI, 128, 64, 4, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
-        case 45: if constexpr (X == 3) launch_cfg<float, EPI, 128, 192, 2, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
-        case 47: if constexpr (X == 3) launch_cfg<float, EPI, 128, 192, 2, 128, 4, 2, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
-        case 52: if constexpr (X == 3) launch_cfg<float, EPI, 192, 192, 1, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 45: if constexpr (X == 3) launch_cfg<float, EPI, 128, 192, 2, 128, 2, 4, RO, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 47: if constexpr (X == 3) launch_cfg<float, EPI, 128, 192, 2, 128, 4, 2, RO, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 52: if constexpr (X == 3) launch_cfg<float, EPI, 192, 192, 1, 128, 2, 4, RO, X>(a, s); else return TOC3D_ERR_ARG; break;
         case 53: if constexpr (X == 3) launch_cfg<float, EPI, 192, 192, 2, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
         case 10: launch_cfg<float, EPI, 64, 128, 2, 128, 2, 2, 1, X>(a, s); break;
         case 14: launch_cfg<float, EPI, 64, 64, 2, 128, 2, 2, 1, X>(a, s); break;
         case 16: launch_cfg<float, EPI, 128, 128, 1, 128, 2, 4, 1, X>(a, s); break;
         case 17: launch_cfg<float, EPI, 128, 128, 2, 128, 2, 4, 1, X>(a, s); break;
-        case 19: launch_cfg<float, EPI, 256, 128, 1, 128, 4, 2, 1, X>(a, s); break;
-        case 22: launch_cfg<float, EPI, 128, 128, 1, 256, 2, 4, 1, X>(a, s); break;      // K-tile of 64 f32: half the barriers per K
+        case 19: launch_cfg<float, EPI, 256, 128, 1, 128, 4, 2, RO, X>(a, s); break;
+        case 22: launch_cfg<float, EPI, 128, 128, 1, 256, 2, 4, RO, X>(a, s); break;      // K-tile of 64 f32: half the barriers per K
         case 26: launch_cfg<float, EPI, 64, 128, 1, 256, 2, 4, 1, X>(a, s); break;
         case 28: launch_cfg<float, EPI, 128, 128, 3, 128, 2, 4, 1, X>(a, s); break;
-        case 49: launch_cfg<float, EPI, 192, 128, 2, 128, 2, 4, 1, X>(a, s); break;
+        case 49: launch_cfg<float, EPI, 192, 128, 2, 128, 2, 4, RO, X>(a, s); break;
+        // phased big tiles on planes (round 6; gemm_phased_kernel, X3): both operands must be planes (TOC3D_DTYPE_F32X3P), K a multiple of 32
+        case 60: if constexpr (X == 3) launch_phased<EPI, 256, 256, 2, 4, true>(a, s); else return TOC3D_ERR_ARG; break;
+        case 61: if constexpr (X == 3) launch_phased<EPI, 256, 128, 4, 2, true>(a, s); else return TOC3D_ERR_ARG; break;
+        case 62: if constexpr (X == 3) launch_phased<EPI, 128, 256, 2, 4, true>(a, s); else return TOC3D_ERR_ARG; break;
+        case 63: if constexpr (X == 3) launch_phased<EPI, 128, 128, 2, 4, true>(a, s); else return TOC3D_ERR_ARG; break;
         default: return TOC3D_ERR_ARG;
     }
     return TOC3D_OK;
