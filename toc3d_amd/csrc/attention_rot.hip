@@ -508,18 +508,38 @@ __global__ __launch_bounds__(1024, 4) void attn_rot_x3_kernel(AttnRotX3Args a) {
         if (np > 0) { padw = (float)np * __builtin_amdgcn_exp2f(-mx[u]); s += padw; }
         const float inv = 1.f / s;
         const int qi = mt * 16 + r16;
-        if (qi < n) {
-            float* dst = a.out + (int64_t)qrow[u] * a.ldo + head * HD + g * 4;
+        // o[d][r] = O[q = r16][dim d*16 + g*4 + r].  (hi, lo) planes of the row, 16 bytes per store: the dim tiles d, d + 1 of one query are exchanged between neighbouring lane
+        // groups (v_permlane16_swap: an even group ends with 8 consecutive dims of tile d, an odd one with 8 of tile d + 1) -- 8 stores per lane instead of 16
+        char* drow = reinterpret_cast<char*>(a.out + (int64_t)qrow[u] * a.ldo + head * HD);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {        // o[d][r] = O[q = r16][dim d*16 + g*4 + r]
-                float o4[4];
+        for (int d = 0; d < 4; d += 2) {
+            typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            unsigned w[2][2][2];                 // [tile d | d + 1][hi | lo][2 words]
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                bf16x4_t hi, lo;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = o[u][d][r];
-                    if (np > 0) v += padw * a.v_bias[head * HD + d * 16 + g * 4 + r];
-                    o4[r] = v * inv;
+                    float v = o[u][d + t][r];
+                    if (np > 0) v += padw * a.v_bias[head * HD + (d + t) * 16 + g * 4 + r];
+                    v *= inv;
+                    const bf16_t h = (bf16_t)v;
+                    hi[r] = h;
+                    lo[r] = (bf16_t)(v - (float)h);
                 }
-                store4_planes(dst + d * 16, o4);
+                const unsigned long long uh = __builtin_bit_cast(unsigned long long, hi), ul = __builtin_bit_cast(unsigned long long, lo);
+                w[t][0][0] = (unsigned)uh; w[t][0][1] = (unsigned)(uh >> 32);
+                w[t][1][0] = (unsigned)ul; w[t][1][1] = (unsigned)(ul >> 32);
+            }
+            // dims (d + t)*16 + g*4 .. of the 32-dim group d >> 1: byte (t*16 + g*4) * 2 of the hi plane; even groups store tile d at their own dims, odd groups tile d + 1
+            // four dims to the left (their left neighbour's)
+            char* p = drow + (d >> 1) * 128 + ((g & 1) ? (16 + (g - 1) * 4) * 2 : g * 8);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const auto rx = __builtin_amdgcn_permlane16_swap(w[0][pl][0], w[1][pl][0], false, false);
+                const auto ry = __builtin_amdgcn_permlane16_swap(w[0][pl][1], w[1][pl][1], false, false);
+                if (qi < n) *reinterpret_cast<u32x4*>(p + pl * 64) = u32x4{rx[0], ry[0], rx[1], ry[1]};
             }
         }
     }
@@ -527,7 +547,10 @@ __global__ __launch_bounds__(1024, 4) void attn_rot_x3_kernel(AttnRotX3Args a) {
 
 void launch_rot_x3(AttnRotX3Args a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
     const int64_t nk32 = (a.stride + 31) / 32 * 32;
-    const bool multi = nk32 * 512 > 144 * 1024;              // the window's K and V planes do not fit beside nothing else: walk it in super-tiles
+#ifndef TOC3D_X3ROT_WHOLE_KB
+#define TOC3D_X3ROT_WHOLE_KB 144
+#endif
+    const bool multi = nk32 * 512 > TOC3D_X3ROT_WHOLE_KB * 1024;   // the window's K and V planes do not fit beside nothing else: walk it in super-tiles
     a.tile_keys = multi ? 128 : (int)nk32;          // (the super-tile kernel's staging is sized for 128 keys on 16 waves)
     const size_t lds = (size_t)a.tile_keys * 512;
     static Toc3dLdsAttr attr_s, attr_m;

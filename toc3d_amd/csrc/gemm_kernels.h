@@ -340,6 +340,24 @@ TOC3D_DEV void store_planes1(float* row, int col, float v) {
     *reinterpret_cast<bf16_t*>(p + 64) = (bf16_t)(v - (float)h);
 }
 
+// Two row tiles of a planes output at a time (round 6): the epilogues of the single-round launches are store-ISSUE bound (see store_pair_wide), and a planes tile
+// left as FOUR 8-byte stores per lane and row-tile pair (hi and lo of each tile) where the f32 output it replaces took two 16-byte ones -- the rotating x3 q|k|v
+// epilogue read 120 us against ~105 for the plain bias epilogue at M = 6000.  Here the hi planes of row tiles i, i + 1 leave as one 16-byte store per lane (the lane-group
+// exchange of store_pair_wide on the bf16 hi values), the lo planes as another.  va / vb: this lane's 4 columns col.. of the two row tiles; col % 4 == 0.
+TOC3D_DEV void store_planes_pair(float* row_a, float* row_b, int col, const float (&va)[4], const float (&vb)[4], bool ok_a, bool ok_b, int g) {
+    bf16_t ha[4], la[4], hb[4], lb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ha[e] = (bf16_t)va[e]; la[e] = (bf16_t)(va[e] - (float)ha[e]);
+        hb[e] = (bf16_t)vb[e]; lb[e] = (bf16_t)(vb[e] - (float)hb[e]);
+    }
+    const int off = (col >> 5) * 128 + (col & 31) * 2;
+    bf16_t* pa = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(row_a) + off);
+    bf16_t* pb = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(row_b) + off);
+    store_pair_wide(pa, pb, pack4(ha), pack4(hb), ok_a, ok_b, g);
+    store_pair_wide(pa + 32, pb + 32, pack4(la), pack4(lb), ok_a, ok_b, g);
+}
+
 // ---- epilogue of one wavefront's (MT*16) x (NT*16) accumulator block whose first row / column are row0 / col0.  The MFMA is issued
 // with the operands swapped (W fragment as A, activation fragment as B), so a lane holds C[row = .. + r16][4 consecutive cols =
 // .. + g*4 + 0..3]: 8-byte (bf16) / 16-byte (f32) vector accesses instead of 2- / 4-byte scattered ones.  a.vec (host-checked
@@ -404,6 +422,28 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                         } else {
                             if (ia) epi_store4(da, ha);
                             if (ib) epi_store4(da + 16 * a.ldo, hb);
+                        }
+                    }
+                return;
+            }
+        }
+        if constexpr (sizeof(T) == 4 && MT % 2 == 0) {
+            if (a.out_planes && a.vec) {                 // hidden units as (hi, lo) planes: pairs of row tiles leave as 16-byte stores (store_planes_pair)
+#pragma unroll
+                for (int i = 0; i < MT; i += 2)
+#pragma unroll
+                    for (int jp = 0; jp < NT / 2; ++jp) {
+                        T ha[4], hb[4];
+                        float s1, q1, s2, q2;
+                        const bool ia = units(i, jp, ha, s1, q1), ib = units(i + 1, jp, hb, s2, q2);
+                        if (epi_stats_out(EPI)) { gs[i * G + jp] = s1; gq[i * G + jp] = q1; gs[(i + 1) * G + jp] = s2; gq[(i + 1) * G + jp] = q2; }
+                        const int unit0 = ((col0 + jp * 32 + g * 4) >> 5) * 16 + g * 4;
+                        float* ra = reinterpret_cast<float*>(out) + (int64_t)(row0 + i * 16 + r16) * a.ldo;
+                        if (col0 + jp * 32 + 32 <= a.N) {                        // the whole 32-column group lies inside (wave-uniform)
+                            store_planes_pair(ra, ra + 16 * a.ldo, unit0, ha, hb, ia, ib, g);
+                        } else {
+                            if (ia) store_planes4(ra, unit0, ha);
+                            if (ib) store_planes4(ra + 16 * a.ldo, unit0, hb);
                         }
                     }
                 return;
@@ -505,6 +545,24 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
             else for (int r = 0; r < nok[j]; ++r) orow[col + r] = o4[r];
         }
     };
+    if constexpr (sizeof(T) == 4 && epi_is_rope(EPI) && MT % 2 == 0) {
+        if (a.out_planes) {                              // rotated q | k | v rows as planes, pairs of row tiles as 16-byte stores (N = 3C, C % 64 == 0: whole column tiles)
+#pragma unroll
+            for (int i = 0; i < MT; i += 2) {
+                const int ra = row0 + i * 16 + r16, rb = ra + 16;
+                float* oa = reinterpret_cast<float*>(a.out) + (int64_t)ra * a.ldo;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (col0 + j * 16 + 16 > a.N) continue;
+                    T va[4], vb[4];
+                    act4(i, j, va);
+                    act4(i + 1, j, vb);
+                    store_planes_pair(oa, oa + 16 * a.ldo, col0 + j * 16 + g * 4, va, vb, ra < a.M, rb < a.M, g);
+                }
+            }
+            return;
+        }
+    }
     if constexpr (!epi_is_residual(EPI) && sizeof(T) == 2 && MT % 2 == 0) {
         if (a.vec8) {                                    // bf16 outputs: pairs of row tiles leave as one 16-byte store per lane (store_pair_wide)
 #pragma unroll
@@ -529,10 +587,28 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
             return;
         }
     }
+    // The act-dtype copy of the residual epilogues as (hi, lo) planes: pairs of row tiles leave as 16-byte stores (store_planes_pair) -- the even tile's values are held until
+    // the odd tile of the same columns is formed (rows ascend with i: a valid odd tile implies a valid even one; an even tile whose partner lies past M leaves alone)
+    constexpr bool PAIR_OK = sizeof(T) == 4 && epi_act_copy(EPI) && epi_is_residual(EPI) && MT % 2 == 0;
+    float keep[PAIR_OK ? NT : 1][4];
+    float* keep_row = nullptr;
+    bool pair = PAIR_OK && a.out_planes;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) pair = pair && (nok[j] == 0 || nok[j] == 4);
+    (void)keep; (void)keep_row;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int row = row0 + i * 16 + r16;
-        if (row >= a.M) continue;
+        if (row >= a.M) {
+            if constexpr (PAIR_OK) {
+                if (pair && (i & 1) && keep_row) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        if (nok[j] == 4) store_planes4(keep_row, col0 + j * 16 + g * 4, keep[j]);
+                }
+            }
+            continue;
+        }
         float mu = 0.f, rs = 1.f;                        // EPI_RESIDUAL_LN: (mean, rstd) of this A row, prepared in LDS by the kernel
         if (LN_IN && epi_is_residual(EPI)) { const f32x2 v = lnrow[i * 16 + r16]; mu = v[0]; rs = v[1]; }
         (void)mu; (void)rs;
@@ -587,7 +663,21 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                     bool planes = false;
                     if constexpr (sizeof(T) == 4) {
                         if (a.out_planes) {
-                            if (nok[j] == 4) store_planes4(reinterpret_cast<float*>(arow - col), col, o4);
+                            bool done = false;
+                            if constexpr (PAIR_OK) {
+                                if (pair) {
+                                    if ((i & 1) == 0) {
+#pragma unroll
+                                        for (int r = 0; r < 4; ++r) keep[j][r] = o4[r];
+                                        keep_row = reinterpret_cast<float*>(arow - col);
+                                    } else {
+                                        store_planes_pair(keep_row, reinterpret_cast<float*>(arow - col), col, keep[j], o4, true, true, g);
+                                    }
+                                    done = true;
+                                }
+                            }
+                            if (done) {}
+                            else if (nok[j] == 4) store_planes4(reinterpret_cast<float*>(arow - col), col, o4);
                             else for (int r = 0; r < nok[j]; ++r) store_planes1(reinterpret_cast<float*>(arow - col), col + r, o4[r]);
                             planes = true;
                         }
