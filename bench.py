@@ -64,9 +64,13 @@ def cpu_baseline(cfg, sd_cpu, inp, name):
     """Oracle (CPU eager fp32 port of the reference path) on the host cores, SURVEY.md 8d / BASELINE.md section 3 protocol: 1 warm-up + the MEDIAN of
     3 frames of the same workload (the warm-up is a 1-view forward: it pages the weights in and spins the thread pool up at a sixth of a frame's cost)."""
     from oracle import toc3d_oracle as O
-    # eager PyTorch stops scaling (and regresses) well before 256 host threads on these small-M ops: cap at 32
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     args = lambda d: (d["x"], d["temp_queries"], d["temp_ref_points"], d["temp_vel"], d["temp_timestamp"], d["temp_ego_pose"], d["ego_pose_inv"])
+    ncpu = os.cpu_count() or 1
+    # SURVEY.md 8d says "all host cores".  Measured on the pool's 256-thread hosts in round 6 (profiles/r06_cpu_baseline_all_cores.json, this protocol with
+    # torch.set_num_threads(256)): 188.7 / 189.0 / 186.3 s per frame = 0.0053 frames/s against 3.9-4.3 s = 0.24 frames/s on 32 threads -- eager PyTorch on 6000-row ops
+    # collapses under a 256-way fork/join per op (and the run takes 25 minutes).  The baseline a reader would tune is the 32-thread one: that is `value`, `cores` says so,
+    # `host_cores` is the box's count, and the all-cores figure is quoted in `all_cores_note`.
+    torch.set_num_threads(min(ncpu, 32))
     ts = []
     with torch.no_grad():
         warm = dict(inp, x=inp["x"][:1], gumbel=[g[:1] for g in inp["gumbel"]])
@@ -76,9 +80,11 @@ def cpu_baseline(cfg, sd_cpu, inp, name):
             O.forward_toc3d(sd_cpu, cfg, *args(inp), True, inp["gumbel"])
             ts.append(time.perf_counter() - t0)
     dt = sorted(ts)[1]
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "config": name,
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": ncpu, "kind": "port", "config": name,
             "seconds_per_frame_each": [round(t, 3) for t in ts],
-            "sample": f"median of 3 frames (6 views @ 800x320 each) of the {name} workload after a 1-view warm-up, eager PyTorch fp32 oracle"}
+            "sample": f"median of 3 frames (6 views @ 800x320 each) of the {name} workload after a 1-view warm-up, eager PyTorch fp32 oracle",
+            "all_cores_note": "threads capped at 32: with all 256 host threads the same protocol reads 0.0053 frames/s (188 s per frame; measured in round 6, "
+                              "profiles/r06_cpu_baseline_all_cores.json) against 0.24 on 32 -- eager PyTorch does not scale past a few tens of threads on these ops"}
 
 
 def read_clocks():
@@ -372,6 +378,25 @@ def instrument(step, set_eager, cfg, V, h, w, precision, n_inst, want_block_loop
     roof["hbm_kernels"] = hk_out
     roof["hbm_kernels_note"] = f"raw event-timed figures are primary; *_corrected subtract the event-pair cost calibrated on a 64 KB copy launch ({1e3 * short_event_cost_ms:.2f} us) where that is < 30 % of the launch"
     roof["algorithmic_bytes_per_launch"] = gemm_bytes / gemm_n
+    # Per distinct GEMM launch: the COMBINED floor max(FLOPs / MFMA peak, algorithmic bytes / 6.3 TB/s) and the fraction of it the launch reaches (the
+    # MFMA fraction alone is the wrong roof for the N = 1024 residual GEMMs, whose f32 read-modify-write of the residual stream is a third of the launch).  6.3 TB/s = the
+    # achievable HBM3E rate of MI355X_MICROARCH.md (8 TB/s nominal); times are event-timed minus the calibrated event-pair cost.
+    per_shape = []
+    for k, v in sorted(detail.items(), key=lambda kv: -kv[1][1]):
+        mnk = re.search(r"epi(\d+) .*M=(\d+) N=(\d+) K=(\d+)", k)
+        if not (is_gemm(k) and mnk):
+            continue
+        e, M_, N_, K_ = (int(x) for x in mnk.groups())
+        out_b = 2 * M_ * N_ * 4 + (M_ * N_ * esz if e == 6 else 0) if e in (1, 5, 6) else (M_ * (N_ // 2) * esz if e in (2, 4, 7) else M_ * N_ * esz)
+        nbytes = (M_ * K_ + N_ * K_) * esz + N_ * 4 + out_b
+        fl = 2.0 * M_ * N_ * K_
+        t_us = max(1e-3, 1e3 * (v[1] / v[0] - event_cost_ms))
+        floor_us = max(fl / (peak * 1e12), nbytes / 6.3e12) * 1e6
+        per_shape.append({"launch": k.replace("toc3d_", ""), "per_step": v[0] // n_inst, "us": round(t_us, 2), "tflops": round(fl / t_us / 1e6, 1),
+                          "mb": round(nbytes / 1e6, 2), "floor_us": round(floor_us, 2), "floor": "mfma" if fl / (peak * 1e12) >= nbytes / 6.3e12 else "hbm",
+                          "frac_of_floor": round(floor_us / t_us, 3)})
+    roof["per_shape"] = per_shape
+    roof["per_shape_note"] = "floor_us = max(2MNK / peak, algorithmic bytes / 6.3 TB/s); frac_of_floor = floor_us / us; FLOPs as issued by the launch (pads skipped)"
     if verbose:
         tot = sum(v[1] for v in breakdown.values())
         print("[bench] per-op GPU time per step (ms), event-timed eager pass:", file=sys.stderr)
@@ -487,8 +512,8 @@ def dry_run(args, rank, world, tdist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)           # 50 warm-up + 200 timed iterations (the driver passes its own)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="toc3d_faster")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x3", "fp32x6"])
     ap.add_argument("--hw", default="320x800")
@@ -684,7 +709,7 @@ def main():
         roof, block_loop_ms = instrument(step, set_eager, cfg, V, h, w, args.precision, n_inst, want_block_loop=True, verbose=True)
         # memory-side bytes per launch of the same kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on
         # gfx950 + WRITE_SIZE, see profiles/r01_gemm_hbm_traffic.json); only valid for the profiled workload
-        for tag_ in ("r05", "r04", "r03", "r02", "r01"):               # newest committed PMC pass of this workload (tools/gpu/profile.sh + tools/summarize_prof.py)
+        for tag_ in ("r06", "r05", "r04", "r03", "r02", "r01"):               # newest committed PMC pass of this workload (tools/gpu/profile.sh + tools/summarize_prof.py)
             tpath = os.path.join(ROOT, "profiles", f"{tag_}_gemm_hbm_traffic.json")
             if os.path.exists(tpath) and args.config == "toc3d_faster" and (H, W) == (320, 800) and args.precision == "bf16":
                 tj = json.load(open(tpath))
@@ -880,6 +905,25 @@ def main():
             if args.config == "toc3d_faster":
                 # BASELINE.json configs[0] exists only as a CPU row: ToC3D_fast (ratio 7/5/5) on the same synthetic frame and weights
                 res["cpu_baseline_configs0"] = cpu_baseline(configs.get("toc3d_fast"), sd_cpu, inp_cpu, "ToC3D_fast (ratio 7/5/5), BASELINE.json configs[0]")
+        # Top-level SCALAR copies of what a reader needs to hold this line against another box or another round (a driver that keeps only known
+        # top-level keys drops the nested dictionaries): the box's yardsticks, every side leg's frames/s and GEMM roofline fraction.
+        def hoist(key, node, *path):
+            for p_ in path:
+                node = node.get(p_) if isinstance(node, dict) else None
+            if isinstance(node, (int, float)):
+                res[key] = node
+        hoist("roofline_frac", res, "roofline", "frac")
+        hoist("calibration_gemm_yardstick_tflops", res, "calibration", "gemm_yardstick_tflops")
+        hoist("calibration_copy_gb_s", res, "calibration", "copy_gb_s")
+        hoist("calibration_sclk_mhz", res, "calibration", "sclk_mhz")
+        for leg in ("batched", "parity_path", "parity_path_fast", "parity_path_x6"):
+            hoist(f"{leg}_value", res, leg, "value")
+            hoist(f"{leg}_roofline_frac", res, leg, "roofline", "frac")
+        for oc, tag in zip(res.get("other_configs") or [], ("dense_eva_vit", "toc3d_faster_1600x640", "toc3d_faster_1600x800")):
+            hoist(f"{tag}_value", oc, "value")
+            hoist(f"{tag}_roofline_frac", oc, "roofline", "frac")
+        hoist("cpu_baseline_value", res, "cpu_baseline", "value")
+        hoist("cpu_baseline_cores", res, "cpu_baseline", "cores")
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -193,19 +193,19 @@ def gen_tiny_e2e():
     _save("tiny_neck", level0=_np(n0), level1=_np(n1))
 
 
-def gen_vitl(names=("toc3d_faster", "toc3d_fast", "eva_dense"), hw=(320, 800), prev=True):
+def gen_vitl(names=("toc3d_faster", "toc3d_fast", "eva_dense"), hw=(320, 800), prev=True, stress=False):
     """Full-size ViT-L fixtures, stored as every-16th-channel slices + per-view norms (SURVEY.md 8c 'F-L-e2e').
     Larger inputs (BASELINE.json config 4: 640x1600, and the reference's own hi-res 800x1600,
     projects/configs/ToC3D_1600_resolution/ToC3D_faster_1600.py:43,177) keep every 32nd channel and no block captures.
     ``stage{s}.score`` (the scorers' image-level log-probs) lets a test force the reference's token selection."""
-    cstep = 16 if hw == (320, 800) else 32
+    cstep = 16 if hw == (320, 800) and not stress else 32
     for name in names:
         cfg = configs.get(name)
         t0 = time.time()
-        sd = synth.make_state_dict(cfg)
-        inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw)
+        sd = synth.make_state_dict(cfg, stress=stress)    # stress: heavy-tailed channels / LayerNorm gains / large-norm tokens (toc3d_amd.synth.STRESS_CHANNELS)
+        inp = synth.make_inputs(cfg, views_per_frame=6, hw=hw, stress=stress)
         if synth.is_toc3d(cfg):
-            out, caps, _ = run_reference_toc3d(cfg, sd, inp, prev, capture_blocks=(5, 6, 11, 17) if (hw == (320, 800) and prev) else ())
+            out, caps, _ = run_reference_toc3d(cfg, sd, inp, prev, capture_blocks=(5, 6, 11, 17) if (hw == (320, 800) and prev and not stress) else ())
             feat = out.img_feats["last_feat"]
             arrs = {}
             for s in range(3):
@@ -225,7 +225,12 @@ def gen_vitl(names=("toc3d_faster", "toc3d_fast", "eva_dense"), hw=(320, 800), p
         arrs[f"last_feat.c{cstep}"] = _np(feat[:, ::cstep])
         arrs["last_feat.view_l2"] = _np(feat.flatten(1).double().norm(dim=1))
         arrs["last_feat.token_l2"] = _np(feat.double().norm(dim=1))
-        suffix = ("" if hw == (320, 800) else f"_{hw[1]}x{hw[0]}") + ("" if prev else "_first")
+        suffix = ("" if hw == (320, 800) else f"_{hw[1]}x{hw[0]}") + ("" if prev else "_first") + ("_stress" if stress else "")
+        if stress:                                        # what the planted pattern does to the activations (recorded next to the expected outputs)
+            tn = feat.double().norm(dim=1)
+            arrs["stress.out_channel_absmax"] = _np(feat.abs().amax(dim=(0, 2, 3)))
+            print(f"  stress statistics of the reference's output: channel abs-max median {float(feat.abs().amax(dim=(0, 2, 3)).median()):.2f} / max "
+                  f"{float(feat.abs().max()):.2f}; token norm median {float(tn.median()):.1f} / max {float(tn.max()):.1f}")
         _save(f"vitl_{name}{suffix}", **arrs)
         print(f"  {name}: reference forward + weights {time.time() - t0:.1f}s")
 
@@ -247,6 +252,8 @@ def main(argv):
         gen_vitl()
     if "vitl_first" in what:                              # first frame of a scene (prev_exists=False), full size
         gen_vitl(names=("toc3d_faster",), prev=False)
+    if "vitl_stress" in what:                             # realistic (heavy-tailed) activation statistics
+        gen_vitl(names=("toc3d_faster",), stress=True)
     if "vitl1600" in what:                                # BASELINE.json config 4 and the reference's own hi-res input
         gen_vitl(names=("toc3d_faster",), hw=(640, 1600))
         gen_vitl(names=("toc3d_faster",), hw=(800, 1600))

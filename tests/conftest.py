@@ -39,12 +39,12 @@ def _memoized_synthetic_weights():
     from toc3d_amd import synth
     real, cache = synth.make_state_dict, OrderedDict()
 
-    def cached(cfg, seed=0, device="cpu"):
-        key = (json.dumps(cfg, sort_keys=True, default=str), int(seed), str(device))
+    def cached(cfg, seed=0, device="cpu", stress=False):
+        key = (json.dumps(cfg, sort_keys=True, default=str), int(seed), str(device), bool(stress))
         if key in cache:
             cache.move_to_end(key)
         else:
-            cache[key] = real(cfg, seed=seed, device=device)
+            cache[key] = real(cfg, seed=seed, device=device, stress=stress)
             while len(cache) > 4:
                 cache.popitem(last=False)
         return type(cache[key])(cache[key])

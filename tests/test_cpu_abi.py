@@ -376,3 +376,20 @@ def test_unchanged_reference_config_builds_the_parity_grade_precision():
         assert toc3d_amd.build_backbone(configs.get(name)).precision == "fp32x3"
         assert toc3d_amd.build_backbone(dict(configs.get(name), precision="bf16")).precision == "bf16"
     assert toc3d_amd.build_neck(configs.CPFPN_TINY).precision == "fp32x3"
+
+
+def test_splitk_workspace_is_sized_from_the_launched_tile_shape():
+    """toc3d_linear_splitk_workspace_bytes inferred (BM, BN) from BM * BN, which cannot tell variant 9's 128x64 tile from the 64x128 tile of
+    variants 10 / 26 -- the host then counted too few tiles when N % 128 is in 1..64 and accepted a workspace the kernel writes past.  The size now comes from the launch
+    table's own tile shape (csrc/gemm_kernels.h, sk_tile_dims): checked here for every split-K tile variant on shapes with ragged N, without a GPU (a host function)."""
+    L = lib.load()
+    dims = {1: (128, 128), 9: (128, 64), 10: (64, 128), 14: (64, 64), 16: (128, 128), 17: (128, 128), 19: (256, 128), 22: (128, 128), 26: (64, 128), 28: (128, 128),
+            29: (128, 128), 55: (96, 128), 56: (96, 128)}
+    for v, (bm, bn) in dims.items():
+        for split in (2, 3, 4):
+            for M, N in ((128, 192), (128, 64), (300, 1024), (6000, 1024), (97, 130)):
+                tiles = -(-M // bm) * -(-N // bn)
+                want = 65536 + tiles * split * bm * bn * 4
+                got = L.toc3d_linear_splitk_workspace_bytes(1000 * split + v, M, N)
+                assert got == want, (v, split, M, N, got, want)
+    assert L.toc3d_linear_splitk_workspace_bytes(2060, 128, 128) < 0 and L.toc3d_linear_splitk_workspace_bytes(16, 128, 128) < 0      # no split-K form / not a split variant

@@ -45,10 +45,10 @@ def iou(a, b):
     return min(res)
 
 
-def build(name, precision):
+def build(name, precision, stress=False):
     cfg = configs.get(name)
     m = toc3d_amd.build_backbone(dict(cfg, precision=precision))
-    m.load_state_dict(synth.make_state_dict(cfg), strict=True)
+    m.load_state_dict(synth.make_state_dict(cfg, stress=stress), strict=True)
     m = m.to(DEV).eval()
     m.autotune = False                    # every tile variant accumulates in the same order: the choice cannot change a bit
     if synth.is_toc3d(cfg):
@@ -67,12 +67,13 @@ def run_hip(m, inp, prev=True, forced=None):
 _SD_DEV = {}
 
 
-def oracle_on_gpu(name, cfg, inp, mode, prev=True, forced=None, capture=None):
+def oracle_on_gpu(name, cfg, inp, mode, prev=True, forced=None, capture=None, stress=False):
     """The oracle's code on the GPU: fp32 (checker) or with torch-bf16 contractions (control)."""
-    if name not in _SD_DEV:
+    key = name + ("/stress" if stress else "")
+    if key not in _SD_DEV:
         _SD_DEV.clear()                   # one ViT-L state dict (1.2 GB) on the device at a time
-        _SD_DEV[name] = {k: v.to(DEV) for k, v in synth.make_state_dict(cfg).items()}
-    sd = _SD_DEV[name]
+        _SD_DEV[key] = {k: v.to(DEV) for k, v in synth.make_state_dict(cfg, stress=stress).items()}
+    sd = _SD_DEV[key]
     a = [inp[k].to(DEV) for k in ARGS]
     with torch.no_grad(), O.contractions(mode):
         return O.forward_toc3d(sd, cfg, *a, prev, [g.to(DEV) for g in inp["gumbel"]], capture=capture,
@@ -143,6 +144,45 @@ def test_vitl_bf16_free_running_within_control(golden_dir, fixture, name, hw, pr
     assert min(i_hip) >= min(i_ctl) - 0.06 and i_hip[0] > 0.98
 
 
+def test_vitl_stress_fixture_heavy_tailed_activations(golden_dir):
+    """VERDICT r05 item 7 / "missing 1": every other fixture draws N(0, sigma^2) weights, whose activations have no outliers; trained ViTs do (a handful of residual-stream
+    channels tens of times wider than the rest, LayerNorm gains that single them out, large-norm tokens).  `vitl_toc3d_faster_stress.npz` is the REAL reference's fp32 output
+    (oracle/gen_golden.py vitl_stress) on weights and inputs with that pattern planted (toc3d_amd.synth.STRESS_CHANNELS: output channel abs-max 1530 against a median of 147).
+    Reported and bounded on it: the exact-f32 path, the parity-grade default (fp32x3), and bf16 -- forced selection and free running, next to the torch-bf16 control."""
+    name = "toc3d_faster"
+    g = np.load(os.path.join(golden_dir, "vitl_toc3d_faster_stress.npz"))
+    ref, step = golden_feat(g)
+    forced = forced_from_golden(g)
+    cfg = configs.get(name)
+    inp = synth.make_inputs(cfg, views_per_frame=6, stress=True)
+    rows = {}
+    for precision in ("fp32", "fp32x3", "bf16"):
+        _, m = build(name, precision, stress=True)
+        out = run_hip(m, inp, True)
+        feat = out.img_feats["last_feat"]
+        assert torch.isfinite(feat).all()
+        rows[precision] = dict(free_max=rel_max(feat[:, ::step], ref), free_l2=rel_l2(feat[:, ::step], ref), iou=[iou(out.keep_idx[s], g[f"keep_idx{s}"]) for s in range(3)])
+        fo = run_hip(m, inp, True, forced).img_feats["last_feat"]
+        rows[precision].update(forced_max=rel_max(fo[:, ::step], ref), forced_l2=rel_l2(fo[:, ::step], ref))
+        del m
+        torch.cuda.empty_cache()
+    cf = oracle_on_gpu(name, cfg, inp, "bf16", True, forced, stress=True)["last_feat"]
+    cr = oracle_on_gpu(name, cfg, inp, "bf16", True, stress=True)
+    ctl = dict(forced_l2=rel_l2(cf[:, ::step], ref), forced_max=rel_max(cf[:, ::step], ref), free_l2=rel_l2(cr["last_feat"][:, ::step], ref),
+               iou=[iou(cr["keep_idx"][s], g[f"keep_idx{s}"]) for s in range(3)])
+    for k, v in list(rows.items()) + [("torch-bf16 control", ctl)]:
+        print(f"[stress fixture {k}] " + "  ".join(f"{a} {b:.3e}" if not isinstance(b, list) else f"{a} {np.round(b, 4).tolist()}" for a, b in v.items()))
+    # the f32-buffer paths: the same 1e-3 bar as on the benign fixtures (north_star), selection identical to the reference's
+    for precision in ("fp32", "fp32x3"):
+        r = rows[precision]
+        assert r["forced_max"] < 1e-3, (precision, r)
+        assert min(r["iou"]) > 0.99 and r["free_max"] < (1e-3 if min(r["iou"]) == 1.0 else 0.3), (precision, r)
+    # bf16: arithmetic error with the selection forced within 1.2x the torch-bf16 control, free running inside the control's band
+    b = rows["bf16"]
+    assert b["forced_l2"] <= 1.2 * ctl["forced_l2"] + 1e-3, (b, ctl)
+    assert b["free_l2"] <= 1.2 * ctl["free_l2"] + 5e-3 and min(b["iou"]) >= min(ctl["iou"]) - 0.06, (b, ctl)
+
+
 @pytest.mark.parametrize("name", ["toc3d_faster", "toc3d_fast"])
 def test_vitl_bf16_per_block_error_budget(golden_dir, name):
     """Residual stream after every block, forced selection: HIP bf16 vs the fp32 oracle, block by block, next to the control."""
@@ -175,6 +215,15 @@ def test_vitl_bf16_per_block_error_budget(golden_dir, name):
     assert all(b[1] <= 1.6 * a[1] + 1e-3 for a, b in zip(rows, rows[1:])), "error must grow smoothly along the depth (no broken block)"
 
 
+def window_scores(score, h, w, L):
+    """image-level scores [V, h*w] -> [windows, L*L] with the reference's pad value (toc3d_eva_vit.py:412-415, eva_utils.py:89-110)."""
+    V = score.shape[0]
+    s = score.reshape(V, h, w)
+    ph, pw = (L - h % L) % L, (L - w % L) % L
+    s = torch.nn.functional.pad(s, (0, pw, 0, ph), value=-1e6)
+    return s.reshape(V, (h + ph) // L, L, (w + pw) // L, L).permute(0, 1, 3, 2, 4).reshape(-1, L * L)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x6"])
 @pytest.mark.parametrize("fixture,hw", [("vitl_toc3d_faster_1600x640", (640, 1600)), ("vitl_toc3d_faster_1600x800", (800, 1600))])
 def test_vitl_1600_fp32_matches_reference(golden_dir, fixture, hw, precision):
@@ -201,6 +250,33 @@ def test_vitl_1600_fp32_matches_reference(golden_dir, fixture, hw, precision):
     tl2 = (feat.double().norm(dim=1).cpu() - torch.from_numpy(g["last_feat.token_l2"])).abs().max().item() / g["last_feat.token_l2"].max()
     bad = ((feat[:, ::step].cpu() - ref).abs().amax(dim=1) > 1e-3 * ref.abs().max()).float().mean().item()
     print(f"[{fixture} {precision}] rel max err {err:.3e} token-norm err {tl2:.3e}  kept-set IoU {[round(v, 5) for v in ious]}  tokens off by > 1e-3: {100 * bad:.4f} %")
+    # Round 6: the f64 run of the REAL reference on the same inputs (oracle/gen_golden_f64.py) as the arbiter of every per-window selection.  What it established: the
+    # smallest kept/dropped gap of a window score is 1e-6 .. 7e-6 at these inputs (near_ties), the reference's own fp32 CPU forward stands 3e-6 from its f64 run and
+    # happens to make every window's f64 selection.  Here: a window whose kept set differs from the f64 run's must be a near-tie -- its f64 gap below twice the error
+    # of OUR image-level scores against the f64 scores -- and there are at most two such windows per (stage, window side).  A flip anywhere else fails.
+    a64 = np.load(os.path.join(golden_dir, fixture + "_f64.npz"))
+    plan = next(iter(m._plans.values()))
+    hh, ww = hw[0] // 16, hw[1] // 16
+    flipped = []
+    for s in range(3):
+        ours = plan["score"][s].view(6, -1).cpu().double()
+        ref64 = torch.from_numpy(a64[f"stage{s}.score"])
+        serr = (ours - ref64).abs().max().item()
+        for L in (16, 20):
+            k = int(L * L * cfg["token_ratio"][s])
+            wo, w6 = window_scores(ours, hh, ww, L), window_scores(ref64, hh, ww, L)
+            ko = torch.sort(wo, dim=1, descending=True, stable=True)[1][:, :k].sort(dim=1)[0]
+            o6 = torch.sort(w6, dim=1, descending=True, stable=True)
+            k6 = o6[1][:, :k].sort(dim=1)[0]
+            diff = (ko != k6).any(dim=1).nonzero().flatten().tolist()
+            for wi in diff:
+                gap = (o6[0][wi, k - 1] - o6[0][wi, k]).item()
+                flipped.append((s, L, wi, gap, serr))
+                assert gap < 2 * serr + 1e-12, f"stage {s} side {L} window {wi}: kept set differs from the f64 reference's at a gap of {gap:.2e}, score error {serr:.2e}"
+            assert len(diff) <= 2, (s, L, diff)
+    print(f"[{fixture} {precision}] windows whose kept set differs from the f64 reference's (stage, side, window, f64 gap, our score error): {flipped}")
+    if precision == "fp32":
+        assert not flipped
     if one_flip:
         # This input (30 000 tokens) holds a per-window top-k near-tie below 1e-6: the exact-f32 kernels happen to break it the way the reference's
         # CPU summation order does, the bf16 x 3 (3e-5) and even the f32-grade bf16 x 6 (6e-6 everywhere else) forms break it the other way --

@@ -345,9 +345,9 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
 static_assert(TOC3D_SPLITK_TICKET_BYTES % 256 == 0, "the partial tiles start on a 256-byte boundary");
 int64_t toc3d_linear_splitk_workspace_bytes(int variant, int64_t M, int64_t N) {
     const int split = variant / 1000;
-    const int64_t elems = toc3d_gemm_splitk_tile_elems(variant % 1000);
-    if (split < 2 || split > TOC3D_SPLITK_MAX || elems == 0 || M < 0 || N <= 0) return -1;
-    const int64_t bn = elems == 128 * 64 ? 64 : (elems == 64 * 64 ? 64 : 128), bm = elems / bn;
+    const int dims = toc3d_gemm_splitk_tile_dims(variant % 1000);      // the launch table's own tile shape (the element count alone cannot tell 128x64 from 64x128)
+    if (split < 2 || split > TOC3D_SPLITK_MAX || dims == 0 || M < 0 || N <= 0) return -1;
+    const int64_t bm = dims >> 16, bn = dims & 0xffff, elems = bm * bn;
     const int64_t tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     if (tiles * 4 > TOC3D_SPLITK_TICKET_BYTES) return -1;
     return TOC3D_SPLITK_TICKET_BYTES + tiles * split * elems * 4;

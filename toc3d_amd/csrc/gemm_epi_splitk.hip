@@ -2,7 +2,7 @@
 // toc3d_eva_vit.py:384): instantiations of gemm_kernels.h with SK = 1 on a few tile variants (own translation unit so that the groups build in parallel).
 #include "gemm_kernels.h"
 
-int64_t toc3d_gemm_splitk_tile_elems(int variant) { return sk_tile_elems(variant); }
+int toc3d_gemm_splitk_tile_dims(int variant) { return sk_tile_dims(variant); }
 
 template <int EPI>
 static int launch_one(int dtype, int variant, const GemmArgs& a, hipStream_t s) {

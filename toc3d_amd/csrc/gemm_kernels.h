@@ -66,7 +66,7 @@ int toc3d_gemm_launch_lnself(int epi, int variant, const GemmArgs& a, hipStream_
 int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 3 products on f32 operands: epilogues 0-9
 int toc3d_gemm_launch_x6(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 6 (three-way split): f32-grade products
 int toc3d_gemm_launch_splitk(int dtype, int epi, int variant, const GemmArgs& a, hipStream_t s);       // residual epilogues with a.split > 1 (gemm_epi_splitk.hip); dtype: TOC3D_BF16 / TOC3D_F32 / TOC3D_F32X3
-int64_t toc3d_gemm_splitk_tile_elems(int variant);                                                      // BM * BN of a split-K tile variant (0: the variant has no split-K form)
+int toc3d_gemm_splitk_tile_dims(int variant);                                                           // BM << 16 | BN of a split-K tile variant (0: the variant has no split-K form)
 
 // ---- GEMM chains (gemm_chain.hip; include/toc3d.h, toc3d_linear_chain): several dependent GEMMs of one block half in ONE persistent launch ----
 constexpr int TOC3D_CHAIN_MAX_OPS = 3;
@@ -1614,12 +1614,18 @@ void launch_cfg_sk(const GemmArgs& a, hipStream_t s) {
     toc3d_launch((gemm_kernel<T, EPI, BM, BN, STAGES, RB, WM, WN, OCC, X3, 1>), dim3(tm * tn * a.split), dim3(64 * WM * WN), lds, s, a);
 }
 // tile variants that have a split-K form (variant mod 1000 of toc3d_linear_fused_ws; variant / 1000 = the split): BM * BN, or 0
-constexpr int64_t sk_tile_elems(int v) {
-    return (v == 16 || v == 17 || v == 28 || v == 29 || v == 1 || v == 22) ? 128 * 128 : (v == 55 || v == 56) ? 96 * 128 : v == 19 ? 256 * 128 : (v == 10 || v == 26) ? 64 * 128 : v == 9 ? 128 * 64 : v == 14 ? 64 * 64 : 0;
+// (BM << 16 | BN, the shape launch_epi_sk below instantiates -- the host sizes the workspace from the SAME table: variants 9 (128x64) and 10 / 26 (64x128) have equal
+// element counts and different tile grids)
+constexpr int sk_tile_dims(int v) {
+    return (v == 16 || v == 17 || v == 28 || v == 29 || v == 1 || v == 22) ? (128 << 16 | 128) : (v == 55 || v == 56) ? (96 << 16 | 128) : v == 19 ? (256 << 16 | 128)
+           : (v == 10 || v == 26) ? (64 << 16 | 128) : v == 9 ? (128 << 16 | 64) : v == 14 ? (64 << 16 | 64) : 0;
 }
+constexpr int64_t sk_tile_elems(int v) { return (int64_t)(sk_tile_dims(v) >> 16) * (sk_tile_dims(v) & 0xffff); }
 template <typename T, int EPI, int X3 = 0>
 int launch_epi_sk(int variant, const GemmArgs& a, hipStream_t s) {
     constexpr bool B = sizeof(T) == 2;
+    static_assert(sk_tile_dims(9) == (128 << 16 | 64) && sk_tile_dims(10) == (64 << 16 | 128) && sk_tile_dims(26) == (64 << 16 | 128) && sk_tile_dims(19) == (256 << 16 | 128) &&
+                  sk_tile_dims(55) == (96 << 16 | 128) && sk_tile_dims(14) == (64 << 16 | 64) && sk_tile_dims(22) == (128 << 16 | 128), "sk_tile_dims must name the tiles instantiated below");
     switch (variant) {
         case 1: launch_cfg_sk<T, EPI, 128, 128, 2, 128, 2, 2, 1, X3>(a, s); break;
         case 9: launch_cfg_sk<T, EPI, 128, 64, 2, 128, 2, 2, 1, X3>(a, s); break;

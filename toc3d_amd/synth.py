@@ -162,7 +162,30 @@ def _draw(name: str, shape, seed: int) -> np.ndarray:
     return w.astype(np.float32)
 
 
-def make_state_dict(cfg, seed: int = 0, device="cpu") -> "OrderedDict[str, torch.Tensor]":
+# Stress statistics: trained ViTs carry "massive activations" -- a handful of residual-stream channels tens of times wider than the rest, LayerNorm
+# gains that single channels out, a few tokens of very large norm -- which N(0, sigma^2) weights never produce.  stress=True plants that pattern into the same seeded
+# draw: six outlier channels whose norm1 gain is x30 in every block (norm2: the first three), whose attention-projection rows are x40 in blocks 1-2 and whose w3 rows are
+# x40 in blocks 2-3 (they write into the residual stream); make_inputs(stress=True) scales four patches per view by 8 (token norms ~1.6e2 against ~2e1).
+STRESS_CHANNELS = (5, 64, 337, 512, 771, 960)
+
+
+def _stress(sd, cfg):
+    C = cfg["embed_dim"]
+    oc = torch.tensor([c % C for c in STRESS_CHANNELS])
+    for i in range(cfg["depth"]):
+        sd[f"blocks.{i}.norm1.weight"][oc] *= 30.0
+        sd[f"blocks.{i}.norm2.weight"][oc[:3]] *= 30.0
+        if i in (1, 2):
+            sd[f"blocks.{i}.attn.proj.weight"][oc] *= 40.0
+        if i in (2, 3):
+            sd[f"blocks.{i}.mlp.w3.weight"][oc] *= 40.0
+    return sd
+
+
+def make_state_dict(cfg, seed: int = 0, device="cpu", stress: bool = False) -> "OrderedDict[str, torch.Tensor]":
+    if stress:
+        sd = _stress(make_state_dict(cfg, seed, "cpu"), cfg)
+        return OrderedDict((k, v.to(device)) for k, v in sd.items())
     spec = state_dict_spec(cfg)
     hd = cfg["embed_dim"] // cfg["num_heads"]
     p = cfg.get("patch_size", 16)
@@ -194,7 +217,7 @@ def neck_state_dict(cfg, seed: int = 0, device="cpu"):
 
 
 def make_inputs(cfg, n_frames: int = 1, views_per_frame: int = 6, hw=(320, 800), seed: int = 0,
-                epoch_timestamps: bool = False, device="cpu"):
+                epoch_timestamps: bool = False, device="cpu", stress: bool = False):
     """Synthetic backbone inputs in the shapes ``Petr3D.extract_img_feat`` passes (``petr3d.py:145-157``).
 
     Returns a dict: x (B*Nv,3,H,W) f32 ~ N(0,1) (post-normalisation statistics); temp_queries (B,Q,256);
@@ -210,6 +233,12 @@ def make_inputs(cfg, n_frames: int = 1, views_per_frame: int = 6, hw=(320, 800),
     tag = f"in/{B}/{views_per_frame}/{H}x{W}/"
     out = {}
     out["x"] = torch.from_numpy(_rng(tag + "x", seed).standard_normal((V, 3, H, W), dtype=np.float32))
+    if stress:                                            # four large-norm tokens per view (STRESS_CHANNELS above)
+        gp = _rng(tag + "stress", seed)
+        for v in range(V):
+            for _ in range(4):
+                r, c = int(gp.integers(0, H // p)), int(gp.integers(0, W // p))
+                out["x"][v, :, r * p:(r + 1) * p, c * p:(c + 1) * p] *= 8.0
     out["temp_queries"] = torch.from_numpy(_rng(tag + "q", seed).standard_normal((B, Q, QUERY_DIM), dtype=np.float32))
     pc = np.asarray(cfg.get("pc_range", [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]), dtype=np.float32)
     u = _rng(tag + "ref", seed).random((B, Q, 3), dtype=np.float32)
