@@ -20,8 +20,6 @@
  *   - "act" buffers are row-major [rows, ld] of `dtype`; K-like dims are padded to multiples of 64
  *     elements with zeros (e.g. the SwiGLU hidden 2730 -> 2752).
  *   - the dlopen() of this library creates no HIP context (safe before fork()).
- *   - declarations inside `#ifdef TOC3D_EXPERIMENTAL` exist only in libraries built with `make EXPERIMENTAL=1` (measured experiments of earlier
- *     rounds that lost, kept with their parity tests; off the product path and out of the default libtoc3d_gfx950.so).
  */
 #ifndef TOC3D_H_
 #define TOC3D_H_
@@ -78,12 +76,6 @@ extern "C" {
 #define TOC3D_EPI_RESIDUAL_STATS 6    /* RESIDUAL + act-dtype copy of the output rows + their per-row statistics (toc3d_linear_fused) */
 #define TOC3D_EPI_SWIGLU_STATS_LN 7   /* SWIGLU_STATS with a LayerNorm of the A rows folded into the epilogue   (toc3d_linear_fused) */
 #define TOC3D_EPI_CONV3X3 8           /* out(f32) = conv3x3(NHWC act tensor) + bias as an implicit GEMM          (toc3d_conv3x3_nhwc) */
-/* epilogues 10-13: round-3 experiment (LayerNorm statistics taken by the consuming GEMM's own K loop; measured slower) -- served only
- * by libraries built with `make EXPERIMENTAL=1`; the default library answers TOC3D_ERR_ARG */
-#define TOC3D_EPI_RESIDUAL_ACT 10         /* RESIDUAL + act-dtype copy of the output rows (no statistics)                 (toc3d_linear_fused) */
-#define TOC3D_EPI_SWIGLU_LNSELF 11        /* SWIGLU of LayerNorm(A rows), the row statistics taken by this GEMM's own K loop (toc3d_linear_fused) */
-#define TOC3D_EPI_RESIDUAL_LNSELF 12      /* RESIDUAL of LayerNorm(A rows) the same way (+ optional act-dtype copy)          (toc3d_linear_fused) */
-#define TOC3D_EPI_QKV_ROPE_LNSELF 13      /* QKV_ROPE of LayerNorm(A rows) the same way                                      (toc3d_linear_qkv_rope_ln) */
 #define TOC3D_EPI_QKV_ROPE 9          /* out(act) = [rope(q) * scale | rope(k) | v] of the fused q|k|v projection  (toc3d_linear_qkv_rope) */
 
 typedef void* toc3d_stream_t;
@@ -150,12 +142,6 @@ int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t
  *                          columns (N-tiles must be multiples of 64); stats_out_cap >= ceil(N / 64).
  *   EPI_SWIGLU_STATS_LN  = EPI_SWIGLU_STATS on A = out_act with W = gamma-scaled interleaved weights, bias = c2, col_sums = c1 in packed column
  *                          order (toc3d_pack_swiglu_lnfold); reads stats_in, writes stats_out (different buffers).
- *   EPI_RESIDUAL_ACT     = EPI_RESIDUAL + out_act [M, ld_act] (the act-dtype copy only, no statistics).
- *   EPI_SWIGLU_LNSELF / EPI_RESIDUAL_LNSELF = the LayerNorm-folding forms above (same W, bias = c2, col_sums = c1, ln_n, ln_eps) WITHOUT a
- *                          statistics hand-off: K spans the whole normalised row (norm2 in front of w1|w2: K = C; ffn_ln in front of w3: K = padded
- *                          hidden width, pad columns zero), so the kernel takes (sum, sum of squares) of every A row from the operand fragments its
- *                          MFMAs consume -- stats_in / stats_out are not used, no LayerNorm launch and no statistics buffer anywhere.  Per row the
- *                          sums are formed in one fixed order for every tile variant.  EPI_RESIDUAL_LNSELF also writes out_act when it is non-NULL.
  * stats_out / stats_in: int32 header [4] + f32 [M, cap, 2] each; stats_in_cap may carry the number of slots per row the producer wrote in its
  * upper 32 bits (cap | slots << 32) when the host knows it, which saves the consumer the dependent read of the header; ln_n = width of the normalised rows (valid hidden units for EPI_RESIDUAL_LN,
  * K for EPI_SWIGLU_STATS_LN).  residual_index (int32 [M] or NULL, residual epilogues): output row m takes its residual from row
@@ -191,37 +177,6 @@ int toc3d_linear_fused_ws(int dtype, int epilogue, int variant, const void* A, i
                           const float* col_sums, int64_t ln_n, float ln_eps, void* out_act, int64_t ld_act, const int32_t* residual_index,
                           void* workspace, int64_t workspace_bytes, toc3d_stream_t stream);
 
-#ifdef TOC3D_EXPERIMENTAL   /* round-3 experiment, measured 1.3-2x slower than the separate launches: only in `make EXPERIMENTAL=1` builds */
-/* Several dependent linear layers of one transformer-block half in ONE persistent launch (bf16): attn.proj + residual -> [norm2] -> mlp.w1 | mlp.w2
- * -> [ffn_ln] -> mlp.w3 + residual (eva_vit.py:44-51,115,262-263; toc3d_eva_vit.py:366-386), the LayerNorms folded as in toc3d_linear_fused.
- * Each op is one toc3d_linear_fused call (same argument meaning; variant, residual_row_mod are not taken); op i reads rows that op i - 1 wrote
- * (A operand, residual, statistics), all ops have the same M.  Results are bit-identical to the same ops issued as separate toc3d_linear_fused
- * launches in order.  `config` = 10 * family + tiling: family 0 = {EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_RESIDUAL_LN}, family 1 =
- * {EPI_SWIGLU_STATS, EPI_RESIDUAL_LN}; toc3d_linear_chain_info returns the number of ops and fills info[4 * op + {0, 1, 2, 3}] = epilogue, tile rows,
- * tile columns, threads (< 0: unknown config).  `schedule` (device int32): [2 * n_bands] = (index of the band's first entry, entries) per band, then
- * the entries op << 28 | M-tile << 16 | N-tile -- every tile of every op exactly once, a tile's producers (the N-tiles of op - 1 that cover its rows)
- * earlier in the SAME band; n_bands <= 64, M-tiles per op <= 256.  A band is processed by the workgroups of one XCD (whichever claims it), tiles are
- * handed from op to op through that XCD's L2; flags & 1 adds an agent-scope release before every hand-off.  `state`: TOC3D_CHAIN_STATE_BYTES of
- * device memory, zeroed by the caller once (the launch re-arms it); one buffer per stream that may run a chain; word 1 is a sticky error code
- * (1: a bounded wait gave up, 2: bad schedule entry).  grid = workgroups of 512 threads (about 2-3 per CU). */
-#define TOC3D_CHAIN_STATE_BYTES 3616
-typedef struct toc3d_chain_op {
-    int64_t epilogue;
-    const void* A; int64_t lda; const void* W; int64_t ldw; const float* bias;
-    void* out; int64_t ldo; const float* residual; int64_t ldr;
-    float* rep_out; const int32_t* rep_index;
-    int64_t M, N, K, n_valid;
-    float* stats_out; int64_t stats_out_cap; const float* stats_in; int64_t stats_in_cap; const float* col_sums; int64_t ln_n; double ln_eps;
-    void* out_act; int64_t ld_act; const int32_t* residual_index;
-} toc3d_chain_op_t;
-int toc3d_linear_chain(int dtype, int config, int64_t n_ops, const toc3d_chain_op_t* ops, const int32_t* schedule, int64_t n_bands, void* state,
-                       int64_t grid, int64_t flags, toc3d_stream_t stream);
-int toc3d_linear_chain_info(int config, int32_t* info);
-/* Development instrumentation: chains launched afterwards (by any thread) leave per-tile time stamps in `buf` (device, zeroed by the caller):
- * uint64 [0] = tiles recorded, then per tile 8 words: XCC+1 << 56 | workgroup << 32 | schedule entry; the 100 MHz real-time counter before the
- * dequeue, after it, after the dependency wait, after the tile, after the publish; HW_ID; 0.  (NULL, 0) switches it off (the default). */
-int toc3d_linear_chain_trace(void* buf, int64_t entries);
-#endif /* TOC3D_EXPERIMENTAL */
 /* mlp.w1 / mlp.w2 interleaved as toc3d_pack_swiglu, scaled by norm2's gamma per input channel; c1 [2*Hp] = row sums of the ROUNDED scaled
  * weights, c2 [2*Hp] = beta . w + b, both in packed row order. */
 int toc3d_pack_swiglu_lnfold(int dtype, const float* w1, const float* w2, const float* b1, const float* b2, const float* gamma, const float* beta,
@@ -373,14 +328,6 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
 int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
                           int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
                           float q_scale, toc3d_stream_t stream);
-#ifdef TOC3D_EXPERIMENTAL
-/* The same with norm1 folded in (EPI_QKV_ROPE_LNSELF; eva_vit.py:258-262): A = the act-dtype copy of the residual-stream rows (left by the previous
- * block's w3 GEMM, EPI_RESIDUAL_LNSELF out_act), W = gamma1-scaled q|k|v weights, bias = c2 = W.beta1 + b, col_sums = c1 = row sums of the rounded
- * scaled W (toc3d_pack_weight_lnfold), ln_n = C; the row statistics come from the kernel's own K loop (K = C spans the row). */
-int toc3d_linear_qkv_rope_ln(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
-                             int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
-                             float q_scale, const float* col_sums, int64_t ln_n, float ln_eps, toc3d_stream_t stream);
-#endif /* TOC3D_EXPERIMENTAL */
 int toc3d_window_attention_rot(int dtype, const void* qkv, int64_t ldqkv, void* out, int64_t ldo, const int32_t* rows, const int32_t* slots,
                                const int32_t* count, const int32_t* count_k, const int32_t* npad, const void* pad_rot, int64_t stride,
                                int64_t nwin, int64_t max_count, int64_t num_heads, const float* v_bias,
@@ -425,20 +372,6 @@ int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int3
 int toc3d_rebase_layernorm_rows(int dtype, float* slow, int64_t C, const int32_t* rep_index, const int32_t* tok, const float* wgt, int64_t N,
                                 int64_t k, const float* rep_raw1, const float* rep_raw2, const float* gamma, const float* beta, float eps,
                                 void* out, int64_t ldo, int64_t rows, toc3d_stream_t stream);
-#ifdef TOC3D_EXPERIMENTAL   /* round-3 experiment, bit-identical and 3 % slower */
-/* toc3d_gather_merge_ln_ex with the PREVIOUS block's toc3d_scatter_update folded in (blocks 7 -> 8, 8 -> 9, ...: the window type changes, so the next
- * block gathers a different token set right after the scatter): x is not scattered first; a token's current value is prev_slow[prev_inverse[token]]
- * (kept by the previous selection) or x[token] + rep_raw1[w] + rep_raw2[w] (+ rep_raw3[w] + rep_raw4[w]) with w = -1 - prev_inverse[token] (dropped),
- * exactly what the scatter would have written (toc3d_eva_vit.py:452-456, same order of additions); the wave that gathers a token also writes that value
- * back to x, so after the launch x is what scatter + gather would have left.  Every real token is gathered exactly once (kept -> copied, dropped -> merged).
- * prev_slow and shortcut must be different buffers.  toc3d_token_inverse_map builds prev_inverse [V * T] from a selection's tok / prow lists. */
-int toc3d_gather_merge_ln_pending(int dtype, float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
-                                  const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
-                                  const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy,
-                                  const int32_t* prev_inverse, const float* prev_slow, const float* rep_raw1, const float* rep_raw2,
-                                  const float* rep_raw3, const float* rep_raw4, toc3d_stream_t stream);
-int toc3d_token_inverse_map(const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k, int32_t* inverse, toc3d_stream_t stream);
-#endif /* TOC3D_EXPERIMENTAL */
 int toc3d_scatter_update(float* x, int64_t C, const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k,
                          const float* slow_out, const float* rep_raw1, const float* rep_raw2, const float* rep_raw3, const float* rep_raw4,
                          toc3d_stream_t stream);
@@ -562,13 +495,6 @@ int toc3d_se_gate(const float* pos, const float* se, float* out, int64_t n, toc3
 
 /* Plain device-to-device copy as a kernel (recordable into a launch plan, unlike hipMemcpyAsync). */
 int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t stream);
-#ifdef TOC3D_EXPERIMENTAL   /* round-2 experiment (a prefetch launch of its own loses; the prefetch riding on the attention launches is the product form) */
-/* Read n <= 8 buffers (HOST arrays ptrs / nbytes of n entries; device pointers 16-byte aligned, read-only for the duration) with `workgroups`
- * workgroups per buffer (0 = 16) and discard the values: a software prefetch of the NEXT block's packed weights into the Infinity Cache,
- * issued on a side stream / plan lane beside the current block (the 0.6 GB of bf16 weights cycle through a 256 MB cache once per frame, so
- * every GEMM otherwise starts on HBM misses).  No output. */
-int toc3d_prefetch(int64_t n, const void* const* ptrs, const int64_t* nbytes, int64_t workgroups, toc3d_stream_t stream);
-#endif /* TOC3D_EXPERIMENTAL */
 /* Up to 16 small device-to-device copies in ONE launch (every launch costs ~5 us of device time, and a frame has nine per-frame input
  * tensors to stage: temp_queries ... ego_pose_inv of detectors/petr3d.py:115-134 plus the three Gumbel tensors).  dst / src / nbytes are
  * HOST arrays of n entries (read during the call); device pointers need no alignment (16-byte body when both are aligned). */

@@ -15,8 +15,8 @@ from toc3d_amd import configs, lib
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(lib.LIB_PATH), "build first: make -C toc3d_amd/csrc"
     dll = ctypes.CDLL(lib.LIB_PATH)
-    names = lib.header_functions()                 # the declarations of THIS build flavour (#ifdef TOC3D_EXPERIMENTAL blocks only for EXPERIMENTAL=1 libraries)
-    assert len(names) >= 50 and set(lib.header_functions(True)) - set(lib.header_functions(False)) == set(lib._SIGS_EXPERIMENTAL) | {"toc3d_linear_chain_info"}
+    names = lib.header_functions()
+    assert len(names) >= 50
     for n in names:
         assert hasattr(dll, n), f"{n} declared in include/toc3d.h but not exported"
     l = lib.load()
@@ -26,8 +26,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_ctypes_signatures_match_header():
-    txt = lib.header_text(True)                    # every declaration, the experimental ones included: their ctypes signatures are checked too
-    sigs = dict(lib._SIGS, **lib._SIGS_EXPERIMENTAL)
+    txt = lib.header_text()
+    sigs = dict(lib._SIGS)
     seen = 0
     for m in re.finditer(r"\bint\s+(toc3d_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
         name, args = m.group(1), m.group(2)
@@ -277,51 +277,6 @@ def test_launch_schedule_switches_are_attributes_not_environment():
             src = open(os.path.join(pkg, fn)).read()
             reads = set(re.findall(r"environ[^\n]*?[\"'](TOC3D_\w+)[\"']", src))
             assert reads <= ({"TOC3D_LIB"} if fn == "lib.py" else set()), (fn, reads)
-
-
-@pytest.mark.skipif(not lib.experimental(), reason="GEMM chains exist only in `make EXPERIMENTAL=1` builds (TOC3D_LIB=libtoc3d_gfx950_exp.so)")
-def test_chain_schedule_host_logic():
-    """toc3d_linear_chain's tile lists (toc3d_amd/lib.py chain_schedule) without a GPU: every tile of every op exactly once, and every tile behind
-    ALL the tiles it reads (the N-tiles of the previous op that cover its rows) inside its own band -- for every config, ragged M, band counts, lags
-    and the N-major order."""
-    for config in (0, 1, 2, 10, 11, 12):
-        info = lib.chain_info(config)
-        assert info is not None and len(info) in (2, 3) and all(t[3] == 512 for t in info)
-        Ns = [1024, 5504, 1024] if len(info) == 3 else [5504, 1024]
-        for M in (130, 777, 2898, 6000):
-            for kw in (dict(n_bands=8), dict(n_bands=3, lag=2), dict(n_bands=64), dict(n_bands=1), dict(n_bands=8, n_major=(1,) if len(info) == 3 else (0,))):
-                sched, nb = lib.chain_schedule(config, M, Ns, **kw)
-                assert 1 <= nb <= lib.CHAIN_MAX_BANDS
-                tiles_n = [-(-n // t[2]) for n, t in zip(Ns, info)]
-                tiles_m = [-(-M // t[1]) for t in info]
-                seen = set()
-                for b in range(nb):
-                    first, count = sched[2 * b], sched[2 * b + 1]
-                    done = {}                                   # (op, m-tile) -> N-tiles finished so far in this band
-                    for e in sched[first:first + count]:
-                        op, mt, nt = (e >> 28) & 7, (e >> 16) & 0xfff, e & 0xffff
-                        assert op < len(info) and mt < tiles_m[op] and nt < tiles_n[op] and e not in seen
-                        seen.add(e)
-                        if op > 0:                              # rows of this tile -> the producer's M-tiles, all complete already
-                            r_lo, r_hi = mt * info[op][1], min(M, (mt + 1) * info[op][1]) - 1
-                            for p in range(r_lo // info[op - 1][1], r_hi // info[op - 1][1] + 1):
-                                assert done.get((op - 1, p), 0) == tiles_n[op - 1], (config, M, kw, op, mt, p)
-                        done[(op, mt)] = done.get((op, mt), 0) + 1
-                assert len(seen) == sum(a * b for a, b in zip(tiles_m, tiles_n))
-    assert lib.chain_info(55) is None
-
-
-@pytest.mark.skipif(not lib.experimental(), reason="round-3 experiments exist only in `make EXPERIMENTAL=1` builds (TOC3D_LIB=libtoc3d_gfx950_exp.so)")
-def test_round3_entry_points_validate_without_gpu():
-    l = lib.load()
-    assert l.toc3d_linear_chain(lib.BF16, 0, 3, None, None, 8, None, 768, 0, None) == -1 and b"bad arguments" in l.toc3d_last_error()
-    assert l.toc3d_linear_chain(lib.F32, 0, 3, None, None, 8, None, 768, 0, None) == -1 and b"bf16 only" in l.toc3d_last_error()
-    assert l.toc3d_gather_merge_ln_pending(lib.BF16, *([None] * 1), 1024, *([None] * 4), 1, 196, 98, 100, None, None, 1e-6, None, None, 1024, 0,
-                                           None, None, None, None, None, None, None) == -1 and b"null buffer" in l.toc3d_last_error()
-    assert l.toc3d_token_inverse_map(None, None, 1, 196, 98, None, None) == -1
-    assert l.toc3d_linear_qkv_rope_ln(lib.BF16, 0, None, 0, None, 0, None, None, 0, 4, 192, 64, None, None, 16, 0.125, None, 64, 1e-6, None) == -1
-    assert b"null buffer" in l.toc3d_last_error()
-    assert l.toc3d_linear_chain_trace(None, 0) == 0
 
 
 def test_frame_timeline_cuts_frames_and_counts_idle_time():

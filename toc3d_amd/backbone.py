@@ -183,8 +183,7 @@ def schedule_defaults(precision):
     """The launch-schedule switches of the backbones and their shipped defaults per precision.  Plain attributes (``model.fold_norm2 = False`` before the
     first forward, or ``schedule=dict(...)`` at construction); every one is pinned by a test (tests/test_gpu_e2e.py, tests/test_cpu_abi.py).  The
     experiments of rounds 2-3 that lost (LayerNorm statistics in the consuming K loop, scatter folded into the next gather, prefetch across the frame
-    boundary, lighter event fences) are not part of the product forward any more: DESIGN.md section 4 keeps their measurements, `make EXPERIMENTAL=1`
-    their kernels."""
+    boundary, lighter event fences) are gone from the tree since round 6: LABNOTES.md keeps their measurements, the git history their kernels."""
     bf16 = precision == "bf16"
     fast = precision in ("bf16", "fp32x3")
     return dict(

@@ -31,10 +31,6 @@ int launch_gemm(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_
     switch (epi) {
         case TOC3D_EPI_BIAS: case TOC3D_EPI_GELU: case TOC3D_EPI_CONV3X3: return toc3d_gemm_launch_plain(is_bf16, epi, variant, a, s);
         case TOC3D_EPI_RESIDUAL: case TOC3D_EPI_RESIDUAL_LN: case TOC3D_EPI_RESIDUAL_STATS: return toc3d_gemm_launch_residual(is_bf16, epi, variant, a, s);
-#ifdef TOC3D_EXPERIMENTAL
-        case TOC3D_EPI_RESIDUAL_ACT: case TOC3D_EPI_SWIGLU_LNSELF: case TOC3D_EPI_RESIDUAL_LNSELF: case TOC3D_EPI_QKV_ROPE_LNSELF:
-            return is_bf16 ? toc3d_gemm_launch_lnself(epi, variant, a, s) : TOC3D_ERR_ARG;
-#endif
         case TOC3D_EPI_SWIGLU: case TOC3D_EPI_SWIGLU_STATS: case TOC3D_EPI_SWIGLU_STATS_LN: return toc3d_gemm_launch_swiglu(is_bf16, epi, variant, a, s);
         case TOC3D_EPI_QKV_ROPE: return toc3d_gemm_launch_rope(is_bf16, epi, variant, a, s);
         default: return TOC3D_ERR_ARG;
@@ -277,16 +273,9 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
     TOC3D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "toc3d_linear: A/W must be 16-byte aligned");
     const bool e_stats_out = epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_SWIGLU_STATS_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS;
     const bool e_ln_in = epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_SWIGLU_STATS_LN;
-    const bool e_ln_self = epilogue == TOC3D_EPI_SWIGLU_LNSELF || epilogue == TOC3D_EPI_RESIDUAL_LNSELF;
-    const bool e_swiglu = epilogue == TOC3D_EPI_SWIGLU || epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_SWIGLU_STATS_LN || epilogue == TOC3D_EPI_SWIGLU_LNSELF;
-    const bool e_residual = epilogue == TOC3D_EPI_RESIDUAL || epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS ||
-                            epilogue == TOC3D_EPI_RESIDUAL_ACT || epilogue == TOC3D_EPI_RESIDUAL_LNSELF;
-    TOC3D_REQUIRE(epilogue != TOC3D_EPI_QKV_ROPE && epilogue != TOC3D_EPI_QKV_ROPE_LNSELF && epilogue >= 0 && epilogue <= TOC3D_EPI_QKV_ROPE_LNSELF,
-                  "toc3d_linear: epilogue %d is not served by this entry point", epilogue);
-    if (e_ln_self) {
-        TOC3D_REQUIRE(bias && col_sums && ln_n > 0 && ln_n <= K, "toc3d_linear: epilogue %d needs bias (c2), col_sums (c1) and 0 < ln_n <= K (K spans the normalised row)", epilogue);
-        TOC3D_REQUIRE(epilogue != TOC3D_EPI_RESIDUAL_LNSELF || !out_act || (ld_act >= N && ((uintptr_t)out_act % 8) == 0 && ld_act % 4 == 0), "toc3d_linear: out_act [M, ld_act >= N], 8-byte aligned rows");
-    }
+    const bool e_swiglu = epilogue == TOC3D_EPI_SWIGLU || epilogue == TOC3D_EPI_SWIGLU_STATS || epilogue == TOC3D_EPI_SWIGLU_STATS_LN;
+    const bool e_residual = epilogue == TOC3D_EPI_RESIDUAL || epilogue == TOC3D_EPI_RESIDUAL_LN || epilogue == TOC3D_EPI_RESIDUAL_STATS;
+    TOC3D_REQUIRE(epilogue >= 0 && epilogue <= TOC3D_EPI_CONV3X3, "toc3d_linear: epilogue %d is not served by this entry point", epilogue);
     if (epilogue >= TOC3D_EPI_SWIGLU_STATS && epilogue != TOC3D_EPI_CONV3X3) TOC3D_REQUIRE(dtype == TOC3D_BF16 || x3_fold, "toc3d_linear: the folded-LayerNorm epilogues are bf16 only (and bf16 x 3 on f32 buffers)");
     if (e_stats_out) {
         TOC3D_REQUIRE(stats_out && ((uintptr_t)stats_out % 16) == 0, "toc3d_linear: epilogue %d needs a 16-byte aligned stats_out buffer", epilogue);
@@ -299,7 +288,7 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
         TOC3D_REQUIRE(bias && col_sums && ln_n > 0, "toc3d_linear: epilogue %d needs bias (c2), col_sums (c1) and ln_n", epilogue);
         TOC3D_REQUIRE(stats_in != stats_out, "toc3d_linear: stats_in and stats_out must be different buffers");
     }
-    if (epilogue == TOC3D_EPI_RESIDUAL_STATS || epilogue == TOC3D_EPI_RESIDUAL_ACT)
+    if (epilogue == TOC3D_EPI_RESIDUAL_STATS)
         TOC3D_REQUIRE(out_act && ld_act >= N && ((uintptr_t)out_act % 8) == 0 && ld_act % 4 == 0, "toc3d_linear: EPI_RESIDUAL_STATS needs out_act [M, ld_act >= N], 8-byte aligned rows");
     if (e_swiglu) {
         TOC3D_REQUIRE(bias && N % 32 == 0 && n_valid > 0 && n_valid <= N / 2, "toc3d_linear: swiglu needs bias, N%%32==0, n_valid");
@@ -405,56 +394,6 @@ int toc3d_linear_fused(int dtype, int epilogue, int variant, const void* A, int6
     return TOC3D_OK;
 }
 
-#ifdef TOC3D_EXPERIMENTAL
-int toc3d_linear_chain(int dtype, int config, int64_t n_ops, const toc3d_chain_op_t* ops, const int32_t* schedule, int64_t n_bands, void* state,
-                       int64_t grid, int64_t flags, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear_chain: bf16 only");
-    TOC3D_REQUIRE(ops && schedule && state && n_ops >= 2 && n_ops <= TOC3D_CHAIN_MAX_OPS, "toc3d_linear_chain: bad arguments");
-    TOC3D_REQUIRE(n_bands > 0 && n_bands <= TOC3D_CHAIN_MAX_BANDS && grid > 0 && grid <= 65535, "toc3d_linear_chain: n_bands in 1..%d, grid > 0", TOC3D_CHAIN_MAX_BANDS);
-    TOC3D_REQUIRE(((uintptr_t)state % 16) == 0 && ((uintptr_t)schedule % 4) == 0, "toc3d_linear_chain: misaligned state / schedule");
-    static_assert(TOC3D_CHAIN_STATE_BYTES == 4 * TOC3D_CHAIN_STATE_WORDS, "TOC3D_CHAIN_STATE_BYTES of include/toc3d.h");
-    int info[4 * TOC3D_CHAIN_MAX_OPS];
-    const int cfg_ops = toc3d_gemm_chain_info(config, info);
-    TOC3D_REQUIRE(cfg_ops == n_ops, "toc3d_linear_chain: config %d has %d ops, %lld given", config, cfg_ops, (long long)n_ops);
-    ChainArgs c{};
-    for (int i = 0; i < n_ops; ++i) {
-        const toc3d_chain_op_t& o = ops[i];
-        TOC3D_REQUIRE(o.epilogue == info[4 * i], "toc3d_linear_chain: op %d of config %d has epilogue %d, %lld given", i, config, info[4 * i], (long long)o.epilogue);
-        TOC3D_REQUIRE(o.M == ops[0].M && o.M > 0, "toc3d_linear_chain: every op works on the same M > 0 rows");
-        const int rc = fused_args(c.op[i].a, dtype, (int)o.epilogue, o.A, o.lda, o.W, o.ldw, o.bias, o.out, o.ldo, o.residual, o.ldr, 0, o.rep_out, o.rep_index,
-                                  o.M, o.N, o.K, o.n_valid, o.stats_out, o.stats_out_cap, o.stats_in, o.stats_in_cap, o.col_sums, o.ln_n, (float)o.ln_eps,
-                                  o.out_act, o.ld_act, o.residual_index);
-        if (rc != TOC3D_OK) return rc;
-        // a consumer tile waits for ITS row panel only, while the slot count in the statistics header is written by the producer's tile (0, 0): the
-        // header may be stale (zero on a first launch) for every other panel -- the host must pass the count (high half of stats_in_cap)
-        TOC3D_REQUIRE((o.epilogue != TOC3D_EPI_RESIDUAL_LN && o.epilogue != TOC3D_EPI_SWIGLU_STATS_LN) || (o.stats_in_cap >> 32) > 0,
-                      "toc3d_linear_chain: op %d consumes LayerNorm statistics: pass the slots per row in the high 32 bits of stats_in_cap (the header is not ordered with the row panels)", i);
-        c.op[i].dep = i - 1;
-        c.op[i].publish = i + 1 < n_ops;
-    }
-    c.n_ops = (int)n_ops;
-    c.n_bands = (int)n_bands;
-    c.sched = schedule;
-    c.state = reinterpret_cast<unsigned*>(state);
-    c.max_polls = 1u << 22;                              // x ~0.3 us per poll: about a second, then the launch gives up instead of hanging
-    c.full_release = (int)(flags & 1);
-    const int rc = toc3d_gemm_chain_launch(config, c, (int)grid, as_stream(stream));
-    if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear_chain: config %d cannot run these ops (M-tiles per op <= %d, K a multiple of 64)", config, TOC3D_CHAIN_MAX_MT); return rc; }
-    TOC3D_LAUNCH_CHECK("toc3d_linear_chain");
-    return TOC3D_OK;
-}
-
-int toc3d_linear_chain_trace(void* buf, int64_t entries) {
-    TOC3D_REQUIRE((buf == nullptr) == (entries == 0) && entries >= 0 && ((uintptr_t)buf % 8) == 0, "toc3d_linear_chain_trace: buffer of 8 + 64 * entries bytes, or (NULL, 0)");
-    toc3d_gemm_chain_set_trace(buf, (int)entries);
-    return TOC3D_OK;
-}
-
-int toc3d_linear_chain_info(int config, int32_t* info) {
-    TOC3D_REQUIRE(info, "toc3d_linear_chain_info: null buffer");
-    return toc3d_gemm_chain_info(config, info);
-}
-#endif  // TOC3D_EXPERIMENTAL
 
 int toc3d_conv3x3_nhwc(int dtype, int variant, const void* x, int64_t C, const void* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
                        int64_t V, int64_t h, int64_t w, int64_t Cout, const void* zeros, toc3d_stream_t stream) {
@@ -492,30 +431,6 @@ int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, co
     return TOC3D_OK;
 }
 
-#ifdef TOC3D_EXPERIMENTAL
-int toc3d_linear_qkv_rope_ln(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
-                             int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
-                             float q_scale, const float* col_sums, int64_t ln_n, float ln_eps, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(dtype == TOC3D_BF16, "toc3d_linear_qkv_rope_ln: bf16 only");
-    TOC3D_REQUIRE(A && W && out && rope_rc && rope_tab && bias && col_sums, "toc3d_linear_qkv_rope_ln: null buffer");
-    TOC3D_REQUIRE(M >= 0 && N > 0 && N % 192 == 0 && K > 0 && K % 64 == 0 && ln_n > 0 && ln_n <= K, "toc3d_linear_qkv_rope_ln: N = 3C with C a multiple of 64, K a multiple of 64, 0 < ln_n <= K");
-    TOC3D_REQUIRE(lda >= K && ldw >= K && ldo >= N && (lda * 2) % 16 == 0 && (ldw * 2) % 16 == 0, "toc3d_linear_qkv_rope_ln: bad leading dims");
-    TOC3D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)rope_tab % 16) == 0, "toc3d_linear_qkv_rope_ln: misaligned buffer");
-    TOC3D_REQUIRE(rope_side > 0 && rope_side <= 64, "toc3d_linear_qkv_rope_ln: rope_side out of range (the tables live in LDS: <= 64)");
-    if (M == 0) return TOC3D_OK;
-    const bool vec = ldo % 4 == 0 && (uintptr_t)out % 8 == 0;
-    static const bool wide_ok = [] { const char* e = getenv("TOC3D_WIDE_STORES"); return !(e && e[0] == '0'); }();
-    const bool vec8 = wide_ok && vec && ldo % 8 == 0 && (uintptr_t)out % 16 == 0;
-    GemmArgs a{A, lda, W, ldw, bias, out, ldo, nullptr, 0, 0, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K, 0, 0, vec ? 1 : 0, vec8 ? 1 : 0,
-               nullptr, 0, nullptr, 0, 0, col_sums, (float)(1.0 / (double)ln_n), ln_eps, nullptr, 0, 0, 0, nullptr, rope_rc, rope_tab, (int)rope_side, q_scale};
-    g_bad_variant = false;
-    const int rc = launch_gemm(1, TOC3D_EPI_QKV_ROPE_LNSELF, variant, a, as_stream(stream));
-    if (rc != TOC3D_OK) { toc3d_set_error("toc3d_linear_qkv_rope_ln: bad variant %d", variant); return rc; }
-    if (g_bad_variant) { toc3d_set_error("toc3d_linear_qkv_rope_ln: variant %d cannot serve this epilogue", variant); return TOC3D_ERR_UNSUPPORTED; }
-    TOC3D_LAUNCH_CHECK("toc3d_linear_qkv_rope_ln");
-    return TOC3D_OK;
-}
-#endif  // TOC3D_EXPERIMENTAL
 
 int toc3d_linear_ex(int dtype, int epilogue, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                     void* out, int64_t ldo, const float* residual, int64_t ldr, int64_t residual_row_mod,

@@ -62,38 +62,10 @@ int toc3d_gemm_launch_plain(int is_bf16, int epi, int variant, const GemmArgs& a
 int toc3d_gemm_launch_residual(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);   // EPI_RESIDUAL, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS
 int toc3d_gemm_launch_swiglu(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);     // EPI_SWIGLU, EPI_SWIGLU_STATS, EPI_SWIGLU_STATS_LN
 int toc3d_gemm_launch_rope(int is_bf16, int epi, int variant, const GemmArgs& a, hipStream_t s);       // EPI_QKV_ROPE (bf16)
-int toc3d_gemm_launch_lnself(int epi, int variant, const GemmArgs& a, hipStream_t s);                   // bf16: EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF
 int toc3d_gemm_launch_x3(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 3 products on f32 operands: epilogues 0-9
 int toc3d_gemm_launch_x6(int epi, int variant, const GemmArgs& a, hipStream_t s);                      // bf16 x 6 (three-way split): f32-grade products
 int toc3d_gemm_launch_splitk(int dtype, int epi, int variant, const GemmArgs& a, hipStream_t s);       // residual epilogues with a.split > 1 (gemm_epi_splitk.hip); dtype: TOC3D_BF16 / TOC3D_F32 / TOC3D_F32X3
 int toc3d_gemm_splitk_tile_dims(int variant);                                                           // BM << 16 | BN of a split-K tile variant (0: the variant has no split-K form)
-
-// ---- GEMM chains (gemm_chain.hip; include/toc3d.h, toc3d_linear_chain): several dependent GEMMs of one block half in ONE persistent launch ----
-constexpr int TOC3D_CHAIN_MAX_OPS = 3;
-constexpr int TOC3D_CHAIN_MAX_MT = 256;                 // M-tiles per op
-constexpr int TOC3D_CHAIN_MAX_BANDS = 64;
-// state words (unsigned, zero before the first launch; the last workgroup of every launch zeroes them again, word 1 excepted):
-//   [0] workgroups that left   [1] sticky error code   [8 + b] owner of band b (0 = free, XCC id + 1)   [8 + 64 + b] queue head of band b
-//   [8 + 128 + op * 256 + mt] finished tiles of (op, M-tile mt)
-constexpr int TOC3D_CHAIN_STATE_WORDS = 8 + 2 * TOC3D_CHAIN_MAX_BANDS + TOC3D_CHAIN_MAX_OPS * TOC3D_CHAIN_MAX_MT;
-struct ChainOp {
-    GemmArgs a;
-    int dep;                                             // op whose row panels this op's A operand / residual / statistics come from (-1: inputs of the launch)
-    int dep_need, dep_bm;                                // N-tiles per M-tile of that op, its M-tile height
-    int publish;                                         // a later op waits for this op's row panels
-};
-struct ChainArgs {
-    ChainOp op[TOC3D_CHAIN_MAX_OPS];
-    int n_ops, n_bands;
-    const int32_t* sched;                                // [2 * n_bands] (first entry, entries) per band, then the entries: op << 28 | M-tile << 16 | N-tile
-    unsigned* state;
-    unsigned max_polls;                                  // bound of every spin (then: error code in state[1], the launch finishes with wrong data instead of hanging)
-    int full_release;                                    // 1: agent-scope release before every publish (placement-independent even if a band's tiles ran on two XCDs)
-    unsigned long long* trace; int trace_cap;            // development: [0] = entries used, then [trace_cap][8] per-tile time stamps (toc3d_chain_set_trace); null in production
-};
-int toc3d_gemm_chain_launch(int config, ChainArgs& c, int grid, hipStream_t s);     // fills dep_need / dep_bm from the config's tile shapes
-void toc3d_gemm_chain_set_trace(void* buf, int entries);
-int toc3d_gemm_chain_info(int config, int* info);                                  // info[4 * op + {0,1,2,3}] = epilogue, BM, BN, threads; returns the number of ops (< 0: unknown config)
 
 // Development instrumentation (tools/ubench/gemm_timeline.hip builds its own copy of these kernels with -DTOC3D_GEMM_TRACE; the library
 // never defines it): every workgroup leaves the 100 MHz real-time counter at entry, after its K loop and after its epilogue stores have
@@ -122,16 +94,12 @@ namespace {
 
 
 
-constexpr bool epi_is_swiglu(int epi) { return epi == TOC3D_EPI_SWIGLU || epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN || epi == TOC3D_EPI_SWIGLU_LNSELF; }
-constexpr bool epi_is_residual(int epi) {
-    return epi == TOC3D_EPI_RESIDUAL || epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_RESIDUAL_STATS || epi == TOC3D_EPI_CONV3X3 || epi == TOC3D_EPI_RESIDUAL_ACT ||
-           epi == TOC3D_EPI_RESIDUAL_LNSELF;
-}
-constexpr bool epi_ln_self(int epi) { return epi == TOC3D_EPI_SWIGLU_LNSELF || epi == TOC3D_EPI_RESIDUAL_LNSELF || epi == TOC3D_EPI_QKV_ROPE_LNSELF; }   // ... its statistics taken by this GEMM's own K loop
-constexpr bool epi_ln_stats_in(int epi) { return epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_SWIGLU_STATS_LN; }                                      // ... its statistics left by the producing GEMM
-constexpr bool epi_ln_in(int epi) { return epi_ln_stats_in(epi) || epi_ln_self(epi); }        // LayerNorm of the A rows folded into the epilogue
-constexpr bool epi_is_rope(int epi) { return epi == TOC3D_EPI_QKV_ROPE || epi == TOC3D_EPI_QKV_ROPE_LNSELF; }
-constexpr bool epi_act_copy(int epi) { return epi == TOC3D_EPI_RESIDUAL_STATS || epi == TOC3D_EPI_RESIDUAL_ACT || epi == TOC3D_EPI_RESIDUAL_LNSELF; }      // residual epilogues that also leave the rows in the act dtype
+constexpr bool epi_is_swiglu(int epi) { return epi == TOC3D_EPI_SWIGLU || epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN; }
+constexpr bool epi_is_residual(int epi) { return epi == TOC3D_EPI_RESIDUAL || epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_RESIDUAL_STATS || epi == TOC3D_EPI_CONV3X3; }
+constexpr bool epi_ln_stats_in(int epi) { return epi == TOC3D_EPI_RESIDUAL_LN || epi == TOC3D_EPI_SWIGLU_STATS_LN; }      // LayerNorm of the A rows folded into the epilogue, its statistics left by the producing GEMM
+constexpr bool epi_ln_in(int epi) { return epi_ln_stats_in(epi); }
+constexpr bool epi_is_rope(int epi) { return epi == TOC3D_EPI_QKV_ROPE; }
+constexpr bool epi_act_copy(int epi) { return epi == TOC3D_EPI_RESIDUAL_STATS; }      // the residual epilogue that also leaves the rows in the act dtype
 constexpr bool epi_stats_out(int epi) { return epi == TOC3D_EPI_SWIGLU_STATS || epi == TOC3D_EPI_SWIGLU_STATS_LN || epi == TOC3D_EPI_RESIDUAL_STATS; }
 // statistics groups per wave-tile row: one per 32 packed columns (SwiGLU) or per 16 output columns (residual)
 constexpr int epi_stat_groups(int epi, int NT) { return epi_is_swiglu(epi) ? (NT / 2 > 0 ? NT / 2 : 1) : NT; }
@@ -143,16 +111,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // 64-byte rows (4 rows per 256-byte bank row): swz = (-(r >> 2)) & 3; rows of 256 / 512 bytes (every row starts on
 // the same bank): swz = r & 15.  Each makes every ds_read_b128 lane group of the MFMA fragment reads hit 16
 // distinct 16-byte slots.
-// SW = 1: the image read by the 32x32x16 MFMA fragments (gemm_tile, MF32): a ds_read_b128 lane group then holds rows {0-3, 12-15, 20-27} (+4 / +32 ...) of ONE
-// logical chunk, and on 128-byte rows two rows of equal parity with equal r & 7 (12 and 20) would share a 16-byte slot: swz = (r >> 1) & 7 separates the
-// eight even and the eight odd rows of every such group.  Rows of 256 / 512 bytes: r & 15 is distinct over those row sets as it stands.
-template <int RB, int SW = 0> TOC3D_DEV int swz(int r) {
-    if constexpr (SW == 1 && RB == 128) return (r >> 1) & 7;
-    return RB >= 256 ? (r & 15) : (RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3));
-}
+template <int RB> TOC3D_DEV int swz(int r) { return RB >= 256 ? (r & 15) : (RB == 128 ? (r & 7) : ((4 - ((r >> 2) & 3)) & 3)); }
 
 // stage one R-row x RB-byte operand tile with 16-byte global_load_lds: R*RB/16 chunks over 256 threads.
-template <typename T, int R, int RB, int NTHR, int SW = 0, int AUX = 0>
+template <typename T, int R, int RB, int NTHR, int AUX = 0>
 TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max_row, int k0, char* lds_tile, int wave, int lane) {
     constexpr int CPR = RB / 16;                        // chunks per row
     // Tiles whose chunk count is not a multiple of the workgroup size (96- / 160-row tiles on 512 threads): the wavefronts past the end of the last round
@@ -168,41 +130,9 @@ TOC3D_DEV void stage_tile(const T* __restrict__ g, int64_t ld, int row0, int max
         const int r = cidx / CPR, p = cidx % CPR;
         int gr = row0 + r;
         gr = gr < max_row ? gr : max_row;
-        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB, SW>(r)) << 4);
+        const char* src = reinterpret_cast<const char*>(g + (int64_t)gr * ld + k0) + ((p ^ swz<RB>(r)) << 4);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + base * 16), 16, 0, AUX);
     }
-}
-
-// ---- 32x32x16 MFMA form (bf16; gemm_tile with X3 == 32) ----------------------------------------------------------------------------
-// v_mfma_f32_32x32x16_bf16: A / B operands = 8 consecutive K per lane, lane = (row | col) + 32 * k-group (two groups of 8 per 16-deep step); a 32x32 block
-// of the output = 16 f32 per lane.  Per 64-deep K-tile a wave reads (TM + TN) / 32 * 4 fragments of 1 KB -- the same LDS bytes per FLOP as the 16x16x32
-// form on the same per-wave tile -- and issues half as many MFMA instructions at the higher 32x32 rate (MI355X_MICROARCH.md: 2382 vs 2075 TF).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// fragment of the 32-row block starting at tile row r0 for the 16-wide K step s of the K-tile (RB bytes per row)
-template <int RB>
-TOC3D_DEV bf16x8 lds_frag32(const char* tile, int r0, int s, int lane) {
-    const int r = r0 + (lane & 31), cc = s * 2 + (lane >> 5);
-    return *reinterpret_cast<const bf16x8*>(tile + r * RB + ((cc ^ swz<RB, 1>(r)) << 4));
-}
-
-// One 32x32 accumulator block (operands swapped like mma_step: D rows = W rows = output columns, D columns = activation rows), i.e. per lane: output row
-// m = lane & 31, columns n = q * 8 + (lane >> 5) * 4 + e for register q * 4 + e  ->  the four 16x16 C^T tiles (i2, j2) the epilogues are written for
-// (lane: row i2 * 16 + (lane & 15), columns j2 * 16 + (lane >> 4) * 4 + e).  In bits: the new lane bit 5 is q's low bit, the new lane bit 4 is the old
-// lane bit 5, the row half i2 is the old lane bit 4 -- a three-cycle between two lane bits and one register bit = one v_permlane32_swap (lane bit 5 <->
-// register bit) followed by one v_permlane16_swap (lane bit 4 <-> register bit) per register pair: 16 VALU instructions per block, no LDS.
-TOC3D_DEV void block32_to_tiles16(const f32x16& c, f32x4& t00, f32x4& t01, f32x4& t10, f32x4& t11) {
-#pragma unroll
-    for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float fa = c[(2 * j2) * 4 + e], fb = c[(2 * j2 + 1) * 4 + e];      // (a bit_cast of the vector-element expression itself reads element 0)
-            const unsigned a = __builtin_bit_cast(unsigned, fa), b = __builtin_bit_cast(unsigned, fb);
-            const auto s1 = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-            const auto s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
-            const float lo = __builtin_bit_cast(float, (unsigned)s2[0]), hi = __builtin_bit_cast(float, (unsigned)s2[1]);
-            if (j2 == 0) { t00[e] = lo; t10[e] = hi; } else { t01[e] = lo; t11[e] = hi; }
-        }
 }
 
 // fragment of row r (tile-local) for the 32-wide K step s, lane group g = lane >> 4
@@ -501,14 +431,8 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
             const int Cq = a.N / 3;
             const int rope_rc = rope_rcs[i];             // loaded before the K loop (no dependent global round trip here)
             float x[4];
-            if (LN_IN) {                                   // norm1 folded (EPI_QKV_ROPE_LNSELF): bias = c2, ccol = c1 of the gamma-scaled q|k|v weights
-                const f32x2 v = lnrow[i * 16 + r16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = v[1] * (acc[i][j][r] - v[0] * ccol[j][r]) + bcol[j][r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = acc[i][j][r] + bcol[j][r];
-            }
+            for (int r = 0; r < 4; ++r) x[r] = acc[i][j][r] + bcol[j][r];
             if (col < 2 * Cq) {
                 const int d0 = col & 63, part = d0 >> 5;
                 const int coord = part ? (rope_rc & 0xffff) : (rope_rc >> 16);
@@ -647,7 +571,7 @@ TOC3D_DEV void gemm_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NT], int row0, 
                         if (reprow) reprow[col + r] = raw[r];
                     }
                 }
-                if (epi_act_copy(EPI) && (EPI != TOC3D_EPI_RESIDUAL_LNSELF || a.out_act)) {
+                if (epi_act_copy(EPI)) {
                     // the updated residual-stream row also leaves in the act dtype (the next GEMM's A operand, its LayerNorm folded into that
                     // GEMM), RESIDUAL_STATS: together with the sums of those rounded values
                     T* arow = reinterpret_cast<T*>(a.out_act) + (int64_t)row * a.ld_act + col;
@@ -892,18 +816,16 @@ TOC3D_DEV bool sk_exchange(const GemmArgs& a, f32x4 (&acc)[MT][NT], char* smem, 
 }
 
 // One BM x BN output tile (rows m0.., columns n0..) by the calling workgroup of 64 * WM * WN threads: K loop + fused epilogue.  `smem` = the
-// workgroup's dynamic LDS.  gemm_kernel below runs one tile per workgroup; gemm_chain_kernel walks a queue of tiles of several GEMMs.
+// workgroup's dynamic LDS.  gemm_kernel below runs one tile per workgroup.
 // SK = 1: deterministic split-K (a.split workgroups per tile).  The calling workgroup multiplies K range `sk_slice` of tile `sk_tile` only; the partial
 // accumulators meet through a.sk_slabs and the workgroup that arrives LAST at the tile's ticket adds them in slice order (so the sum does not depend on which
 // one that is) and runs the epilogue; the others return after their store.  See sk_exchange below.
 template <typename T, int EPI, int BM, int BN, int STAGES, int RB, int WM, int WN, int X3 = 0, int OCC = 1, int SK = 0>
 TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* smem, const int sk_tile = 0, const int sk_slice = 0) {
-    static_assert(SK == 0 || (EPI != TOC3D_EPI_CONV3X3 && !epi_is_rope(EPI) && !epi_ln_self(EPI) && X3 != 32), "split-K serves the plain linear epilogues on the 16x16x32 K loop");
-    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4) || ((X3 == 32 || X3 == 1) && sizeof(T) == 2),
-                  "the bf16 x 3 / x 6 product forms run on f32 operands, the 32x32x16 MFMA form and the register-pipelined loop on bf16");
+    static_assert(SK == 0 || (EPI != TOC3D_EPI_CONV3X3 && !epi_is_rope(EPI)), "split-K serves the plain linear epilogues");
+    static_assert(X3 == 0 || ((X3 == 3 || X3 == 6) && sizeof(T) == 4) || (X3 == 1 && sizeof(T) == 2),
+                  "the bf16 x 3 / x 6 product forms run on f32 operands, the register-pipelined loop on bf16");
     constexpr bool PIPE = X3 == 1;                      // fragments of the NEXT 32-deep K step are read while the MFMAs of the current one run (see the loop)
-    constexpr bool MF32 = X3 == 32;                     // v_mfma_f32_32x32x16_bf16 in the K loop (see lds_frag32); accumulators handed to the epilogue as 16x16 tiles
-    constexpr int SW = MF32 ? 1 : 0;
     constexpr int NTHR = 64 * WM * WN;                  // WM x WN wavefronts
     constexpr int TM = BM / WM, TN = BN / WN;           // per-wave output tile
     constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
@@ -945,34 +867,6 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int MT32 = MF32 ? TM / 32 : 1, NT32 = MF32 ? TN / 32 : 1;
-    static_assert(!MF32 || (TM % 32 == 0 && TN % 32 == 0 && RB >= 128), "32x32 MFMA blocks: per-wave tiles of whole 32x32 blocks, K-tiles of >= 64");
-    f32x16 acc32[MT32][NT32];
-    if constexpr (MF32) {
-#pragma unroll
-        for (int i = 0; i < MT32; ++i)
-#pragma unroll
-            for (int j = 0; j < NT32; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
-    }
-
-    // EPI_*_LNSELF: LayerNorm of the A rows folded into the epilogue with the statistics taken by this kernel's own K loop (K spans the whole
-    // normalised row: norm1 / norm2 in front of q|k|v / w1|w2, ffn_ln in front of w3) -- no statistics hand-off, no LayerNorm launch.
-    constexpr bool LNSELF = epi_ln_self(EPI);
-    static_assert(!LNSELF || (sizeof(T) == 2 && X3 == 0), "self-normalising epilogues are bf16 only (16x16 MFMA form)");
-    constexpr int LN_OWN = LNSELF ? (MT + WN - 1) / WN : 1;
-    f32x4 ln_sum[LN_OWN], ln_sq[LN_OWN];
-#pragma unroll
-    for (int q = 0; q < LN_OWN; ++q) { ln_sum[q] = f32x4{0.f, 0.f, 0.f, 0.f}; ln_sq[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    Frag<T> ln_ones;
-    if constexpr (LNSELF) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ln_ones.v[e] = (bf16_t)1.0f;
-    }
-    const int wn_u = __builtin_amdgcn_readfirstlane(wn);     // wave-uniform: the row-tile ownership test is a scalar branch
-    (void)wn_u;
-
     // W rows are padded to a multiple of 128 at pack time, A rows are clamped to M-1
     const int w_max = ((a.N + 127) / 128) * 128 - 1;
     // EPI_CONV3X3 (necks/cp_fpn.py:124-133 as an implicit GEMM): the A tile of K-tile t is the (ky, kx) = tap t*BK / C neighbour of each
@@ -1003,36 +897,21 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
                 const int y2 = (cv_yx[u] >> 16) + dy, x2 = (cv_yx[u] & 0xffff) + dx;
                 const bool in = (unsigned)y2 < (unsigned)a.conv_h && (unsigned)x2 < (unsigned)a.conv_w;
                 // out-of-image taps: any 16 zero bytes (no chunk offset: K-tiles of 256 / 512 bytes would run past a small zero line)
-                const char* src = in ? reinterpret_cast<const char*>(A + (int64_t)(cv_m[u] + dy * a.conv_w + dx) * C + c0) + ((pch ^ swz<RB, SW>(r)) << 4)
+                const char* src = in ? reinterpret_cast<const char*>(A + (int64_t)(cv_m[u] + dy * a.conv_w + dx) * C + c0) + ((pch ^ swz<RB>(r)) << 4)
                                      : reinterpret_cast<const char*>(a.zeros);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slot + (u * NTHR + wave * 64) * 16), 16, 0, 0);
             }
         } else {
-            stage_tile<T, BM, RB, NTHR, SW>(A, a.lda, m0, a.M - 1, k_base + t * BK, slot, wave, lane);
+            stage_tile<T, BM, RB, NTHR>(A, a.lda, m0, a.M - 1, k_base + t * BK, slot, wave, lane);
         }
 #ifndef TOC3D_W_AUX
 #define TOC3D_W_AUX 0                                   // experiment (round 5, profiles/r05_nt_stores.txt): cache policy bits of the W operand's DMA loads (2 = nt: stream past the L2's LRU)
 #endif
-        stage_tile<T, BN, RB, NTHR, SW, TOC3D_W_AUX>(W, a.ldw, n0, w_max, k_base + t * BK, slot + A_BYTES, wave, lane);
+        stage_tile<T, BN, RB, NTHR, TOC3D_W_AUX>(W, a.ldw, n0, w_max, k_base + t * BK, slot + A_BYTES, wave, lane);
     };
     auto multiply = [&](int t) {
         const char* sA = smem + (t % STAGES) * STAGE_BYTES;
         const char* sB = sA + A_BYTES;
-        if constexpr (MF32) {
-#pragma unroll
-            for (int s = 0; s < 2 * KS; ++s) {           // 16-deep steps
-                bf16x8 fa[MT32], fb[NT32];
-#pragma unroll
-                for (int i = 0; i < MT32; ++i) fa[i] = lds_frag32<RB>(sA, wm * TM + i * 32, s, lane);
-#pragma unroll
-                for (int j = 0; j < NT32; ++j) fb[j] = lds_frag32<RB>(sB, wn * TN + j * 32, s, lane);
-#pragma unroll
-                for (int i = 0; i < MT32; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT32; ++j) acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc32[i][j], 0, 0, 0);   // swapped: C^T layout
-            }
-            return;
-        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             Frag<T> fa[MT], fb[NT];
@@ -1041,23 +920,6 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
                 for (int i = 0; i < MT; ++i) fa[i] = lds_frag<RB>(sA, wm * TM + i * 16 + r16, s, g, T());
 #pragma unroll
                 for (int j = 0; j < NT; ++j) fb[j] = lds_frag<RB>(sB, wn * TN + j * 16 + r16, s, g, T());
-            }
-            if constexpr (LNSELF) {
-                // LayerNorm statistics of the A rows on the matrix cores (they idle two thirds of this loop; VALU forms -- dot products or converts
-                // and adds on the fragments -- cost 5-10 us per launch, profiles/r03_lnself.txt).  Of the WN wavefronts that multiply the same A
-                // rows, wave wn takes row tiles wn, wn + WN, ...: it reads that fragment X [16 rows x 32 k] once more at its own (wave-uniform) LDS
-                // row and issues two more MFMAs:  X . 1 (every column of the result = the row sums)  and  X . X^T (the Gram matrix: its
-                // diagonal = the row sums of squares; a bf16 product is exact in f32).  Accumulated over K like the GEMM itself, so the bits do
-                // not depend on the tile variant.
-#pragma unroll
-                for (int q = 0; q < LN_OWN; ++q) {
-                    const int oi = wn_u + WN * q;
-                    if (MT % WN == 0 || oi < MT) {
-                        const Frag<T> fo = lds_frag<RB>(sA, wm * TM + oi * 16 + r16, s, g, T());
-                        mma_step(ln_sum[q], fo, ln_ones);
-                        mma_step(ln_sq[q], fo, fo);
-                    }
-                }
             }
             if constexpr (X3 == 6) {
                 bf16x8 ah[MT], am[MT], al[MT], bh[NT], bm[NT], bl[NT];
@@ -1193,7 +1055,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
         // the MIDDLE of K-tile kt, half a tile earlier than in the plain ring (one tile less may stay in flight: STAGES >= 3, meant for 4).
         //   RAW: tile kt + 1 is read behind the counted wait + barrier of K-tile kt.
         //   WAR: behind that barrier the slot of tile kt - 1 is refilled; its last fragments (kt - 1, 1) were consumed by MFMAs every wave issued before arriving.
-        static_assert(STAGES >= 3 && KS == 2 && !LNSELF && EPI != TOC3D_EPI_CONV3X3, "register-pipelined loop: rings of >= 3 K-tiles of 64 bf16, linear epilogues");
+        static_assert(STAGES >= 3 && KS == 2 && EPI != TOC3D_EPI_CONV3X3, "register-pipelined loop: rings of >= 3 K-tiles of 64 bf16, linear epilogues");
         Frag<T> fa0[MT], fb0[NT], fa1[MT], fb1[NT];
         auto read_set = [&](int t, auto S, Frag<T> (&fa)[MT], Frag<T> (&fb)[NT]) {
             constexpr int sidx = decltype(S)::value;
@@ -1281,32 +1143,6 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     TOC3D_TRACE(1);
     if constexpr (SK != 0) {
         if (!sk_exchange<MT, NT, NTHR, BM * BN>(a, acc, smem, sk_tile, sk_slice, tid)) return;      // not the last arriver of this tile: the partial is stored, done
-    }
-    if constexpr (MF32) {
-#pragma unroll
-        for (int i = 0; i < MT32; ++i)
-#pragma unroll
-            for (int j = 0; j < NT32; ++j) block32_to_tiles16(acc32[i][j], acc[2 * i][2 * j], acc[2 * i][2 * j + 1], acc[2 * i + 1][2 * j], acc[2 * i + 1][2 * j + 1]);
-    }
-
-    if constexpr (LNSELF) {
-        // (mean, rstd) of the tile's rows into the row table behind the operand stages (nothing else lives there).  C layout of the 16x16 MFMA:
-        // a lane holds C[4 g + r][r16], r = 0..3 -- the lanes with g == r16 >> 2 hold the diagonal element of row r16 (and that row's sum) in
-        // element r16 & 3.  f64 for the variance like the statistics-consuming form.
-#pragma unroll
-        for (int q = 0; q < LN_OWN; ++q) {
-            const int oi = wn_u + WN * q;
-            if (MT % WN == 0 || oi < MT) {
-                const int e = r16 & 3;
-                const float s1f = e == 0 ? ln_sum[q][0] : (e == 1 ? ln_sum[q][1] : (e == 2 ? ln_sum[q][2] : ln_sum[q][3]));
-                const float s2f = e == 0 ? ln_sq[q][0] : (e == 1 ? ln_sq[q][1] : (e == 2 ? ln_sq[q][2] : ln_sq[q][3]));
-                const double mean = (double)s1f * (double)a.ln_inv_n;
-                double var = (double)s2f * (double)a.ln_inv_n - mean * mean;
-                var = var > 0.0 ? var : 0.0;
-                if ((r16 >> 2) == g) lnrow[wm * TM + oi * 16 + r16] = f32x2{(float)mean, 1.0f / sqrtf((float)var + a.ln_eps)};
-            }
-        }
-        lds_barrier();
     }
     tile_finish<T, EPI, BM, BN, WM, WN, (STAGES > 1)>(a, acc, m0, n0, smem, lnrow, rope_rcs, rope_tab);
 }
@@ -1648,9 +1484,7 @@ int launch_epi_sk(int variant, const GemmArgs& a, hipStream_t s) {
 template <int EPI, int BM, int BN, int WM, int WN, bool X3 = false>
 void launch_phased(const GemmArgs& a, hipStream_t s) {
     // round 5: every linear epilogue (the folded LayerNorms' statistics in and out, the rotating q|k|v epilogue); not the conv gather (its own operand loader)
-    // nor the experimental self-normalising forms (statistics inside the K loop)
-    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) || EPI == TOC3D_EPI_CONV3X3 || epi_ln_self(EPI) ||
-                  EPI == TOC3D_EPI_RESIDUAL_ACT) {
+    if constexpr ((epi_is_swiglu(EPI) && (BN / WN) % 32 != 0) || (epi_stats_out(EPI) && BN % (epi_is_swiglu(EPI) ? 128 : 64) != 0) || EPI == TOC3D_EPI_CONV3X3) {
         g_bad_variant = true;
     } else {
         constexpr int lds_fixed = 2 * (BM + BN) * 128 + (epi_ln_in(EPI) ? BM * 8 : 0);              // two K-tiles of 64 bf16 (+ the row table)
@@ -1679,86 +1513,31 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
     }
     switch (variant) {
         case 1: launch_cfg<T, EPI, 128, 128, 2>(a, s); break;
-#ifdef TOC3D_EXPERIMENTAL
-        case 2: launch_cfg<T, EPI, 128, 128, 3>(a, s); break;
-        case 3: launch_cfg<T, EPI, 128, 128, 4>(a, s); break;
-        case 4: launch_cfg<T, EPI, 128, 64, 3>(a, s); break;
-        case 5: launch_cfg<T, EPI, 128, 64, 4>(a, s); break;
-        case 6: launch_cfg<T, EPI, 64, 128, 3>(a, s); break;
-        case 7: launch_cfg<T, EPI, 64, 64, 4>(a, s); break;
-#endif
         case 8: launch_cfg<T, EPI, 128, 128, 1>(a, s); break;
         case 9: launch_cfg<T, EPI, 128, 64, 2>(a, s); break;
         case 10: launch_cfg<T, EPI, 64, 128, 2>(a, s); break;
-#ifdef TOC3D_EXPERIMENTAL
-        case 11: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 2, 64>(a, s); else return TOC3D_ERR_ARG; break;
-        case 12: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64>(a, s); else return TOC3D_ERR_ARG; break;
-#endif
         case 13: launch_cfg<T, EPI, 128, 64, 1>(a, s); break;
         case 14: launch_cfg<T, EPI, 64, 64, 2>(a, s); break;
         case 15: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 2, 4>(a, s); break;      // v8 forced to <= 128 registers: 4 workgroups / CU
         case 16: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 6 : 1)>(a, s); break;   // 8 waves, 64x32 per wave; bf16 held to 80 registers (6 waves / SIMD = 3 workgroups / CU; the SwiGLU epilogue would take 82)
         case 17: launch_cfg<T, EPI, 128, 128, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, double buffered (64 KiB)
-#ifdef TOC3D_EXPERIMENTAL
-        case 18: launch_cfg<T, EPI, 256, 128, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128 tile, double buffered (96 KiB)
-#endif
         case 19: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 2, 1>(a, s); break;      // 8 waves, 256x128, single buffer (48 KiB)
-#ifdef TOC3D_EXPERIMENTAL
-        case 20: launch_cfg<T, EPI, 128, 256, 2, 128, 2, 4, 1>(a, s); break;      // 8 waves, 128x256 tile, double buffered
-        case 21: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 2, 1>(a, s); break;      // 8 waves 256x256, 128x128... per-wave 64x128
-#endif
         // big K-tiles for latency-bound launches (about one tile per CU): fewer, fatter load rounds
         case 22: launch_cfg<T, EPI, 128, 128, 1, 256, 2, 4, 1>(a, s); break;      // K-tile 128 bf16, 64 KiB
-#ifdef TOC3D_EXPERIMENTAL
-        case 23: launch_cfg<T, EPI, 128, 128, 1, 512, 2, 4, 1>(a, s); break;      // K-tile 256 bf16, 128 KiB
-#endif
         case 24: launch_cfg<T, EPI, 64, 128, 1, 512, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 256, 96 KiB
-#ifdef TOC3D_EXPERIMENTAL
-        case 25: launch_cfg<T, EPI, 128, 128, 2, 256, 2, 4, 1>(a, s); break;      // K-tile 128, double buffered, 128 KiB
-#endif
         case 26: launch_cfg<T, EPI, 64, 128, 1, 256, 2, 4, 1>(a, s); break;       // 64x128 tile, K-tile 128, 48 KiB
         case 27: launch_cfg<T, EPI, 64, 64, 1, 512, 2, 2, 1>(a, s); break;        // 64x64 tile, 4 waves, K-tile 256, 64 KiB
         // deep LDS rings on 8 wavefronts: more bytes continuously in flight per CU (counted vmcnt, one barrier per K-tile)
         case 28: launch_cfg<T, EPI, 128, 128, 3, 128, 2, 4, 1>(a, s); break;      // 96 KiB
         case 29: launch_cfg<T, EPI, 128, 128, 4, 128, 2, 4, 1>(a, s); break;      // 128 KiB
         case 30: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 4, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 64 KiB
-#ifdef TOC3D_EXPERIMENTAL
-        case 31: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 6, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // K-tile 32, 96 KiB
-        case 32: launch_cfg<T, EPI, 256, 128, 3, 128, 4, 2, 1>(a, s); break;      // 256x128, 3-deep, 144 KiB
-#endif
         case 33: launch_cfg<T, EPI, 128, 64, 4, 128, 2, 4, 1>(a, s); break;       // 128x64, 4-deep, 96 KiB
         // 16 wavefronts per workgroup: 256-wide tiles (fewer L2->LDS bytes per FLOP) without giving up waves per CU
-#ifdef TOC3D_EXPERIMENTAL
-        case 34: launch_cfg<T, EPI, 256, 128, 1, 128, 4, 4, 1>(a, s); break;      // 256x128, 64x32 per wave, 48 KiB
-        case 35: launch_cfg<T, EPI, 256, 256, 1, 128, 4, 4, 1>(a, s); break;      // 256x256, 64x64 per wave, 64 KiB
-        case 36: launch_cfg<T, EPI, 128, 256, 1, 128, 4, 4, 1>(a, s); break;      // 128x256, 32x64 per wave, 48 KiB
-        case 37: launch_cfg<T, EPI, 256, 256, 2, 128, 4, 4, 1>(a, s); break;      // 256x256 double buffered, 128 KiB
-#endif
         // K-tile 32 rings on 8 wavefronts at the LDS footprint of the single-buffer tile: prefetch inside the workgroup without losing occupancy
-#ifdef TOC3D_EXPERIMENTAL
-        case 38: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 32 KiB
-        case 39: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 128, 3, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 48 KiB
-        case 40: launch_cfg<T, EPI, 128, 256, 1, 128, 2, 4, 1>(a, s); break;      // 128x256, 64x64 per wave, 48 KiB
-        case 41: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 128, 256, 2, 64, 2, 4, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 128x256, K-tile 32 x 2, 48 KiB
-        case 42: if (sizeof(T) == 2) launch_cfg<bf16_t, EPI, 256, 128, 2, 64, 4, 2, 1>(a, s); else return TOC3D_ERR_ARG; break;   // 256x128, K-tile 32 x 2, 48 KiB
-#endif
         // N-tiles that are not powers of two (the vendor library's answer to tile-count quantisation on N = 3072 / 1024)
-#ifdef TOC3D_EXPERIMENTAL
-        case 43: launch_cfg<T, EPI, 128, 192, 1, 128, 2, 4, 1>(a, s); break;      // 128x192, 64x48 per wave, 40 KiB
-        case 44: launch_cfg<T, EPI, 128, 96, 1, 128, 2, 2, 1>(a, s); break;       // 128x96, 4 waves, 64x48 per wave, 28 KiB
-#endif
         case 45: launch_cfg<T, EPI, 128, 192, 2, 128, 2, 4, 1>(a, s); break;      // 128x192 double buffered, 80 KiB
-#ifdef TOC3D_EXPERIMENTAL
-        case 46: launch_cfg<T, EPI, 128, 96, 2, 128, 2, 2, 1>(a, s); break;       // 128x96 double buffered, 56 KiB
-#endif
         case 47: launch_cfg<T, EPI, 128, 192, 2, 128, 4, 2, 1>(a, s); break;      // 128x192 double buffered, 32x96 per wave (serves SwiGLU)
-#ifdef TOC3D_EXPERIMENTAL
-        case 48: launch_cfg<T, EPI, 128, 192, 3, 128, 2, 4, 1>(a, s); break;      // 128x192, 3-deep ring, 120 KiB
-#endif
         case 49: launch_cfg<T, EPI, 192, 128, 2, 128, 2, 4, 1>(a, s); break;      // 192x128 double buffered, 96x32 per wave (serves SwiGLU), 80 KiB
-#ifdef TOC3D_EXPERIMENTAL
-        case 50: launch_cfg<T, EPI, 192, 128, 1, 128, 2, 4, 1>(a, s); break;      // 192x128 single buffer, 40 KiB
-#endif
         // (the rotating q|k|v epilogue is held to 128 registers -- two workgroups per CU like the other epilogues: unconstrained it took 138, ONE workgroup per CU and 83 instead of 51 us at M = 6000)
         case 52: launch_cfg<T, EPI, 192, 192, 1, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 single buffer, 96x48 per wave, 48 KiB: 512 tiles for q|k|v at M = 6000 (one per slot at two per CU)
         case 53: launch_cfg<T, EPI, 192, 192, 2, 128, 2, 4, (epi_is_rope(EPI) ? 4 : 1)>(a, s); break;      // 192x192 double buffered, 96 KiB
@@ -1771,29 +1550,6 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 58: launch_cfg<T, EPI, 160, 128, 2, 128, 2, 4, 1>(a, s); break;                          // 160x128 double buffered, 72 KiB
         case 59: launch_cfg<T, EPI, 192, 128, 3, 128, 2, 4, 1>(a, s); break;                          // 192x128 3-deep ring, 120 KiB: 32 x 8 = 256 tiles for N = 1024 at M = 6000
         case 51: launch_cfg<T, EPI, 128, 128, 1, 128, 2, 4, (sizeof(T) == 2 ? 8 : 1)>(a, s); break;   // variant 16 held to 64 registers (bf16): FOUR workgroups per CU -- the loop is bound by operand bytes in flight per CU
-#ifdef TOC3D_EXPERIMENTAL
-        // 32x32x16 MFMA form of the K loop (bf16 only; round 4; correct and NOT faster, profiles/r04_mfma32_variants.txt: experimental builds only): per-wave tiles of whole 32x32 blocks, own LDS swizzle, same epilogues (the accumulators are
-        // permuted into the 16x16 C^T layout first).  NOT bit-identical with the 16x16x32 variants: the matrix core sums 16 instead of 32 products per step.
-#define TOC3D_MF32(BM_, BN_, ST_, RB_, WM_, WN_, OCC_)                                                                              \
-        if constexpr (sizeof(T) == 2 && !epi_ln_self(EPI)) launch_cfg<bf16_t, EPI, BM_, BN_, ST_, RB_, WM_, WN_, OCC_, 32>(a, s); \
-        else return TOC3D_ERR_ARG;                                                                                                 \
-        break
-        case 70: TOC3D_MF32(128, 128, 1, 128, 2, 4, 6);      // variant 16's tile: 8 waves, 64x32 per wave, single buffer
-        case 71: TOC3D_MF32(128, 128, 2, 128, 2, 4, 1);      // variant 17's: double buffered
-        case 72: TOC3D_MF32(128, 128, 1, 128, 2, 2, 4);      // 4 waves, 64x64 per wave (2x2 blocks), single buffer, <= 128 registers: 4 workgroups per CU
-        case 73: TOC3D_MF32(128, 128, 2, 128, 2, 2, 1);      // ... double buffered
-        case 74: TOC3D_MF32(256, 128, 1, 128, 4, 2, 1);      // 8 waves, 256x128, 64x64 per wave, single buffer (48 KiB)
-        case 75: TOC3D_MF32(256, 128, 2, 128, 4, 2, 1);      // ... double buffered (96 KiB)
-        case 76: TOC3D_MF32(128, 256, 2, 128, 2, 4, 1);      // 8 waves, 128x256, 64x64 per wave, double buffered
-        case 77: TOC3D_MF32(256, 256, 2, 128, 4, 2, 1);      // 8 waves, 256x256, 64x128 per wave, double buffered (128 KiB)
-        case 78: TOC3D_MF32(192, 192, 1, 128, 2, 2, 1);      // 4 waves, 192x192, 96x96 per wave (3x3 blocks), single buffer (48 KiB)
-        case 79: TOC3D_MF32(128, 128, 4, 128, 2, 4, 1);      // variant 29's: 4-deep ring
-        case 80: TOC3D_MF32(256, 128, 3, 128, 4, 2, 1);      // 256x128, 3-deep ring (144 KiB)
-        case 81: TOC3D_MF32(128, 128, 3, 128, 2, 2, 1);      // 4 waves, 64x64 per wave, 3-deep ring (96 KiB)
-        case 82: TOC3D_MF32(64, 128, 2, 128, 2, 2, 1);       // 64x128, 4 waves, 32x64 per wave, double buffered
-        case 83: TOC3D_MF32(128, 64, 2, 128, 2, 2, 1);       // 128x64, 4 waves, 64x32 per wave, double buffered
-#undef TOC3D_MF32
-#endif  // TOC3D_EXPERIMENTAL
         // phased big tiles (bf16 only): one workgroup per CU, four phases per K-tile, the two wave groups one barrier apart
         case 60: if (sizeof(T) == 2) launch_phased<EPI, 256, 256, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 128x64 per wave, 128 KiB
         case 61: if (sizeof(T) == 2) launch_phased<EPI, 256, 128, 4, 2>(a, s); else return TOC3D_ERR_ARG; break;   // 64x64 per wave, 96 KiB
@@ -1801,7 +1557,7 @@ int launch_epi(int variant, GemmArgs a, hipStream_t s) {
         case 63: if (sizeof(T) == 2) launch_phased<EPI, 128, 128, 2, 4>(a, s); else return TOC3D_ERR_ARG; break;   // 64x32 per wave, 64 KiB: two per CU
         // register-pipelined rings (bf16 only; gemm_tile, PIPE): the next K step's fragments are read while the current one's MFMAs run -- for one workgroup per CU
 #define TOC3D_PIPE(BM_, BN_, ST_, WM_, WN_)                                                                                                              \
-        if constexpr (sizeof(T) == 2 && !epi_ln_self(EPI) && EPI != TOC3D_EPI_CONV3X3) launch_cfg<bf16_t, EPI, BM_, BN_, ST_, 128, WM_, WN_, 1, 1>(a, s); \
+        if constexpr (sizeof(T) == 2 && EPI != TOC3D_EPI_CONV3X3) launch_cfg<bf16_t, EPI, BM_, BN_, ST_, 128, WM_, WN_, 1, 1>(a, s); \
         else return TOC3D_ERR_ARG;                                                                                                                       \
         break
         case 64: TOC3D_PIPE(128, 128, 4, 2, 4);              // variant 29's tile and ring: 8 waves, 64x32 per wave, 128 KiB

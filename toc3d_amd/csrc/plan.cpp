@@ -105,22 +105,10 @@ namespace {
         }                                                                                     \
     } while (0)
 
-// Flags of the events behind the cross-lane edges.  They are only ever waited on by hipStreamWaitEvent of a stream of the SAME device, never by
-// the host, so the system-scope fence an event record performs by default (L2 write-back + invalidate, and its cost to the kernels that follow)
-// is not needed for correctness: kernel boundaries already release / acquire at agent scope.  TOC3D_EVENT_FENCE: 0 = HIP's default (system-scope
-// fence), 1 = hipEventReleaseToDevice, 2 = hipEventDisableSystemFence.
-unsigned event_flags() {
-    static const unsigned flags = [] {
-#ifdef TOC3D_EXPERIMENTAL
-        const char* e = getenv("TOC3D_EVENT_FENCE");       // (EXPERIMENTAL=1 builds only: measured 0.4-0.7 % slower, profiles/r03_event_fence.txt)
-        const int mode = e ? atoi(e) : 0;
-#else
-        const int mode = 0;
-#endif
-        return (unsigned)hipEventDisableTiming | (mode == 1 ? (unsigned)hipEventReleaseToDevice : mode == 2 ? (unsigned)hipEventDisableSystemFence : 0u);
-    }();
-    return flags;
-}
+// Flags of the events behind the cross-lane edges: HIP's default (system-scope fence at the record).  The events are only ever waited on by streams of the same
+// device, so hipEventReleaseToDevice / hipEventDisableSystemFence would be legal -- both were measured 0.4-0.7 % SLOWER (profiles/r03_event_fence.txt: the gap behind
+// a signalling launch is the command processor's barrier packet, not the cache write-back) and are not offered.
+unsigned event_flags() { return (unsigned)hipEventDisableTiming; }
 
 // The side lanes of EVERY plan of the process run on one set of HIP streams per device, created by the first plan that needs them.  Round 4 finding
 // (profiles/r04_stream_priority.txt, tools/ubench/schedule_ab.py with identical schedules): with private streams per plan, the process's first model ran

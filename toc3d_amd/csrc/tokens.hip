@@ -871,11 +871,6 @@ static int launch_gather(int dtype, const float* x, int64_t C, const int32_t* to
         toc3d_launch((gather_merge_ln_kernel<T, 4, P>), grid, block, lds, s, x, (int)C, tok, wgt, crow_tok, rep_row, (int)nW, (int)N, (int)k, (int)rows, \
                      gamma, beta, eps, shortcut, (T*)a_out, lda, (int)(kept_copy != 0), pd);                                        \
     } while (0)
-#ifdef TOC3D_EXPERIMENTAL
-    if (pd.inv && dtype == TOC3D_BF16) TOC3D_GATHER(bf16_t, true);
-    else if (pd.inv && dtype == TOC3D_F32) TOC3D_GATHER(float, true);
-    else
-#endif
     if (dtype == TOC3D_BF16) TOC3D_GATHER(bf16_t, false);
     else if (dtype == TOC3D_F32) TOC3D_GATHER(float, false);
     else if (dtype == TOC3D_F32X3P) {            // a_out as (hi, lo) planes (the q|k|v GEMM's A operand); shortcut stays f32
@@ -947,32 +942,6 @@ int toc3d_gather_merge_ln_split(int dtype, const float* x, int64_t C, const int3
     return TOC3D_OK;
 }
 
-#ifdef TOC3D_EXPERIMENTAL
-int toc3d_gather_merge_ln_pending(int dtype, float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
-                                  const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
-                                  const float* beta, float eps, float* shortcut, void* a_out, int64_t lda, int64_t kept_copy,
-                                  const int32_t* prev_inverse, const float* prev_slow, const float* rep_raw1, const float* rep_raw2,
-                                  const float* rep_raw3, const float* rep_raw4, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(x && tok && wgt && crow_tok && rep_row && gamma && beta && shortcut && a_out, "toc3d_gather_merge_ln_pending: null buffer");
-    TOC3D_REQUIRE(prev_inverse && prev_slow && rep_raw1 && rep_raw2, "toc3d_gather_merge_ln_pending: the pending scatter needs its inverse map, compact rows and two updates");
-    TOC3D_REQUIRE((rep_raw3 == nullptr) == (rep_raw4 == nullptr), "toc3d_gather_merge_ln_pending: rep_raw3 and rep_raw4 come as a pair");
-    TOC3D_REQUIRE(prev_slow != shortcut, "toc3d_gather_merge_ln_pending: the previous compact rows are read while `shortcut` is written: two buffers");
-    TOC3D_REQUIRE(dtype == TOC3D_BF16 || dtype == TOC3D_F32, "toc3d_gather_merge_ln_pending: bf16 / f32 only (the planes form has no pending-scatter kernel: it would silently drop the scatter)");
-    TOC3D_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "toc3d_gather_merge_ln_pending: C=%lld must be a multiple of 4 and <= 1024", (long long)C);
-    TOC3D_REQUIRE(k >= 0 && k < N && lda >= C && lda % 4 == 0 && rows >= nW && N - k <= 1024, "toc3d_gather_merge_ln_pending: bad k / lda / rows");
-    if (nW <= 0) return TOC3D_OK;
-    return launch_gather(dtype, x, C, tok, wgt, crow_tok, rep_row, nW, N, k, rows, gamma, beta, eps, shortcut, a_out, lda, kept_copy,
-                         PendingScatter{prev_inverse, prev_slow, rep_raw1, rep_raw2, rep_raw3, rep_raw4, x}, stream);
-}
-
-int toc3d_token_inverse_map(const int32_t* tok, const int32_t* prow, int64_t nW, int64_t N, int64_t k, int32_t* inverse, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(tok && prow && inverse && k >= 0 && k < N, "toc3d_token_inverse_map: bad arguments");
-    if (nW <= 0 || N <= 0) return TOC3D_OK;
-    toc3d_launch(token_inverse_map_kernel, dim3((unsigned)((nW * N + 255) / 256)), dim3(256), 0, as_stream(stream), tok, prow, (int)nW, (int)N, (int)k, inverse);
-    TOC3D_LAUNCH_CHECK("toc3d_token_inverse_map");
-    return TOC3D_OK;
-}
-#endif  // TOC3D_EXPERIMENTAL
 
 int toc3d_gather_merge_ln(int dtype, const float* x, int64_t C, const int32_t* tok, const float* wgt, const int32_t* crow_tok,
                           const int32_t* rep_row, int64_t nW, int64_t N, int64_t k, int64_t rows, const float* gamma,
@@ -1026,23 +995,6 @@ int toc3d_copy_bytes(void* dst, const void* src, int64_t nbytes, toc3d_stream_t 
     return TOC3D_OK;
 }
 
-#ifdef TOC3D_EXPERIMENTAL
-int toc3d_prefetch(int64_t n, const void* const* ptrs, const int64_t* nbytes, int64_t workgroups, toc3d_stream_t stream) {
-    TOC3D_REQUIRE(n >= 0 && n <= PREFETCH_MAX_SEGS && (n == 0 || (ptrs && nbytes)), "toc3d_prefetch: 0 <= n <= %d buffers, host arrays of n entries", PREFETCH_MAX_SEGS);
-    if (n == 0) return TOC3D_OK;
-    PrefetchSegs sg;
-    for (int64_t i = 0; i < n; ++i) {
-        TOC3D_REQUIRE(nbytes[i] >= 0 && (nbytes[i] == 0 || ptrs[i]) && ((uintptr_t)ptrs[i] % 16) == 0, "toc3d_prefetch: buffer %lld must be 16-byte aligned", (long long)i);
-        sg.ptr[i] = (const f32x4*)ptrs[i];
-        sg.n16[i] = nbytes[i] / 16;
-    }
-    int64_t wg = workgroups > 0 ? workgroups : 16;
-    wg = wg > 256 ? 256 : wg;
-    toc3d_launch(prefetch_kernel, dim3((unsigned)wg, (unsigned)n), dim3(256), 0, as_stream(stream), sg, (float*)nullptr);
-    TOC3D_LAUNCH_CHECK("toc3d_prefetch");
-    return TOC3D_OK;
-}
-#endif  // TOC3D_EXPERIMENTAL
 
 int toc3d_copy_segments(int64_t n, void* const* dst, const void* const* src, const int64_t* nbytes, toc3d_stream_t stream) {
     TOC3D_REQUIRE(n >= 0 && n <= COPY_MAX_SEGS && (n == 0 || (dst && src && nbytes)), "toc3d_copy_segments: 0 <= n <= %d segments, host arrays of n entries", COPY_MAX_SEGS);

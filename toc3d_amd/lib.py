@@ -11,24 +11,23 @@ import re
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so"))       # TOC3D_LIB: an experimental build beside the shipped one
+LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so"))       # TOC3D_LIB: a development build beside the shipped one (library A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
 ABI_VERSION = 7                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
 F32, BF16, F32X3, F32X6, F32X3W, F32X3P, F32X3WO, F32X3WA = 0, 1, 2, 3, 4, 5, 6, 7          # F32X3: linear layers only -- f32 buffers, products as three bf16 MFMAs (include/toc3d.h)
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-EPI_RESIDUAL_ACT, EPI_SWIGLU_LNSELF, EPI_RESIDUAL_LNSELF, EPI_QKV_ROPE_LNSELF = 10, 11, 12, 13
 # q scale of the pre-rotated attention path (toc3d_linear_qkv_rope -> toc3d_window_attention_rot, head_dim 64): head_dim^-0.5 (eva_vit.py:104-109) times log2(e) --
 # that kernel's softmax is exp2-based (include/toc3d.h), so the conversion factor rides on the multiply the epilogue does anyway
 ATTN_ROT_Q_SCALE = 64 ** -0.5 * 1.4426950408889634
 NO_FUSED = (None, 0, None, 0, None, 0, 0.0, None, 0, None)     # the ten extra arguments of toc3d_linear_fused for epilogues 0-3
 # GEMM tile variants (mod 100; + 100 / 200 / 300 select the XCD order at run time) the product library carries: every variant the autotuner may pick or a
-# shipped table names.  EXPERIMENTAL=1 builds add the rest (csrc/gemm_kernels.h launch_epi).
+# shipped table names (csrc/gemm_kernels.h launch_epi).
 PRODUCT_VARIANTS = (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28, 29, 30, 33, 45, 47, 49, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66)
 
 
 def has_variant(v: int) -> bool:
-    return experimental() or (v % 100) in PRODUCT_VARIANTS
+    return (v % 100) in PRODUCT_VARIANTS
 
 _P, _I64, _I, _F = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
@@ -89,39 +88,19 @@ _SIGS = {
     "toc3d_plan_end": "pi",
     "toc3d_plan_run": "pp",
 }
-# entry points that exist only in `make EXPERIMENTAL=1` builds (include/toc3d.h, #ifdef TOC3D_EXPERIMENTAL): bound when the loaded library has them
-_SIGS_EXPERIMENTAL = {
-    "toc3d_linear_chain": "iilpplpllp",
-    "toc3d_linear_chain_trace": "pl",
-    "toc3d_linear_qkv_rope_ln": "iiplplppllllpplfplfp",
-    "toc3d_gather_merge_ln_pending": "iplppppllllppfppll" + "pppppp" + "p",
-    "toc3d_token_inverse_map": "pplllpp",
-    "toc3d_prefetch": "lpplp",
-}
 _CT = {"p": _P, "l": _I64, "i": _I, "f": _F, "L": ctypes.c_uint64}
 
 _lib = None
 
 
-def header_text(experimental: bool) -> str:
-    """include/toc3d.h without comments; the `#ifdef TOC3D_EXPERIMENTAL` blocks kept only when ``experimental``."""
-    txt = open(HEADER_PATH).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    if not experimental:
-        txt = re.sub(r"#ifdef TOC3D_EXPERIMENTAL.*?#endif", "", txt, flags=re.S)
-    return txt
+def header_text() -> str:
+    """include/toc3d.h without comments."""
+    return re.sub(r"/\*.*?\*/", "", open(HEADER_PATH).read(), flags=re.S)
 
 
-def header_functions(experimental: bool = None):
-    """Names of all functions declared in include/toc3d.h for this build flavour (used by the symbol-export test)."""
-    if experimental is None:
-        experimental = globals()["experimental"]()
-    return sorted(set(re.findall(r"\b(toc3d_\w+)\s*\(", header_text(experimental))))
-
-
-def experimental() -> bool:
-    """The loaded library is an EXPERIMENTAL=1 build (it exports the entry points of the `#ifdef TOC3D_EXPERIMENTAL` blocks)."""
-    return hasattr(load(), "toc3d_linear_chain")
+def header_functions():
+    """Names of all functions declared in include/toc3d.h (used by the symbol-export test)."""
+    return sorted(set(re.findall(r"\b(toc3d_\w+)\s*\(", header_text())))
 
 
 def load():
@@ -139,7 +118,7 @@ def load():
     except AttributeError:
         abi = None
     if abi != ABI_VERSION:
-        # checked BEFORE any symbol is bound: an older / experimental build (TOC3D_LIB) fails here with a message, not with a bare
+        # checked BEFORE any symbol is bound: an older build (TOC3D_LIB) fails here with a message, not with a bare
         # AttributeError on the first entry point it lacks
         raise RuntimeError(f"{LIB_PATH} reports ABI version {abi}, this package binds ABI {ABI_VERSION} (include/toc3d.h): "
                            "rebuild the library (`make -C toc3d_amd/csrc`)")
@@ -158,7 +137,7 @@ def load():
     if hasattr(lib, "toc3d_linear_chain_info"):
         lib.toc3d_linear_chain_info.restype = _I        # number of ops (< 0: unknown config), not an error code
         lib.toc3d_linear_chain_info.argtypes = [_I, _P]
-    for name, sig in list(_SIGS.items()) + [(n, s_) for n, s_ in _SIGS_EXPERIMENTAL.items() if hasattr(lib, n)]:
+    for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = _I
         fn.argtypes = [_CT[c] for c in sig]
@@ -228,99 +207,3 @@ def stream_ptr():
 
 def recording() -> bool:
     return rec_lane() is not None
-
-
-# ---- GEMM chains (include/toc3d.h, toc3d_linear_chain; EXPERIMENTAL builds only) ---------------------------------------------------------------------
-CHAIN_STATE_BYTES = 3616
-CHAIN_MAX_BANDS, CHAIN_MAX_MT = 64, 256
-
-
-class ChainOp(ctypes.Structure):
-    """toc3d_chain_op_t: one toc3d_linear_fused call of a chain."""
-    _fields_ = [("epilogue", _I64), ("A", _P), ("lda", _I64), ("W", _P), ("ldw", _I64), ("bias", _P), ("out", _P), ("ldo", _I64),
-                ("residual", _P), ("ldr", _I64), ("rep_out", _P), ("rep_index", _P), ("M", _I64), ("N", _I64), ("K", _I64), ("n_valid", _I64),
-                ("stats_out", _P), ("stats_out_cap", _I64), ("stats_in", _P), ("stats_in_cap", _I64), ("col_sums", _P), ("ln_n", _I64),
-                ("ln_eps", ctypes.c_double), ("out_act", _P), ("ld_act", _I64), ("residual_index", _P)]
-
-
-def chain_op(epi, A, lda, W, ldw, bias, out, ldo, res, ldr, rep_out, rep_index, M, N, K, n_valid, fused=NO_FUSED):
-    """The arguments of toc3d_linear_fused (without dtype / variant / residual_row_mod / stream) as one chain op."""
-    so, so_cap, si, si_cap, c1, ln_n, ln_eps, out_act, ld_act, res_index = fused
-    return ChainOp(epi, _conv(A), lda, _conv(W), ldw, _conv(bias), _conv(out), ldo, _conv(res), ldr, _conv(rep_out), _conv(rep_index), M, N, K, n_valid,
-                   _conv(so), so_cap, _conv(si), si_cap, _conv(c1), ln_n, ln_eps, _conv(out_act), ld_act, _conv(res_index))
-
-
-def chain_info(config):
-    """[(epilogue, tile rows, tile columns, threads)] per op of a chain config, or None for an unknown config."""
-    info = (ctypes.c_int32 * 12)()
-    n = load().toc3d_linear_chain_info(config, info)
-    return None if n < 0 else [tuple(info[4 * i:4 * i + 4]) for i in range(n)]
-
-
-def chain_schedule(config, M, Ns, n_bands=8, lag=1, n_major=()):
-    """Tile lists of toc3d_linear_chain as a flat int32 list: the M-tiles are cut into ``n_bands`` contiguous bands (in units of the tallest tile of
-    the chain, so that a row panel never straddles two bands); inside a band: every tile of op 0 (M-tile major), then the tiles of op i for the band's
-    panels one after the other, the tiles of op i + 1 for panel p following ``lag`` panels behind their producers (they are complete, or about to
-    be, when a workgroup reaches them).  ``n_major``: ops whose tiles run N-tile major across the band's panels (one W column panel serves all
-    row panels of the band from the L2) -- then every tile of the next op waits for the whole band.  Returns (list, n_bands)."""
-    info = chain_info(config)
-    assert info is not None and len(info) == len(Ns)
-    bms = [i[1] for i in info]
-    bns = [i[2] for i in info]
-    big = max(bms)
-    panels = -(-M // big)
-    n_bands = max(1, min(n_bands, panels, CHAIN_MAX_BANDS))
-    tiles = [[] for _ in range(n_bands)]
-    for b in range(n_bands):
-        p0, p1 = b * panels // n_bands, (b + 1) * panels // n_bands           # panels of height `big`
-        r0, r1 = p0 * big, min(M, p1 * big)
-        if r1 <= r0:
-            continue
-        mts = [list(range(r0 // bm, -(-r1 // bm))) for bm in bms]            # M-tiles of every op inside the band
-        tn = [-(-n // bn) for n, bn in zip(Ns, bns)]
-        seq = []
-
-        def emit(op, mt_list):
-            if op in n_major:
-                for nt in range(tn[op]):
-                    for mt in mt_list:
-                        seq.append(op << 28 | mt << 16 | nt)
-            else:
-                for mt in mt_list:
-                    for nt in range(tn[op]):
-                        seq.append(op << 28 | mt << 16 | nt)
-        # groups of M-tiles per panel of height `big`
-        groups = [[[mt for mt in mts[op] if mt * bms[op] // big == p] for p in range(p0, p1)] for op in range(len(Ns))]
-        npan = p1 - p0
-        emit(0, mts[0])
-        # ops 1..: staggered by `lag` panels
-        steps = npan + lag * (len(Ns) - 2) if len(Ns) > 1 else 0
-        for t in range(steps):
-            for op in range(1, len(Ns)):
-                q = t - lag * (op - 1)
-                if 0 <= q < npan:
-                    if op in n_major or (op - 1) in n_major:
-                        continue
-                    emit(op, groups[op][q])
-        for op in range(1, len(Ns)):
-            if op in n_major or (op - 1) in n_major:
-                emit(op, mts[op])
-        tiles[b] = seq
-    tiles = [t for t in tiles if t]
-    head, flat, off = [], [], 2 * len(tiles)
-    for t in tiles:
-        head += [off, len(t)]
-        off += len(t)
-        flat += t
-    return head + flat, len(tiles)
-
-
-def linear_chain(dtype, config, ops, schedule, n_bands, state, grid, flags, stream):
-    arr = (ChainOp * len(ops))(*ops)
-    call("toc3d_linear_chain", dtype, config, len(ops), ctypes.addressof(arr), schedule, n_bands, state, grid, flags, stream)
-
-
-def chain_status(state) -> int:
-    """Sticky error word of a chain state buffer (0: every bounded wait of every launch so far was satisfied; 1: a wait gave up -- the outputs of that
-    launch are WRONG, not late; 2: bad schedule entry).  The launch itself returns TOC3D_OK in all cases: callers poll this at their sync points."""
-    return int(state.view(-1).view(__import__("torch").int32)[1].item())

@@ -169,22 +169,32 @@ def _draw(name: str, shape, seed: int) -> np.ndarray:
 STRESS_CHANNELS = (5, 64, 337, 512, 771, 960)
 
 
-def _stress(sd, cfg):
+STRESS_GAIN, STRESS_ROWS = 30.0, 40.0
+
+
+def _stress(sd, cfg, gain=None, rows=None):
+    """Out of place: the tensors of ``sd`` may be shared with a cache of the plain draw (tests/conftest.py)."""
+    gain, rows = STRESS_GAIN if gain is None else gain, STRESS_ROWS if rows is None else rows
     C = cfg["embed_dim"]
     oc = torch.tensor([c % C for c in STRESS_CHANNELS])
+
+    def scaled(key, idx, f):
+        t = sd[key].clone()
+        t[idx] *= f
+        sd[key] = t
     for i in range(cfg["depth"]):
-        sd[f"blocks.{i}.norm1.weight"][oc] *= 30.0
-        sd[f"blocks.{i}.norm2.weight"][oc[:3]] *= 30.0
+        scaled(f"blocks.{i}.norm1.weight", oc, gain)
+        scaled(f"blocks.{i}.norm2.weight", oc[:3], gain)
         if i in (1, 2):
-            sd[f"blocks.{i}.attn.proj.weight"][oc] *= 40.0
+            scaled(f"blocks.{i}.attn.proj.weight", oc, rows)
         if i in (2, 3):
-            sd[f"blocks.{i}.mlp.w3.weight"][oc] *= 40.0
+            scaled(f"blocks.{i}.mlp.w3.weight", oc, rows)
     return sd
 
 
-def make_state_dict(cfg, seed: int = 0, device="cpu", stress: bool = False) -> "OrderedDict[str, torch.Tensor]":
+def make_state_dict(cfg, seed: int = 0, device="cpu", stress=False) -> "OrderedDict[str, torch.Tensor]":
     if stress:
-        sd = _stress(make_state_dict(cfg, seed, "cpu"), cfg)
+        sd = _stress(OrderedDict(make_state_dict(cfg, seed, "cpu")), cfg, *(stress if isinstance(stress, tuple) else ()))
         return OrderedDict((k, v.to(device)) for k, v in sd.items())
     spec = state_dict_spec(cfg)
     hd = cfg["embed_dim"] // cfg["num_heads"]
