@@ -197,7 +197,7 @@ def test_view_groups_on_separate_streams_are_bit_identical(name):
 def test_repeated_forwards_are_bit_identical(name, groups, instances, vpf):
     """Same weights, same inputs, same injected noise: every forward returns the same bits -- across freshly built
     models (new stream objects / allocations) and with view groups overlapping on separate streams.  Regression for the
-    packed-FP32 erratum that made ~40% of the two-group bf16 runs differ in the last bits."""
+    packed-FP32 erratum (LABNOTES.md) that made ~40% of the two-group bf16 runs differ in the last bits."""
     ref = None
     for _ in range(instances):
         cfg, m = build(name, "bf16")

@@ -208,7 +208,7 @@ def test_window_attention_dense_with_virtual_pads(name, dt, tdt, L):
 
 @pytest.mark.parametrize("name,dt,tdt", DTYPES)
 def test_window_attention_is_bit_stable_with_co_resident_workgroups(name, dt, tdt):
-    """Regression for the packed-FP32 erratum: with more attention workgroups than CUs (several per CU) the
+    """Regression for the packed-FP32 erratum (LABNOTES.md): with more attention workgroups than CUs (several per CU) the
     bf16 kernel built with v_pk_fma_f32 returned slightly different K tiles from launch to launch.  Same inputs, many
     launches, every output must be bit-identical -- and equal to the launch made on an otherwise idle GPU."""
     V, h, w, L, C, heads = 12, 20, 50, 16, 128, 2
@@ -626,7 +626,7 @@ def test_phased_tiles_every_ktile_count_and_bit_stable_under_load(K):
 @pytest.mark.parametrize("name,dt,tdt", DTYPES)
 def test_linear_is_bit_stable_under_load(name, dt, tdt):
     """The GEMM keeps packed-FP32 instructions in its epilogues (csrc/Makefile); the erratum seen in the attention kernel
-     must not touch it: every epilogue, at ViT-L sizes with several workgroups per CU and the attention kernel
+    (LABNOTES.md) must not touch it: every epilogue, at ViT-L sizes with several workgroups per CU and the attention kernel
     running beside it on a second stream, gives the same bits on every launch."""
     M, C, Hd = 6000, 1024, 2730
     Hp = ru(Hd, 64)
@@ -762,7 +762,7 @@ def test_linear_unaligned_outputs_take_the_scalar_epilogue(name, dt, tdt):
 def test_every_tuned_gemm_pipeline_is_bit_stable_beside_attention(variant):
     """Each K-loop flavour the autotuner may pick (single buffer, rings of 2-4 stages, K-tiles of 32 / 64 / 128 / 256, 4 and 8
     wavefronts, banded order) launched repeatedly while the flash-attention kernel of another stream shares the CUs: regression
-    for the raw-barrier scheduling race of the single-buffer loop, which only showed under that kind of co-residency."""
+    for the raw-barrier scheduling race of the single-buffer loop (LABNOTES.md), which only showed under that kind of co-residency."""
     dt, tdt = lib.BF16, torch.bfloat16
     M, C, N = 6000, 1024, 3072
     a_d = as_act(rnd(M, C, seed=1), tdt)

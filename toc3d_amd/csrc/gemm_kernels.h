@@ -1050,7 +1050,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     if constexpr (PIPE) {
         // Register-pipelined ring (round 5) for the launches that run ONE workgroup per CU (N = 1024 at M < 6000: 176-392 tiles).  The loop below this one reads a K step's
         // fragments and then multiplies them, every wave in step between two barriers: with no second workgroup on the CU the matrix pipe idles through every LDS round trip
-        // (deep rings at one workgroup per CU ran at half the rate of single buffers at four).  Here a wave holds TWO fragment sets: the reads of K step
+        // (deep rings at one workgroup per CU ran at half the rate of single buffers at four, LABNOTES.md).  Here a wave holds TWO fragment sets: the reads of K step
         // (kt, 1) are issued in front of the MFMAs of (kt, 0), those of (kt + 1, 0) in front of the MFMAs of (kt, 1) -- the barrier that publishes tile kt + 1 therefore sits in
         // the MIDDLE of K-tile kt, half a tile earlier than in the plain ring (one tile less may stay in flight: STAGES >= 3, meant for 4).
         //   RAW: tile kt + 1 is read behind the counted wait + barrier of K-tile kt.
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_kernel(GemmArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // Phased big-tile kernel (bf16): BM x BN per 512-thread workgroup, ONE workgroup per CU, latency hidden inside the workgroup.
 //
-// The 128x128 family above is bound by the L2 -> LDS fill rate (32 KB per 2.1 MFLOP K-step) and hides
+// The 128x128 family above is bound by the L2 -> LDS fill rate (32 KB per 2.1 MFLOP K-step, LABNOTES.md) and hides
 // latency only through co-resident workgroups.  Here a K-step of a 256x256 tile brings 64 KB for 8.4 MFLOP (half the bytes per
 // FLOP), every wavefront owns a 128x64 block (half the LDS read bytes per FLOP of the 64x32 blocks above), and the K loop is
 // cut into four *phases* per 64-deep K-tile (cdna_hip_programming.md "8-phase" template, re-derived for this ring):
