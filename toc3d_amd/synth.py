@@ -164,12 +164,13 @@ def _draw(name: str, shape, seed: int) -> np.ndarray:
 
 # Stress statistics: trained ViTs carry "massive activations" -- a handful of residual-stream channels tens of times wider than the rest, LayerNorm
 # gains that single channels out, a few tokens of very large norm -- which N(0, sigma^2) weights never produce.  stress=True plants that pattern into the same seeded
-# draw: six outlier channels whose norm1 gain is x30 in every block (norm2: the first three), whose attention-projection rows are x40 in blocks 1-2 and whose w3 rows are
-# x40 in blocks 2-3 (they write into the residual stream); make_inputs(stress=True) scales four patches per view by 8 (token norms ~1.6e2 against ~2e1).
+# draw: six outlier channels whose norm1 gain is x STRESS_GAIN in every block (norm2: the first three), whose attention-projection rows are x STRESS_ROWS in blocks 1-2 and
+# whose w3 rows are x STRESS_ROWS in blocks 2-3 (they write into the residual stream: output channel abs-max 391 against a median of 18); make_inputs(stress=True) scales
+# four patches per view by 8.
 STRESS_CHANNELS = (5, 64, 337, 512, 771, 960)
 
 
-STRESS_GAIN, STRESS_ROWS = 30.0, 40.0
+STRESS_GAIN, STRESS_ROWS = 3.0, 100.0      # (chosen so that the reference itself is well conditioned: its fp32 forward stands 5.7e-5 from its f64 forward with identical kept lists; x30 gains make the reference's OWN fp32 run flip selections: LABNOTES round 6)
 
 
 def _stress(sd, cfg, gain=None, rows=None):
