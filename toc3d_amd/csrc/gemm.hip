@@ -311,7 +311,7 @@ static int fused_args(GemmArgs& a, int dtype, int epilogue, const void* A, int64
     a = GemmArgs{A, lda, W, ldw, bias, out, ldo, residual, ldr, (int)residual_row_mod, residual_index, rep_out, rep_index,
                (int)M, (int)N, (int)K, (int)n_valid, 0, vec ? 1 : 0, vec8 ? 1 : 0,
                stats_out, (int)stats_out_cap, stats_in, (int)(stats_in_cap & 0xffffffff), (int)(stats_in_cap >> 32), col_sums, ln_n > 0 ? (float)(1.0 / (double)ln_n) : 0.f, ln_eps, out_act, ld_act,
-               0, 0, nullptr, nullptr, nullptr, 0, 1.0f, planes_a, planes, planes_o};
+               0, 0, nullptr, nullptr, nullptr, 0, 1.0f, planes_a, planes, planes_o, 0, nullptr, nullptr, dtype == TOC3D_F32X3 ? 1 : 0};
     if (planes) {
         TOC3D_REQUIRE(epilogue != TOC3D_EPI_CONV3X3 || !planes_a, "toc3d_linear: the 3x3 conv gathers f32 activations (A cannot be planes)");
         const void* act_copy = epilogue == TOC3D_EPI_CONV3X3 ? nullptr : out_act;     // (the conv carries its zero line and h << 32 | w in these two slots)

@@ -14,7 +14,7 @@ cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 10 --warmup
 
 
 def family(name):
-    for key in ("gemm_chain_kernel", "gemm_phased_kernel", "gemm_kernel", "attn_rot_kernel", "attn_small_kernel", "attn_kernel", "ln_rows_kernel", "ln_act_kernel", "ln_rebase_kernel", "gather_merge_ln_kernel", "scatter_update_kernel",
+    for key in ("gemm_phased_kernel", "gemm_kernel", "attn_rot_x3_kernel", "attn_rot_kernel", "attn_small_kernel", "attn_kernel", "ln_rows_kernel", "ln_act_kernel", "ln_rebase_kernel", "gather_merge_ln_kernel", "scatter_update_kernel",
                 "window_topk_kernel", "rank_desc_kernel", "motion_queries_kernel", "collapse_kernel", "score_tokens_kernel", "im2col", "nhwc_to_nchw",
                 "abs_pos", "pack_", "window_map_dense", "score_head", "global_mean_half", "copy_segments", "copy_bytes", "prefetch"):
         if key in name:
