@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TOC3D_ABI_VERSION 7   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
+#define TOC3D_ABI_VERSION 8   /* bumped whenever entry points are added or changed; toc3d_amd/lib.py checks it before binding symbols */
 
 #define TOC3D_OK 0
 #define TOC3D_ERR_ARG (-1)
@@ -308,8 +308,11 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
                       int32_t* arows, int32_t* aslots, int32_t* acount_q, int32_t* acount_k, int32_t* crow_rc, toc3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * Pre-rotated attention (bf16 path, round 3): RoPE and the q scale move from the attention kernel into the q|k|v projection's epilogue, so the
- * attention kernel stages K and V by DMA (global_load_lds) with no arithmetic at all.
+ * Pre-rotated attention (bf16 path, round 3; bf16 x 3 on (hi, lo) planes, round 6): RoPE and the q scale move from the attention kernel into the q|k|v projection's
+ * epilogue, so the attention kernel stages K and V by DMA (global_load_lds) with no arithmetic at all.  dtype = TOC3D_DTYPE_BF16, or for precision "fp32x3":
+ * toc3d_linear_qkv_rope with TOC3D_DTYPE_F32X3P (A and W in planes) / F32X3WO (A plain f32, W in planes) writes q | k | v as planes (ldo % 32 == 0, 128-byte aligned), and
+ * toc3d_window_attention_rot with TOC3D_DTYPE_F32X3P reads them and writes `out` as planes (leading dimensions in f32 elements; both contractions as bf16 x 3 products,
+ * f32 softmax statistics and accumulation; windows of up to 1024 keys -- over 288 keys in 128-key super-tiles; no weight prefetch on this form).
  * toc3d_linear_qkv_rope: out act [M, ldo >= N] = [rope(q) * q_scale | rope(k) | v] for the fused projection W = [q; k; v] packed by
  *   toc3d_pack_weight (N = 3C, heads of 64 dims; backbones/eva_vit.py:97-109, toc3d_eva_vit.py:495-508, eva_utils.py:378-379).  Row m is rotated by
  *   the table rows rope_rc[m] = r << 16 | c: dims 0..31 of every head by row r of the first table half, dims 32..63 by row c of the second
@@ -325,6 +328,7 @@ int toc3d_window_topk(const float* scores, int64_t V, int64_t h, int64_t w, int6
  *   (as for toc3d_window_attention_pf; prefetch_workgroups != 0 enables them) are pulled through the caches by the attention wavefronts
  *   themselves, a few KB each by LDS-DMA while they compute -- no extra workgroups.
  */
+float toc3d_attn_rot_q_scale(int64_t head_dim);   /* the q_scale to pass for buffers toc3d_window_attention_rot reads: head_dim^-0.5 * log2(e) */
 int toc3d_linear_qkv_rope(int dtype, int variant, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
                           int64_t M, int64_t N, int64_t K, const int32_t* rope_rc, const float* rope_tab, int64_t rope_side,
                           float q_scale, toc3d_stream_t stream);

@@ -320,6 +320,23 @@ def test_header_constants_match_the_python_binding():
     for k, v in py.items():
         if k.startswith("TOC3D_DTYPE_"):
             assert enum.get("TOC3D_" + k[len("TOC3D_DTYPE_"):]) == v, (k, enum)
+    # the q scale of the pre-rotated attention path is the LIBRARY's convention (exp2-based softmax): the Python constant must be what it reports
+    assert abs(lib.load().toc3d_attn_rot_q_scale(64) - lib.ATTN_ROT_Q_SCALE) < 1e-7 * lib.ATTN_ROT_Q_SCALE
+
+
+def test_backbone_survives_pickles_written_before_gumbel_seed_became_a_property():
+    """a whole-module pickle from before the property carries `gumbel_seed` in __dict__ and no `_gumbel_seed`; reading the property then raised through
+    nn.Module.__getattr__.  __setstate__ migrates the entry; the class carries defaults."""
+    import copy
+    import pickle
+    m = toc3d_amd.build_backbone(dict(configs.get("toc3d_tiny")))
+    m.gumbel_seed = 1234
+    st = m.__getstate__()
+    st["gumbel_seed"] = st.pop("_gumbel_seed")                 # the old layout
+    old = m.__class__.__new__(m.__class__)
+    old.__setstate__(st)
+    assert old.gumbel_seed == 1234 and "gumbel_seed" not in old.__dict__
+    assert pickle.loads(pickle.dumps(m)).gumbel_seed == 1234 and copy.deepcopy(m).gumbel_seed == 1234
 
 
 def test_unchanged_reference_config_builds_the_parity_grade_precision():

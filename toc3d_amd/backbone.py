@@ -275,12 +275,13 @@ def tuned_linear(self, epi, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, r
         # measured slower on every launch of the frame, profiles/r05_splitk.txt).  One zeroed workspace per owner and stream: launches on one lane share it.
         need = int(lib.load().toc3d_linear_splitk_workspace_bytes(var, M, N))
         pool = self.__dict__.setdefault("_sk_ws", {})
+        s = (out.device.index, s)                     # (the default stream's handle is 0 on every device: ADVICE r05)
         ws = pool.get(s)
         if ws is None or ws.numel() * 4 < need:
             if ws is not None:
                 self.__dict__.setdefault("_sk_ws_old", []).append(ws)      # recorded plans may still name it
             ws = pool[s] = torch.zeros((need + 3) // 4, dtype=torch.int32, device=out.device)
-        lib.call("toc3d_linear_fused_ws", dtg, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, ws, ws.numel() * 4, s)
+        lib.call("toc3d_linear_fused_ws", dtg, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, ws, ws.numel() * 4, s[1])
         return
     lib.call("toc3d_linear_fused", dtg, epi, var, A, lda, W, ldw, bias, out, ldo, res, ldr, res_mod, rep_out, rep_index, M, N, K, n_valid, *fused, s)
 
@@ -350,16 +351,19 @@ class _BackboneBase(nn.Module):
     def _load_from_state_dict(self, *a, **k):
         self._packed = None
         self._plans = {}                # recorded launch plans point into the packed weights
+        self.__dict__.pop("_sk_ws", None), self.__dict__.pop("_sk_ws_old", None)      # split-K workspaces belong to the dropped plans' device
         return super()._load_from_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
         self._packed = None
         self._plans = {}                # (the Gumbel frame counter survives: plans on the same device keep naming it, _rng_state carries its value to a new one)
+        self.__dict__.pop("_sk_ws", None), self.__dict__.pop("_sk_ws_old", None)      # split-K workspaces belong to the dropped plans' device
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = None
         self._plans = {}
+        self.__dict__.pop("_sk_ws", None), self.__dict__.pop("_sk_ws_old", None)      # split-K workspaces belong to the dropped plans' device
         return super().load_state_dict(*a, **k)
 
     # -- copies / pickles: recorded launch plans (native handles with baked device pointers), workspaces and packed weights belong to
@@ -377,6 +381,13 @@ class _BackboneBase(nn.Module):
             # of a model that has run share their noise; assign a different gumbel_seed to a replica that needs its own stream.
             d["_gumbel_rng"] = d["_gumbel_rng"].detach().to("cpu").clone()
         return d
+
+    def __setstate__(self, d):
+        # pickles written before `gumbel_seed` became a property carry the plain attribute
+        if "gumbel_seed" in d and "_gumbel_seed" not in d:
+            d = dict(d)
+            d["_gumbel_seed"] = d.pop("gumbel_seed")
+        self.__dict__.update(d)
 
     def __deepcopy__(self, memo):
         import copy
@@ -859,6 +870,8 @@ class EVA_ViT(_BackboneBase):
 
 class ToC3DEVAViT(_BackboneBase):
     """EVA-02 ViT with ToC3D motion-query-guided token compression, reference ``toc3d_eva_vit.py:25-326``."""
+    _gumbel_seed = None              # (class defaults: an instance restored from an old pickle finds them)
+    _gumbel_rng = None
 
     def __init__(self, img_size=1024, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4 * 2 / 3,
                  qkv_bias=True, drop_path_rate=0.0, norm_layer=partial(nn.LayerNorm, eps=1e-6), act_layer=nn.GELU,

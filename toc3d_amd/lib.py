@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("TOC3D_LIB", "libtoc3d_gfx950.so"))       # TOC3D_LIB: a development build beside the shipped one (library A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "toc3d.h")
 
-ABI_VERSION = 7                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
+ABI_VERSION = 8                 # == TOC3D_ABI_VERSION of include/toc3d.h (tests/test_cpu_abi.py cross-checks)
 F32, BF16, F32X3, F32X6, F32X3W, F32X3P, F32X3WO, F32X3WA = 0, 1, 2, 3, 4, 5, 6, 7          # F32X3: linear layers only -- f32 buffers, products as three bf16 MFMAs (include/toc3d.h)
 EPI_BIAS, EPI_RESIDUAL, EPI_SWIGLU, EPI_GELU, EPI_SWIGLU_STATS, EPI_RESIDUAL_LN, EPI_RESIDUAL_STATS, EPI_SWIGLU_STATS_LN, EPI_CONV3X3, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 # q scale of the pre-rotated attention path (toc3d_linear_qkv_rope -> toc3d_window_attention_rot, head_dim 64): head_dim^-0.5 (eva_vit.py:104-109) times log2(e) --
@@ -123,6 +123,8 @@ def load():
         raise RuntimeError(f"{LIB_PATH} reports ABI version {abi}, this package binds ABI {ABI_VERSION} (include/toc3d.h): "
                            "rebuild the library (`make -C toc3d_amd/csrc`)")
     lib.toc3d_last_error.restype = ctypes.c_char_p
+    lib.toc3d_attn_rot_q_scale.restype = _F
+    lib.toc3d_attn_rot_q_scale.argtypes = [_I64]
     lib.toc3d_motion_weights_floats.restype = _I64
     lib.toc3d_window_topk_rows.restype = _I64
     lib.toc3d_window_topk_rows.argtypes = [_I64] * 5
