@@ -253,6 +253,37 @@ def test_rot_attention_is_bit_stable_and_rides_prefetch():
     assert bool(torch.isfinite(outs[0].float()).all()) and float(outs[0].float().abs().max()) > 0
 
 
+@pytest.mark.parametrize("L", [16, 20])
+def test_rot_attention_on_planes_is_bit_stable_with_co_resident_workgroups(L):
+    """The planes form under load: 12 views (96 / 36 windows x 2 heads, several workgroups per CU; L = 20: the 128-key super-tile kernel with its per-tile barriers and
+    restaging), repeated launches beside a GEMM stream on a second HIP stream: identical bits every time (the packed-FP32 erratum and the barrier-fence race of
+    LABNOTES.md were both found by this kind of test)."""
+    V, h, w, C, heads = 12, 20, 50, 128, 2
+    M, N = V * h * w, L * L
+    nW = V * (-(-h // L)) * (-(-w // L))
+    qkv = planes_encode(rnd(M, 3 * C, seed=3).to(DEV))
+    rows = torch.empty(nW, N, dtype=torch.int32, device=DEV)
+    slots, count, npad = torch.empty_like(rows), torch.empty(nW, dtype=torch.int32, device=DEV), torch.empty(nW, dtype=torch.int32, device=DEV)
+    lib.call("toc3d_window_map_dense", V, h, w, L, rows, slots, count, npad, S())
+    vb = rnd(C, seed=6).to(DEV)
+    big_a, big_w = as_act(rnd(4096, 1024, seed=24), TBF), pack(rnd(2048, 1024, seed=25, scale=1 / 32), BF, TBF)
+    big_o, big_b = torch.zeros(4096, 2048, dtype=TBF, device=DEV), torch.zeros(2048, device=DEV)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    outs = [torch.zeros(M, C, dtype=F32T, device=DEV) for _ in range(12)]
+    for i, o in enumerate(outs):
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    lib.call("toc3d_linear_ex", BF, lib.EPI_BIAS, 17, big_a, 1024, big_w, 1024, big_b, big_o, 2048, None, 0, 0, None, None, 4096, 2048, 1024, 0, S())
+        attn_rot("x3", qkv, C, o, rows, slots, count, None, npad, None, N, nW, int(count.max()), heads, vb)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int32), outs[0].view(torch.int32))
+    v = planes_decode(outs[0])
+    assert bool(torch.isfinite(v).all()) and float(v.abs().max()) > 0
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("n,np_pad", [(129, 0), (201, 0), (256, 0), (96, 160), (400, 0)])
 def test_rot_attention_deferred_rescale_is_the_exact_softmax(n, np_pad, prec):
