@@ -547,10 +547,7 @@ __global__ __launch_bounds__(1024, 4) void attn_rot_x3_kernel(AttnRotX3Args a) {
 
 void launch_rot_x3(AttnRotX3Args a, int64_t max_count, int64_t num_heads, int64_t nwin, hipStream_t s) {
     const int64_t nk32 = (a.stride + 31) / 32 * 32;
-#ifndef TOC3D_X3ROT_WHOLE_KB
-#define TOC3D_X3ROT_WHOLE_KB 144
-#endif
-    const bool multi = nk32 * 512 > TOC3D_X3ROT_WHOLE_KB * 1024;   // the window's K and V planes do not fit beside nothing else: walk it in super-tiles
+    const bool multi = nk32 * 512 > 144 * 1024;     // the window's K and V planes (512 B per key) do not fit one workgroup's LDS: walk the keys in super-tiles
     a.tile_keys = multi ? 128 : (int)nk32;          // (the super-tile kernel's staging is sized for 128 keys on 16 waves)
     const size_t lds = (size_t)a.tile_keys * 512;
     static Toc3dLdsAttr attr_s, attr_m;
