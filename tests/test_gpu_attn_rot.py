@@ -95,7 +95,7 @@ def test_qkv_projection_with_rope_in_the_epilogue_on_planes():
     assert relerr(planes_decode(out), ref) < 5e-5
     out_plain_a = qkv_rope(act_p(A, "x3", planes=False), w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L, prec="x3", a_planes=False)
     assert torch.equal(out_plain_a.view(torch.int32), out.view(torch.int32)), "A split in the kernel or delivered as planes: the same bits"
-    for v in (1, 8, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 52, 53, 60, 61, 62, 63, 116, 117, 149, 152, 160, 161):
+    for v in (1, 8, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 116, 117, 149, 152, 155, 160, 161):
         assert torch.equal(qkv_rope(act_p(A, "x3"), w_d, b.to(DEV), M, C, rc_of(slots, L), tab, L, v, prec="x3").view(torch.int32), out.view(torch.int32)), f"variant {v} differs"
 
 

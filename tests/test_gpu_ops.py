@@ -1253,7 +1253,7 @@ def test_bf16x3_on_planes_is_bit_identical_to_the_in_kernel_split():
                 else:
                     assert torch.equal(g_, r_), f"{tag} variant {v}: {n} differs from F32X3"
     # round 6: the phased big tiles on planes (gemm_phased_kernel, X3 -- both operands must be planes): the same bits again, every epilogue of the block half
-    for v in (60, 61, 62, 63, 160, 163):
+    for v in (60, 61, 62, 63, 160, 163, 54, 55, 56, 57, 58, 59, 155):      # (54-59: the 96- / 160-row tiles, whose partial DMA rounds the x3 form only takes on planes)
         got_p = half(2, v)
         for k, (n, g_, r_) in enumerate(zip(names, got_p, ref)):
             if k in (2, 4):
@@ -1262,6 +1262,8 @@ def test_bf16x3_on_planes_is_bit_identical_to_the_in_kernel_split():
                 assert torch.equal(g_, r_), f"F32X3P phased variant {v}: {n} differs from F32X3"
     with pytest.raises(RuntimeError):      # the phased x3 form stages planes as they lie: an f32 A operand is refused
         half(1, 60)
+    with pytest.raises(RuntimeError):      # ... and so are the 96-row tiles (their in-LDS split would need whole DMA rounds)
+        half(1, 55)
     with pytest.raises(RuntimeError):      # rows of planes are whole 32-element groups
         bad = torch.zeros(M, C + 8, device=DEV)
         lib.call("toc3d_linear_ex", lib.F32X3P, lib.EPI_BIAS, 16, bad, C + 8, to_planes(wproj), C, bp, torch.zeros(M, C, device=DEV), C, None, 0, 0, None, None, M, C, C, 0, S())

@@ -174,7 +174,7 @@ _VARIANTS = {lib.BF16: (1, 8, 9, 10, 13, 14, 15, 16, 17, 19, 22, 24, 26, 27, 28,
              lib.F32: (1, 8, 9, 10, 13, 14, 16, 17, 22, 26, 28, 33, 110, 126),
              lib.F32X3: (1, 8, 9, 10, 14, 16, 17, 19, 22, 26, 28, 29, 33, 45, 47, 49, 52, 53, 110, 114, 116, 117, 122, 126, 129, 145, 147, 149, 152)}
 # the phased big tiles on planes (round 6) need BOTH operands in planes: candidates of TOC3D_DTYPE_F32X3P only
-_VARIANTS_X3P = _VARIANTS[lib.F32X3] + (60, 61, 62, 63, 160, 161, 162, 163)
+_VARIANTS_X3P = _VARIANTS[lib.F32X3] + (54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 154, 155, 156, 158, 159, 160, 161, 162, 163)      # (54-59: the 96- / 160-row tiles, planes only too)
 _VARIANTS[lib.F32X6] = _VARIANTS[lib.F32X3W] = _VARIANTS[lib.F32X3WO] = _VARIANTS[lib.F32X3WA] = _VARIANTS[lib.F32X3]
 _VARIANTS[lib.F32X3P] = _VARIANTS_X3P
 

@@ -837,8 +837,10 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     constexpr int MT = TM / 16, NT = TN / 16;           // 16x16 MFMA tiles per wave
     constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;
     constexpr int LOADS = (BM * (RB / 16) + NTHR - 1) / NTHR + (BN * (RB / 16) + NTHR - 1) / NTHR;   // global_load_lds per thread per K-tile (stage_tile rounds up)
-    static_assert(((BM * (RB / 16)) % NTHR == 0 && (BN * (RB / 16)) % NTHR == 0) || (X3 == 0 && EPI != TOC3D_EPI_CONV3X3),
-                  "tiles with a partial DMA round: plain bf16 / f32 operand loaders only");
+    // tiles with a partial DMA round (96- / 160-row tiles): the plain operand loaders, and -- round 6 -- the bf16 x 3 form when BOTH operands arrive as (hi, lo) planes
+    // (nothing is split in LDS then: split_rows_x3's piece bookkeeping, which assumes whole rounds, is never used; launch_cfg refuses the other cases at run time)
+    constexpr bool PARTIAL_ROUND = (BM * (RB / 16)) % NTHR != 0 || (BN * (RB / 16)) % NTHR != 0;
+    static_assert(!PARTIAL_ROUND || ((X3 == 0 || X3 == 3) && EPI != TOC3D_EPI_CONV3X3), "tiles with a partial DMA round: plain operand loaders, or x3 on planes");
     constexpr int KS = RB / 32 / (int)sizeof(T);        // 32-wide K steps per K-tile
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
@@ -987,7 +989,7 @@ TOC3D_DEV void gemm_tile(const GemmArgs& a, const int m0, const int n0, char* sm
     // row's 32-k group (8 bytes each; reads precede writes inside the wave, so the conversion is in place).  The first form split every fragment in
     // registers in every wave that multiplied it: 204 VALU instructions per 24 MFMAs in the K loop (profiles/r03_x3_split.txt).
     auto split_rows_x3 = [&](int t) {
-        if constexpr (X3 == 3) {
+        if constexpr (X3 == 3 && !PARTIAL_ROUND) {
             char* slot = smem + (t % STAGES) * STAGE_BYTES;
             constexpr int CPR = RB / 16, PER = (BM + BN) * CPR / NTHR;      // the A tile and the W tile are contiguous: rows 0 .. BM + BN - 1 of RB bytes
             f32x4 v[PER];
@@ -1426,9 +1428,10 @@ void launch_cfg(const GemmArgs& a, hipStream_t s) {
                                   !(X3 == 3 && (EPI == TOC3D_EPI_SWIGLU_STATS || EPI == TOC3D_EPI_RESIDUAL_LN || EPI == TOC3D_EPI_RESIDUAL_STATS ||
                                                 EPI == TOC3D_EPI_SWIGLU_STATS_LN || EPI == TOC3D_EPI_QKV_ROPE)));   // ... and the bf16 x 3 forms of the ffn_ln and norm2 folds (f32 copies, f32 statistics)
     constexpr bool partial_round = (BM * (RB / 16)) % (64 * WM * WN) != 0 || (BN * (RB / 16)) % (64 * WM * WN) != 0;      // 96- / 160-row tiles
-    if constexpr (unsupported || (partial_round && (X3 != 0 || EPI == TOC3D_EPI_CONV3X3))) {
+    if constexpr (unsupported || (partial_round && ((X3 != 0 && X3 != 3) || EPI == TOC3D_EPI_CONV3X3))) {
         g_bad_variant = true;
     } else {
+        if (partial_round && X3 == 3 && !(a.a_planes && a.w_planes)) { g_bad_variant = true; return; }      // x3 on a 96- / 160-row tile: both operands must be planes (gemm_tile)
         constexpr int lds_fixed = STAGES * (BM + BN) * RB + (epi_ln_in(EPI) ? BM * 8 : 0);   // + the (mean, rstd) row table
         const int lds = lds_fixed + (epi_is_rope(EPI) && STAGES == 1 ? (a.rope_L * 256 + 1023) / 1024 * 1024 : 0);   // single buffer: + the RoPE tables (cos | sin), whole DMA instructions
         static Toc3dLdsAttr attr;          // > 64 KiB of dynamic LDS: raise the per-kernel limit once per device (thread-safe)
@@ -1610,6 +1613,13 @@ int launch_epi_x(int variant, GemmArgs a, hipStream_t s) {
         case 28: launch_cfg<float, EPI, 128, 128, 3, 128, 2, 4, 1, X>(a, s); break;
         case 49: launch_cfg<float, EPI, 192, 128, 2, 128, 2, 4, RO, X>(a, s); break;
         // phased big tiles on planes (round 6; gemm_phased_kernel, X3): both operands must be planes (TOC3D_DTYPE_F32X3P), K a multiple of 32
+        // M-tiles of 96 / 160 rows on planes (round 6: the N = 1024 residual GEMMs of the accelerated blocks make 176-392 tiles of 128 rows for 256 CUs; see the bf16 table)
+        case 54: if constexpr (X == 3) launch_cfg<float, EPI, 96, 128, 1, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 55: if constexpr (X == 3) launch_cfg<float, EPI, 96, 128, 2, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 56: if constexpr (X == 3) launch_cfg<float, EPI, 96, 128, 4, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 57: if constexpr (X == 3) launch_cfg<float, EPI, 160, 128, 1, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 58: if constexpr (X == 3) launch_cfg<float, EPI, 160, 128, 2, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
+        case 59: if constexpr (X == 3) launch_cfg<float, EPI, 192, 128, 3, 128, 2, 4, 1, X>(a, s); else return TOC3D_ERR_ARG; break;
         case 60: if constexpr (X == 3) launch_phased<EPI, 256, 256, 2, 4, true>(a, s); else return TOC3D_ERR_ARG; break;
         case 61: if constexpr (X == 3) launch_phased<EPI, 256, 128, 4, 2, true>(a, s); else return TOC3D_ERR_ARG; break;
         case 62: if constexpr (X == 3) launch_phased<EPI, 128, 256, 2, 4, true>(a, s); else return TOC3D_ERR_ARG; break;
